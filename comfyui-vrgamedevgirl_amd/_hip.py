@@ -1,0 +1,118 @@
+"""ctypes binding of libvrgdg_hip.so (the C ABI declared in include/vrgdg_hip.h).
+
+There is NO CPU fallback: if the library is missing, or no HIP device is visible, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
+
+VRG_OK = 0
+BORDER_REPLICATE, BORDER_ZERO = 0, 1
+STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
+STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN = 1, 2, 4, 8
+
+
+class NoiseDesc(C.Structure):
+    """vrg_noise_desc"""
+    _fields_ = [("seed0", C.c_uint64), ("seed_stride", C.c_uint64), ("offset0", C.c_uint64),
+                ("offset_stride", C.c_uint64), ("chunk0", C.c_int64), ("chunk_frames", C.c_int32),
+                ("grid_threads", C.c_uint32)]
+
+
+class ChainDesc(C.Structure):
+    """vrg_chain_desc"""
+    _fields_ = [("stages", C.c_int32), ("variant", C.c_int32),
+                ("intensity", C.c_float), ("sat", C.c_float), ("one_minus_sat", C.c_float),
+                ("noise", NoiseDesc),
+                ("lut", C.c_void_p), ("lut_size", C.c_int32),
+                ("domain_min", C.c_float * 3), ("domain_max", C.c_float * 3),
+                ("blend_mode", C.c_int32), ("blend", C.c_float), ("one_minus_blend", C.c_float),
+                ("img_ms", C.c_void_p), ("ref_ms", C.c_void_p), ("ref_frames", C.c_int32),
+                ("k", C.c_float), ("one_minus_k", C.c_float),
+                ("stencil_op", C.c_int32), ("border", C.c_int32), ("strength", C.c_float)]
+
+
+_F3 = C.c_float * 3
+_P = C.c_void_p
+_SIGNATURES = {
+    "vrg_abi_version": (C.c_int, []),
+    "vrg_error_string": (C.c_char_p, [C.c_int]),
+    "vrg_device_info": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "vrg_event_create": (C.c_int, [C.POINTER(_P)]),
+    "vrg_event_record": (C.c_int, [_P, _P]),
+    "vrg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "vrg_event_destroy": (C.c_int, [_P]),
+    "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
+    "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                C.POINTER(NoiseDesc), _P]),
+    "vrg_grain_injected_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P]),
+    "vrg_lut3d_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, _F3, _F3, C.c_int32, C.c_float,
+                                C.c_float, _P]),
+    "vrg_stencil3x3_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_float, _P]),
+    "vrg_lab_stats_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "vrg_colormatch_apply_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float,
+                                           C.c_float, _P]),
+    "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
+    "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library and attach the prototypes (no device needed)."""
+    import torch  # noqa: F401  -- FIRST: the HIP runtime must be the one torch loaded (same soname, shared streams/pointers)
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"libvrgdg_hip.so not found at {path}: build it with `python {os.path.join(PKG_DIR, 'build_ext.py')}` "
+            "(hipcc, gfx950). This package has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vrg_abi_version() != 1:
+        raise RuntimeError("libvrgdg_hip.so ABI version mismatch")
+    return lib
+
+
+def lib() -> C.CDLL:
+    """The loaded library, for launching kernels: also requires a visible HIP device."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                import torch
+                if not torch.cuda.is_available():
+                    raise RuntimeError("comfyui-vrgamedevgirl_amd needs an AMD GPU (MI355X / gfx950) visible to "
+                                       "PyTorch-ROCm; there is no CPU fallback")
+                _lib = load_library()
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != VRG_OK:
+        msg = lib().vrg_error_string(status).decode()
+        if status == 1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what}: {msg}")
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream() -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,374 @@
+// vrg_chain.hip -- Lab statistics (colour-match pass 1) and the fused grain -> LUT -> colour match ->
+// 3x3 sharpen chain.  gfx950 only.
+//
+// "pre" stages (grain, LUT, colour match) are pure per-pixel functions of the input pixel and its
+// absolute position; chain_pre() evaluates them for one pixel.  The fused kernels call it
+//   * once per pixel                      (point-wise chains: no sharpen stage),
+//   * once per tile+halo pixel into LDS   (chains ending in a 3x3 stencil),
+//   * once per pixel inside the reduction (statistics of the grain->LUT output).
+// That makes every fused result bit-identical to running the stand-alone kernels back to back.
+#include "vrg_common.hpp"
+
+namespace vrg {
+
+constexpr int STATS_BPF_MAX = 128;        // reduction blocks per frame (function of the frame size only)
+constexpr int STATS_PX_PER_BLOCK = 16384;
+
+__host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
+    int64_t b = (pixels + STATS_PX_PER_BLOCK - 1) / STATS_PX_PER_BLOCK;
+    return (int)(b < 1 ? 1 : (b > STATS_BPF_MAX ? STATS_BPF_MAX : b));
+}
+
+// grain -> LUT -> colour match for the pixel at (frame f of this call, pixel p of the frame).
+template <int STAGES>
+__device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3]) {
+    float v[3] = {xin[0], xin[1], xin[2]};
+    if (STAGES & VRG_STAGE_GRAIN) {
+        const int64_t chunk = f / D.noise.chunk_frames;
+        const int64_t fl = f - chunk * D.noise.chunk_frames;
+        const uint64_t li = (uint64_t)(fl * D.noise.frame_elems) + (uint64_t)p * 3u;
+        const uint64_t seed = chunk_seed(D.noise, chunk);
+        const uint64_t off = chunk_offset(D.noise, chunk);
+        float n[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, D.noise.G, li + c);
+        float g[3];
+        grain_pixel(v, n, D.I, D.S, D.T, g);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    if (STAGES & VRG_STAGE_LUT) {
+        float g[3];
+        lut_pixel(D.lut, v, g);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    if (STAGES & VRG_STAGE_COLORMATCH) {
+        const float* ims = D.cm.img_ms + f * 6;
+        const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
+        float g[3];
+        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+}
+
+// ----------------------------------------------------------------------------------------------
+// Point-wise chain (no sharpen): one pixel per thread.
+// ----------------------------------------------------------------------------------------------
+template <int STAGES>
+__global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__ in, px3* __restrict__ out, int32_t ppf, ChainK D) {
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= ppf) return;
+    const int64_t f = blockIdx.y;
+    const px3 v = in[f * ppf + p];
+    const float x[3] = {v.r, v.g, v.b};
+    float o[3];
+    chain_pre<STAGES>(D, f, p, x, o);
+    out[f * ppf + p] = px3{o[0], o[1], o[2]};
+}
+
+// ----------------------------------------------------------------------------------------------
+// Chain ending in a 3x3 stencil: 32x64-pixel tile per 256-thread block; the pre-stage result of the
+// tile plus a one-pixel halo is staged in LDS as three planes (conflict-free row reads), then every
+// thread produces 8 output pixels.  Halo recompute: (34*66)/(32*64) = 1.096x.
+// ----------------------------------------------------------------------------------------------
+constexpr int TILE_H = 32, TILE_W = 64;
+constexpr int HALO_H = TILE_H + 2, HALO_W = TILE_W + 2;
+constexpr int LDS_PITCH = HALO_W + 1;
+
+template <int STAGES>
+__global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
+                                                     int32_t tiles_x, ChainK D) {
+    __shared__ float tile[3][HALO_H][LDS_PITCH];
+    const int32_t ty0 = (blockIdx.x / tiles_x) * TILE_H;
+    const int32_t tx0 = (blockIdx.x % tiles_x) * TILE_W;
+    const int64_t f = blockIdx.y;
+    const int32_t ppf = H * W;
+    const px3* fin = in + f * ppf;
+    const bool zero = D.zero_border != 0;
+
+    for (int i = threadIdx.x; i < HALO_H * HALO_W; i += 256) {
+        const int hy = i / HALO_W, hx = i - hy * HALO_W;
+        int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const bool inside = (y >= 0) && (y < H) && (x >= 0) && (x < W);
+        float o[3] = {0.0f, 0.0f, 0.0f};
+        // pixels right/below the frame that only pad the last tiles are never read by a valid output
+        // except through the border rule, which is coordinate clamping (replicate) or zero.
+        if (inside || !zero) {
+            y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+            x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+            const int32_t p = y * W + x;
+            const px3 v = fin[p];
+            const float xi[3] = {v.r, v.g, v.b};
+            chain_pre<STAGES>(D, f, p, xi, o);
+        }
+        tile[0][hy][hx] = o[0];
+        tile[1][hy][hx] = o[1];
+        tile[2][hy][hx] = o[2];
+    }
+    __syncthreads();
+    px3* fout = out + f * ppf;
+    for (int i = threadIdx.x; i < TILE_H * TILE_W; i += 256) {
+        const int ly = i / TILE_W, lx = i - ly * TILE_W;
+        const int y = ty0 + ly, x = tx0 + lx;
+        if (y >= H || x >= W) continue;
+        float o[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) p[dy][dx] = tile[c][ly + dy][lx + dx];
+            o[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
+        }
+        fout[y * W + x] = px3{o[0], o[1], o[2]};
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Lab statistics.  Per (frame, channel): n, mean, M2 in fp64.  Stage 1: each block reduces a
+// contiguous slice of the frame's pixels to six fp64 sums of (lab - pivot), (lab - pivot)^2, where
+// pivot = Lab of the frame's first pixel (kills the cancellation of near-constant frames);
+// wave64 DPP-free shuffle tree -> LDS -> one partial per block.  Stage 2: one wave per frame adds
+// the partials in a fixed order.  No atomics: the result is deterministic and independent of how
+// many frames a call covers (the block count depends on the frame size only).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
+                                                       double* __restrict__ partials) {
+    __shared__ double red[4][6];
+    const int64_t f = blockIdx.y;
+    const px3* fin = in + f * ppf;
+    float pivot[3];
+    {
+        const px3 v0 = fin[0];
+        const float x0[3] = {v0.r, v0.g, v0.b};
+        float pre[3];
+        chain_pre<STAGES>(D, f, 0, x0, pre);
+        rgb_to_lab(pre, pivot);
+    }
+    const int32_t per = (ppf + bpf - 1) / bpf;
+    const int32_t lo = blockIdx.x * per;
+    const int32_t hi = lo + per < ppf ? lo + per : ppf;
+    double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
+    for (int32_t p = lo + threadIdx.x; p < hi; p += 256) {
+        const px3 v = fin[p];
+        const float x[3] = {v.r, v.g, v.b};
+        float pre[3], lab[3];
+        chain_pre<STAGES>(D, f, p, x, pre);
+        rgb_to_lab(pre, lab);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double d = (double)lab[c] - (double)pivot[c];
+            s1[c] += d;
+            s2[c] += d * d;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double a = wave_sum(s1[c]);
+        const double b = wave_sum(s2[c]);
+        if (lane == 0) { red[wave][c] = a; red[wave][3 + c] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const double t = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        partials[(f * bpf + blockIdx.x) * 6 + threadIdx.x] = t;
+    }
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(64) void k_lab_merge(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
+                                                   const double* __restrict__ partials, double* __restrict__ stats) {
+    const int64_t f = blockIdx.x;
+    float pivot[3];
+    {
+        const px3 v0 = in[f * ppf];
+        const float x0[3] = {v0.r, v0.g, v0.b};
+        float pre[3];
+        chain_pre<STAGES>(D, f, 0, x0, pre);
+        rgb_to_lab(pre, pivot);
+    }
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = 0; b < bpf; ++b) {
+            s1 += partials[(f * bpf + b) * 6 + c];
+            s2 += partials[(f * bpf + b) * 6 + 3 + c];
+        }
+        const double n = (double)ppf;
+        const double dm = s1 / n;
+        double m2 = s2 - s1 * dm;
+        if (m2 < 0.0) m2 = 0.0;
+        stats[(f * 3 + c) * 3 + 0] = n;
+        stats[(f * 3 + c) * 3 + 1] = (double)pivot[c] + dm;
+        stats[(f * 3 + c) * 3 + 2] = m2;
+    }
+}
+
+// {n, mean, M2} fp64 -> {mean, std_unbiased + 1e-5} fp32 (nodes.py:99-100: .std() is unbiased; n == 1 -> NaN like torch)
+__global__ void k_stats_finalize(const double* __restrict__ stats, float* __restrict__ ms, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const double n = stats[i * 3], mean = stats[i * 3 + 1], m2 = stats[i * 3 + 2];
+    const float sd = (float)__builtin_sqrt(m2 / (n - 1.0));
+    ms[i * 2] = (float)mean;
+    ms[i * 2 + 1] = sd + 1e-5f;
+}
+
+template <int STAGES>
+static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, const ChainK& D, double* stats, void* scratch,
+                        hipStream_t st) {
+    const int64_t ppf = (int64_t)H * W;
+    const int bpf = stats_blocks_per_frame(ppf);
+    double* partials = reinterpret_cast<double*>(scratch);
+    for (int64_t f0 = 0; f0 < frames; f0 += 32768) {
+        const int64_t nf = frames - f0 < 32768 ? frames - f0 : 32768;
+        ChainK d = D;
+        if (STAGES & VRG_STAGE_GRAIN) {
+            if (f0 % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
+            d.noise.chunk0 += f0 / D.noise.chunk_frames;
+        }
+        const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
+        hipLaunchKernelGGL(k_lab_partials<STAGES>, dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
+                           partials + f0 * bpf * 6);
+        hipLaunchKernelGGL(k_lab_merge<STAGES>, dim3((uint32_t)nf), dim3(64), 0, st, src, (int32_t)ppf, bpf, d,
+                           partials + f0 * bpf * 6, stats + f0 * 9);
+        if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
+    }
+    return VRG_OK;
+}
+
+template <int STAGES>
+static int launch_chain(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, bool sharpen,
+                        hipStream_t st) {
+    const int64_t ppf = (int64_t)H * W;
+    for (int64_t f0 = 0; f0 < frames; f0 += 32768) {
+        const int64_t nf = frames - f0 < 32768 ? frames - f0 : 32768;
+        ChainK d = D;
+        if (STAGES & VRG_STAGE_GRAIN) {
+            if (f0 % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
+            d.noise.chunk0 += f0 / D.noise.chunk_frames;
+        }
+        if (STAGES & VRG_STAGE_COLORMATCH) {
+            if (D.cm.ref_frames != 1 && (f0 % D.cm.ref_frames)) return VRG_ERR_UNSUPPORTED;
+            d.cm.img_ms += f0 * 6;
+        }
+        const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
+        px3* dst = reinterpret_cast<px3*>(out) + f0 * ppf;
+        if (sharpen) {
+            const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H;
+            hipLaunchKernelGGL(k_chain_tile<STAGES>, dim3((uint32_t)(tx * ty), (uint32_t)nf), dim3(256), 0, st, src, dst, H, W, tx, d);
+        } else {
+            hipLaunchKernelGGL(k_chain_pointwise<STAGES>, dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st, src,
+                               dst, (int32_t)ppf, d);
+        }
+        if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
+    }
+    return VRG_OK;
+}
+
+static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) {
+    D = ChainK{};
+    D.stages = d->stages;
+    if (d->stages & VRG_STAGE_GRAIN) {
+        if (d->noise.chunk_frames < 1 || d->noise.grid_threads == 0 || (d->noise.grid_threads % 256u)) return VRG_ERR_BAD_ARG;
+        if ((int64_t)d->noise.chunk_frames * H * W * 3 > 0x7fffffffll) return VRG_ERR_UNSUPPORTED;
+        D.I = d->intensity; D.S = d->sat; D.T = d->one_minus_sat;
+        D.noise = make_noise(&d->noise, (int64_t)H * W * 3);
+    }
+    if (d->stages & VRG_STAGE_LUT) {
+        if (!d->lut || d->lut_size < 2 || (d->blend_mode != 1 && d->blend_mode != 2)) return VRG_ERR_BAD_ARG;
+        D.lut = make_lut(d->lut, d->lut_size, d->domain_min, d->domain_max, d->blend_mode, d->blend, d->one_minus_blend);
+    }
+    if (d->stages & VRG_STAGE_COLORMATCH) {
+        D.cm = CmK{d->img_ms, d->ref_ms, d->ref_frames, d->k, d->one_minus_k};
+    }
+    if (d->stages & VRG_STAGE_SHARPEN) {
+        if (d->stencil_op < 0 || d->stencil_op > 2 || d->border < 0 || d->border > 1) return VRG_ERR_BAD_ARG;
+        D.stencil_op = d->stencil_op; D.zero_border = d->border == VRG_BORDER_ZERO; D.strength = d->strength;
+    }
+    return VRG_OK;
+}
+
+}  // namespace vrg
+
+using namespace vrg;
+
+#define VRG_DISPATCH_PRE(STG, CALL)                       \
+    switch ((STG) & 7) {                                  \
+        case 0: return CALL(0);                           \
+        case 1: return CALL(1);                           \
+        case 2: return CALL(2);                           \
+        case 3: return CALL(3);                           \
+        case 4: return CALL(4);                           \
+        case 5: return CALL(5);                           \
+        case 6: return CALL(6);                           \
+        default: return CALL(7);                          \
+    }
+
+extern "C" {
+
+int64_t vrg_lab_stats_scratch_bytes(int64_t frames) { return frames < 0 ? 0 : frames * STATS_BPF_MAX * 6 * (int64_t)sizeof(double); }
+
+int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, double* stats, void* scratch, void* stream) {
+    if (!in || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if ((int64_t)height * width > 0x7fffffff) return VRG_ERR_UNSUPPORTED;
+    ChainK D{};
+    return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+}
+
+int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames, void* stream) {
+    if (!stats || !mean_std || frames < 0) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    const int64_t count = frames * 3;
+    hipLaunchKernelGGL(k_stats_finalize, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, mean_std,
+                       count);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc, double* stats,
+                        void* scratch, void* stream) {
+    if (!in || !desc || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
+    vrg_chain_desc pre = *desc;
+    pre.stages &= (VRG_STAGE_GRAIN | VRG_STAGE_LUT);   // statistics are taken on the colour-match *input*
+    ChainK D;
+    const int rc = fill_chain(&pre, height, width, D);
+    if (rc) return rc;
+    switch (pre.stages & 3) {
+        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+    }
+}
+
+int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc,
+                        void* stream) {
+    if (!in || !out || !desc || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (desc->stages == 0 || (desc->stages & ~15)) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
+    if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
+    if (desc->variant != 0) return VRG_ERR_UNSUPPORTED;
+    ChainK D;
+    const int rc = fill_chain(desc, height, width, D);
+    if (rc) return rc;
+    const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
+#define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
+    VRG_DISPATCH_PRE(desc->stages, CALL)
+#undef CALL
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// vrg_common.hpp -- kernel-side parameter blocks shared by the translation units of libvrgdg_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vrgdg_hip.h"
+#include "vrg_pixel_math.hpp"
+
+namespace vrg {
+
+// one RGB pixel; 4-byte aligned so that a load/store is a single global_*_dwordx3
+struct __attribute__((packed, aligned(4))) px3 { float r, g, b; };
+
+// Device copy of vrg_noise_desc plus the per-call geometry the noise mapping needs.
+struct NoiseK {
+    uint64_t seed0, seed_stride, off0, off_stride;
+    int64_t chunk0;
+    int64_t frame_elems;   // H*W*3
+    int32_t chunk_frames;
+    uint32_t G;
+};
+
+VRG_HD uint64_t chunk_seed(const NoiseK& n, int64_t chunk_rel) { return n.seed0 + (uint64_t)(n.chunk0 + chunk_rel) * n.seed_stride; }
+VRG_HD uint64_t chunk_offset(const NoiseK& n, int64_t chunk_rel) { return n.off0 + (uint64_t)(n.chunk0 + chunk_rel) * n.off_stride; }
+
+struct CmK {
+    const float* img_ms;   // [frames][3][2]
+    const float* ref_ms;   // [ref_frames][3][2]
+    int32_t ref_frames;
+    float K, T;
+};
+
+struct ChainK {
+    int32_t stages;
+    float I, S, T;
+    NoiseK noise;
+    LutParams lut;
+    CmK cm;
+    int32_t stencil_op, zero_border;
+    float strength;
+};
+
+inline NoiseK make_noise(const vrg_noise_desc* d, int64_t frame_elems) {
+    NoiseK n;
+    n.seed0 = d->seed0; n.seed_stride = d->seed_stride; n.off0 = d->offset0; n.off_stride = d->offset_stride;
+    n.chunk0 = d->chunk0; n.frame_elems = frame_elems; n.chunk_frames = d->chunk_frames; n.G = d->grid_threads;
+    return n;
+}
+
+inline LutParams make_lut(const float* table, int n, const float dmin[3], const float dmax[3], int blend_mode,
+                          float blend, float one_minus_blend) {
+    LutParams P;
+    P.table = table; P.n = n; P.top = (float)(n - 1);
+    P.unit_domain = 1;
+    for (int c = 0; c < 3; ++c) {
+        P.dmin[c] = dmin[c];
+        const float span = dmax[c] - dmin[c];
+        P.span[c] = span < 1e-6f ? 1e-6f : span;   // torch.clamp(domain_max - domain_min, min=1e-6)
+        if (!(P.dmin[c] == 0.0f && P.span[c] == 1.0f)) P.unit_domain = 0;
+    }
+    P.blend_mode = blend_mode; P.blend = blend; P.one_minus_blend = one_minus_blend;
+    return P;
+}
+
+#define VRG_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e_ = hipGetLastError();                   \
+        if (e_ != hipSuccess) return VRG_ERR_LAUNCH;         \
+    } while (0)
+
+}  // namespace vrg

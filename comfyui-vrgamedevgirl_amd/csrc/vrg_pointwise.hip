@@ -1,0 +1,288 @@
+// vrg_pointwise.hip -- stand-alone per-pixel kernels: noise stream, film grain, 3D LUT, colour-match
+// apply.  gfx950 only.  Every kernel is HBM-streaming: consecutive lanes touch consecutive addresses
+// (12 B/lane pixel records or 16 B/lane element quads), nothing is re-read from HBM.
+#include "vrg_common.hpp"
+
+namespace vrg {
+
+// ----------------------------------------------------------------------------------------------
+// Raw torch.randn stream.  One thread = one (chunk, call k, subsequence idx): one Philox call, four
+// normals, written to the four elements idx + G*(4k+ii) -- the same thread/element relation as
+// ATen's distribution_elementwise_grid_stride_kernel, so the Philox work is the minimum possible.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_noise(float* __restrict__ out, NoiseK nk, int64_t chunk_numel,
+                                                uint32_t groups_per_chunk /* K = ceil(numel/(4G)) */) {
+    const uint32_t G = nk.G;
+    const uint32_t blocks_per_group = (G + 255u) / 256u;
+    const uint32_t bpc = blocks_per_group * groups_per_chunk;
+    const int64_t chunk = blockIdx.x / bpc;
+    const uint32_t rem = blockIdx.x - (uint32_t)chunk * bpc;
+    const uint32_t k = rem / blocks_per_group;
+    const uint32_t idx = (rem - k * blocks_per_group) * 256u + threadIdx.x;
+    if (idx >= G) return;
+    const uint64_t seed = chunk_seed(nk, chunk);
+    const uint64_t ctr = (chunk_offset(nk, chunk) >> 2) + k;
+    const u32x4 r = philox_for(seed, idx, ctr);
+    const f32x2 a = box_muller(r.x, r.y);
+    const f32x2 b = box_muller(r.z, r.w);
+    const float n[4] = {a.x, a.y, b.x, b.y};
+    float* base = out + chunk * chunk_numel;
+    const int64_t li0 = (int64_t)4 * G * k + idx;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int64_t li = li0 + (int64_t)G * ii;
+        if (li < chunk_numel) base[li] = n[ii];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Film grain with in-register noise.  Block = 256 threads = 1024 consecutive Philox subsequences
+// (4 per thread) of one call k of one chunk: 1024 Philox calls feed the 4096 elements
+// {idx + G*(4k+ii)}.  Each element also needs the raw normal of its pixel's green element, which is
+// the element itself or its left/right neighbour: the normals are exchanged through LDS, and the two
+// neighbours outside the block's range (per sibling range) are produced by the general per-element
+// routine on 8 lanes.
+// ----------------------------------------------------------------------------------------------
+constexpr int GRAIN_IPT = 4;                    // subsequences per thread
+constexpr int GRAIN_N = 256 * GRAIN_IPT;        // subsequences per block
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_grain(const float* __restrict__ in, float* __restrict__ out, NoiseK nk,
+                                                int64_t chunk_numel, uint32_t groups_per_chunk, float I, float S, float T) {
+    __shared__ float sn[4][GRAIN_N + 8];
+    const uint32_t G = nk.G;
+    const uint32_t blocks_per_group = (G + GRAIN_N - 1) / GRAIN_N;
+    const uint32_t bpc = blocks_per_group * groups_per_chunk;
+    const int64_t chunk = blockIdx.x / bpc;
+    const uint32_t rem = blockIdx.x - (uint32_t)chunk * bpc;
+    const uint32_t k = rem / blocks_per_group;
+    const uint32_t idx_base = (rem - k * blocks_per_group) * GRAIN_N;
+    const uint32_t valid_n = (G - idx_base) < (uint32_t)GRAIN_N ? (G - idx_base) : (uint32_t)GRAIN_N;
+    const uint32_t t4 = threadIdx.x * GRAIN_IPT;
+    const uint64_t seed = chunk_seed(nk, chunk);
+    const uint64_t off = chunk_offset(nk, chunk);
+    const uint64_t ctr = (off >> 2) + k;
+
+    float nz[GRAIN_IPT][4];
+#pragma unroll
+    for (int j = 0; j < GRAIN_IPT; ++j) {
+        const u32x4 r = philox_for(seed, idx_base + t4 + j, ctr);
+        const f32x2 a = box_muller(r.x, r.y);
+        const f32x2 b = box_muller(r.z, r.w);
+        nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = b.x; nz[j][3] = b.y;
+    }
+    if (t4 < valid_n) {   // valid_n is a multiple of 4 whenever G is (G = grid*256)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            float4 v = make_float4(nz[0][ii], nz[1][ii], nz[2][ii], nz[3][ii]);
+            *reinterpret_cast<float4*>(&sn[ii][4 + t4]) = v;
+        }
+    }
+    const int64_t group_base = (int64_t)4 * G * k + idx_base;   // chunk-local element of (ii=0, first idx)
+    if (threadIdx.x < 8) {
+        const int ii = threadIdx.x >> 1;
+        const int right = threadIdx.x & 1;
+        const int64_t li = group_base + (int64_t)G * ii + (right ? (int64_t)valid_n : -1);
+        float v = 0.0f;
+        if (li >= 0 && li < chunk_numel) v = torch_randn_element(seed, off, G, (uint64_t)li);
+        sn[ii][right ? 4 + valid_n : 3] = v;
+    }
+    __syncthreads();
+    if (t4 >= valid_n) return;
+
+    const float* cin = in + chunk * chunk_numel;
+    float* cout = out + chunk * chunk_numel;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int64_t li0 = group_base + (int64_t)G * ii + t4;
+        if (li0 >= chunk_numel) continue;
+        float x[4], o[4];
+        const bool full = li0 + 3 < chunk_numel;
+        if (VEC && full) {
+            const float4 v = *reinterpret_cast<const float4*>(cin + li0);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (li0 + j < chunk_numel) ? cin[li0 + j] : 0.0f;
+        }
+        int c = (int)((uint32_t)li0 % 3u);   // chunk_numel < 2^31 (checked by the entry point)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ng = sn[ii][4 + t4 + j + 1 - c];   // c==1: itself
+            o[j] = grain_element(x[j], nz[j][ii], ng, c, I, S, T);
+            c = (c == 2) ? 0 : c + 1;
+        }
+        if (VEC && full) {
+            *reinterpret_cast<float4*>(cout + li0) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (li0 + j < chunk_numel) cout[li0 + j] = o[j];
+        }
+    }
+}
+
+// Noise-injection form: out = grain(x, noise) with caller-supplied normals (one pixel per thread).
+__global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ in, const px3* __restrict__ nz,
+                                                         px3* __restrict__ out, int64_t pixels, float I, float S, float T) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= pixels) return;
+    const px3 v = in[p];
+    const px3 n = nz[p];
+    const float x[3] = {v.r, v.g, v.b};
+    const float nn[3] = {n.r, n.g, n.b};
+    float o[3];
+    grain_pixel(x, nn, I, S, T, o);
+    out[p] = px3{o[0], o[1], o[2]};
+}
+
+// ----------------------------------------------------------------------------------------------
+// 3D LUT.  One pixel per thread; the table (<= 431 KB for 33^3) lives in global memory and is served
+// by the vector L1 / per-XCD L2 (it does not fit the 160 KB LDS in fp32 -- SURVEY.md section 7).
+// ----------------------------------------------------------------------------------------------
+template <bool RGB_ONLY>
+__global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, float* __restrict__ out, int64_t pixels,
+                                                int channels, LutParams P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= pixels) return;
+    float x[3], o[3];
+    if (RGB_ONLY) {
+        const px3 v = reinterpret_cast<const px3*>(in)[p];
+        x[0] = v.r; x[1] = v.g; x[2] = v.b;
+    } else {
+        const float* s = in + p * channels;
+        x[0] = s[0]; x[1] = s[1]; x[2] = s[2];
+    }
+    lut_pixel(P, x, o);
+    if (RGB_ONLY) {
+        reinterpret_cast<px3*>(out)[p] = px3{o[0], o[1], o[2]};
+    } else {
+        float* d = out + p * channels;
+        d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+        const float* s = in + p * channels;
+        for (int c = 3; c < channels; ++c) d[c] = s[c];   // image.clone() pass-through (IV_Adjustments.py:341-343)
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Colour-match apply (pass 2).  ms arrays: [frame][3][2] = {mean, std + 1e-5}.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict__ in, px3* __restrict__ out,
+                                                           int32_t pixels_per_frame, CmK cm) {
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= pixels_per_frame) return;
+    const int64_t f = blockIdx.y;
+    const int64_t at = f * pixels_per_frame + p;
+    const px3 v = in[at];
+    const float x[3] = {v.r, v.g, v.b};
+    const float* ims = cm.img_ms + f * 6;
+    const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
+    float o[3];
+    colormatch_pixel(x, ims, rms, cm.K, cm.T, o);
+    out[at] = px3{o[0], o[1], o[2]};
+}
+
+}  // namespace vrg
+
+using namespace vrg;
+
+extern "C" {
+
+int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems, const vrg_noise_desc* nd, void* stream) {
+    if (!out || !nd || frames < 0 || frame_elems <= 0 || nd->chunk_frames < 1 || nd->grid_threads == 0 ||
+        (nd->grid_threads % 256u) != 0)
+        return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if (frames % nd->chunk_frames != 0) return VRG_ERR_BAD_ARG;
+    const int64_t chunks = frames / nd->chunk_frames;
+    const int64_t numel = (int64_t)nd->chunk_frames * frame_elems;
+    const NoiseK nk = make_noise(nd, frame_elems);
+    const uint64_t groups = (uint64_t)((numel + 4 * (int64_t)nk.G - 1) / (4 * (int64_t)nk.G));
+    const uint64_t blocks = (uint64_t)chunks * groups * ((nk.G + 255u) / 256u);
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_noise, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, out, nk, numel, (uint32_t)groups);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
+                  float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+    if (!in || !out || !nd || frames < 0 || height <= 0 || width <= 0 || nd->chunk_frames < 1 || nd->grid_threads == 0 ||
+        (nd->grid_threads % 256u) != 0)
+        return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if (frames % nd->chunk_frames != 0) return VRG_ERR_BAD_ARG;
+    const int64_t frame_elems = (int64_t)height * width * 3;
+    const int64_t chunks = frames / nd->chunk_frames;
+    const int64_t numel = (int64_t)nd->chunk_frames * frame_elems;
+    if (numel > 0x7fffffffll) return VRG_ERR_UNSUPPORTED;   // torch itself splits randn above INT32 indexing
+    const NoiseK nk = make_noise(nd, frame_elems);
+    const uint64_t groups = (uint64_t)((numel + 4 * (int64_t)nk.G - 1) / (4 * (int64_t)nk.G));
+    const uint64_t blocks = (uint64_t)chunks * groups * ((nk.G + GRAIN_N - 1) / GRAIN_N);
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    // float4 path needs every chunk base and G*ii offsets 16-byte aligned
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (numel % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_grain<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
+                           (uint32_t)groups, intensity, sat, one_minus_sat);
+    else
+        hipLaunchKernelGGL(k_grain<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
+                           (uint32_t)groups, intensity, sat, one_minus_sat);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels, float intensity, float sat,
+                           float one_minus_sat, void* stream) {
+    if (!in || !noise || !out || pixels < 0) return VRG_ERR_BAD_ARG;
+    if (pixels == 0) return VRG_OK;
+    const uint64_t blocks = (uint64_t)(pixels + 255) / 256;
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_grain_injected, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const px3*>(in), reinterpret_cast<const px3*>(noise), reinterpret_cast<px3*>(out), pixels,
+                       intensity, sat, one_minus_sat);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels, const float* lut, int32_t lut_size,
+                  const float domain_min[3], const float domain_max[3], int32_t blend_mode, float blend, float one_minus_blend,
+                  void* stream) {
+    if (!in || !out || !lut || !domain_min || !domain_max || pixels < 0 || channels < 3 || lut_size < 2 ||
+        (blend_mode != 1 && blend_mode != 2))
+        return VRG_ERR_BAD_ARG;
+    if (pixels == 0) return VRG_OK;
+    const LutParams P = make_lut(lut, lut_size, domain_min, domain_max, blend_mode, blend, one_minus_blend);
+    const uint64_t blocks = (uint64_t)(pixels + 255) / 256;
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    if (channels == 3)
+        hipLaunchKernelGGL(k_lut3d<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, pixels, channels, P);
+    else
+        hipLaunchKernelGGL(k_lut3d<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, pixels, channels, P);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, const float* img_ms,
+                             const float* ref_ms, int32_t ref_frames, float k, float one_minus_k, void* stream) {
+    if (!in || !out || !img_ms || !ref_ms || frames < 0 || height <= 0 || width <= 0 || ref_frames < 1) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    const int64_t ppf = (int64_t)height * width;
+    if (ppf > 0x7fffffff) return VRG_ERR_UNSUPPORTED;
+    CmK cm{img_ms, ref_ms, ref_frames, k, one_minus_k};
+    const uint32_t bx = (uint32_t)((ppf + 255) / 256);
+    for (int64_t f0 = 0; f0 < frames; f0 += 32768) {
+        const int64_t nf = frames - f0 < 32768 ? frames - f0 : 32768;
+        CmK c = cm;
+        c.img_ms = img_ms + f0 * 6;
+        // ref frame index uses f % ref_frames relative to the call start; 32768 is a multiple of any
+        // chunk size only if ref_frames divides it -- keep the mapping exact by offsetting explicitly.
+        if (ref_frames != 1 && (f0 % ref_frames) != 0) return VRG_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_colormatch_apply, dim3(bx, (uint32_t)nf), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const px3*>(in) + f0 * ppf, reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c);
+        VRG_CHECK_LAUNCH();
+    }
+    return VRG_OK;
+}
+
+}  // extern "C"

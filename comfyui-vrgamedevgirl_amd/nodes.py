@@ -1,0 +1,175 @@
+"""ComfyUI node classes of the per-pixel video post-processing path, MI355X-native.
+
+Operator surface (mapping keys, INPUT_TYPES widget specs, RETURN_TYPES, FUNCTION, CATEGORY, DESCRIPTION,
+argument names and order) is the reference's -- nodes.py:18-384 and :1881-1933 there -- so these classes
+drop into any existing graph.  The bodies only move frames and call the HIP operators in ``ops``.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from . import ops
+from ._devices import compute_device, frame_groups, intermediate_device
+
+_IMAGE = ("IMAGE",)
+
+
+def _float_widget(default, lo, hi, step):
+    return ("FLOAT", {"default": default, "min": lo, "max": hi, "step": step})
+
+
+def _frames_bytes(images: torch.Tensor) -> int:
+    return int(images[0].numel()) * 4 if images.shape[0] else 0
+
+
+def _run_grouped(images, fn, multiple_of=1):
+    """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame)` returns GPU frames."""
+    dev = compute_device()
+    out_dev = intermediate_device()
+    if images.is_cuda:
+        return fn(images.to(dev), 0).to(out_dev)
+    if images.dtype != torch.float32:
+        images = images.float()
+    pieces = []
+    for s, e in frame_groups(images.shape[0], _frames_bytes(images), multiple_of):
+        pieces.append(fn(images[s:e].to(dev), s).to(out_dev))
+    if not pieces:
+        return torch.empty_like(images, device=out_dev)
+    return pieces[0] if len(pieces) == 1 else torch.cat(pieces, dim=0)
+
+
+class FastFilmGrain:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {"required": {
+            "images": _IMAGE,
+            "grain_intensity": _float_widget(0.04, 0.001, 1.0, 0.001),
+            "saturation_mix": _float_widget(0.5, 0.0, 1.0, 0.01),
+            "batch_size": ("INT", {"default": 4, "min": 0, "max": 500, "step": 1}),
+        }}
+
+    RETURN_TYPES = _IMAGE
+    FUNCTION = "apply_grain"
+    CATEGORY = "video/enhancement"
+    DESCRIPTION = "Adds lightweight film grain"
+
+    def apply_grain(self, images, grain_intensity, saturation_mix, batch_size):
+        # `batch_size` frames share one torch.randn draw from the device's global generator, exactly like
+        # the reference's chunk loop; 0 means one draw for the whole batch.
+        step = batch_size if batch_size > 0 else max(int(images.shape[0]), 1)
+
+        def run(gpu_frames, _first):
+            return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step)
+
+        return (_run_grouped(images, run, multiple_of=step),)
+
+
+class ColorMatchToReference:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {"required": {
+            "images": _IMAGE,
+            "reference_image": _IMAGE,
+            "match_strength": _float_widget(1.0, 0.0, 1.0, 0.01),
+            "batch_size": ("INT", {"default": 1, "min": 1, "max": 500, "step": 1}),
+        }}
+
+    RETURN_TYPES = _IMAGE
+    FUNCTION = "match_color"
+    CATEGORY = "video/enhancement"
+    DESCRIPTION = "Matches the color tone of input image to a reference image using LAB mean/std alignment"
+
+    def match_color(self, images, reference_image, match_strength, batch_size):
+        dev = compute_device()
+        ref = reference_image.to(device=dev, dtype=torch.float32)
+        n_ref = int(ref.shape[0])
+        frames = int(images.shape[0])
+        if n_ref != 1:
+            # the reference broadcasts [n_ref,3,1,1] statistics against every batch_size chunk
+            sizes = {min(batch_size, frames - i) for i in range(0, frames, batch_size)}
+            if sizes != {n_ref}:
+                bad = next(iter(sizes - {n_ref}))
+                raise RuntimeError(f"The size of tensor a ({bad}) must match the size of tensor b ({n_ref}) at "
+                                   "non-singleton dimension 0")
+        ref_ms = ops.finalize_stats(ops.lab_stats(ref))
+
+        def run(gpu_frames, _first):
+            return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms)
+
+        return (_run_grouped(images, run, multiple_of=n_ref if n_ref != 1 else 1),)
+
+
+class _Sharpen:
+    _OP = ""
+    _MAX = 2.0
+    _RGB_ONLY_ON_GPU_FLAG = True
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {"required": {
+            "images": _IMAGE,
+            "strength": _float_widget(0.5, 0.0, cls._MAX, 0.01),
+            "use_gpu": ("BOOLEAN", {"default": False}),
+        }}
+
+    RETURN_TYPES = _IMAGE
+    CATEGORY = "video/enhancement"
+
+    def _apply(self, images: torch.Tensor, strength: float, use_gpu: bool) -> Tuple[torch.Tensor]:
+        # use_gpu selects the reference's *border / sign semantics* (False: edge-replicate numpy path,
+        # True: zero-padded avg_pool2d / conv2d path); both run on the MI355X here.
+        if use_gpu and self._RGB_ONLY_ON_GPU_FLAG and images.shape[-1] != 3:
+            raise RuntimeError(f"Given groups=3, expected input to have 3 channels, but got {images.shape[-1]} channels instead")
+
+        def run(gpu_frames, _first):
+            return ops.stencil3x3(gpu_frames, self._OP, strength, zero_border=bool(use_gpu))
+
+        return (_run_grouped(images, run),)
+
+
+class FastUnsharpSharpen(_Sharpen):
+    _OP = "unsharp"
+    _MAX = 10.0
+    _RGB_ONLY_ON_GPU_FLAG = False
+    FUNCTION = "apply_unsharp"
+    DESCRIPTION = "Unsharp mask (CPU default, optional GPU path)."
+
+    def apply_unsharp(self, images, strength, use_gpu):
+        return self._apply(images, strength, use_gpu)
+
+
+class FastLaplacianSharpen(_Sharpen):
+    _OP = "laplacian"
+    FUNCTION = "apply_laplacian"
+    DESCRIPTION = "Laplacian sharpen (CPU default, optional GPU)."
+
+    def apply_laplacian(self, images, strength, use_gpu):
+        return self._apply(images, strength, use_gpu)
+
+
+class FastSobelSharpen(_Sharpen):
+    _OP = "sobel"
+    FUNCTION = "apply_sobel"
+    DESCRIPTION = "Sobel sharpen (CPU default, optional GPU)."
+
+    def apply_sobel(self, images, strength, use_gpu):
+        return self._apply(images, strength, use_gpu)
+
+
+NODE_CLASS_MAPPINGS = {
+    "FastFilmGrain": FastFilmGrain,
+    "ColorMatchToReference": ColorMatchToReference,
+    "FastUnsharpSharpen": FastUnsharpSharpen,
+    "FastLaplacianSharpen": FastLaplacianSharpen,
+    "FastSobelSharpen": FastSobelSharpen,
+}
+
+NODE_DISPLAY_NAME_MAPPINGS = {
+    "FastFilmGrain": "\U0001F39E\uFE0F Fast Film Grain",
+    "ColorMatchToReference": "\U0001F3A8 Color Match To Reference",
+    "FastUnsharpSharpen": "\U0001F3AF Fast Unsharp Sharpen",
+    "FastLaplacianSharpen": "\U0001F300 Fast Laplacian Sharpen",
+    "FastSobelSharpen": "\U0001F4CF Fast Sobel Sharpen",
+}

@@ -1,0 +1,407 @@
+"""Tensor-level operators over device-resident fp32 ``[F, H, W, C]`` frames.
+
+Each function enqueues hand-written HIP kernels (libvrgdg_hip.so, C ABI in include/vrgdg_hip.h) on the
+current torch HIP stream and returns a new tensor; inputs are never modified.  Scalars that the reference
+computes in Python doubles are computed here in double and rounded to fp32 exactly once, as torch does
+when a Python float meets an fp32 tensor.
+
+PyTorch is used for device memory, streams and the generator state only -- there is no torch arithmetic
+on the data path and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _hip, rng
+
+_F3 = C.c_float * 3
+
+
+def _f32(v: float) -> float:
+    """Python double -> nearest fp32 (as a Python float), the rounding torch applies to a scalar operand."""
+    return float(np.float32(v))
+
+
+def _check_frames(t: torch.Tensor, name="images", channels: Optional[int] = None):
+    if not isinstance(t, torch.Tensor) or t.ndim != 4:
+        raise ValueError(f"{name} must be a [frames, height, width, channels] tensor")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (ops.* are device-resident; nodes.* move data for you)")
+    if channels is not None and t.shape[-1] != channels:
+        raise ValueError(f"{name} must have {channels} channels, got {t.shape[-1]}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# noise descriptors
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class NoisePlan:
+    """How the frames of a call map onto torch.randn calls: `chunk_frames` frames per call."""
+    chunk_frames: int
+    stream: rng.ChunkedStream
+    chunk0: int = 0
+
+    def desc(self, chunk0: Optional[int] = None) -> _hip.NoiseDesc:
+        s = self.stream
+        return _hip.NoiseDesc(seed0=s.seed, seed_stride=s.seed_stride, offset0=s.offset0, offset_stride=s.offset_stride,
+                              chunk0=self.chunk0 if chunk0 is None else chunk0, chunk_frames=self.chunk_frames,
+                              grid_threads=s.grid_threads)
+
+
+def plan_noise(frames: int, frame_numel: int, chunk_frames: int, device, generator=None):
+    """Reserve the generator range FastFilmGrain's chunk loop would consume (nodes.py:46-51).
+    Returns (plan for the full chunks or None, plan for the ragged tail chunk or None, n_full_chunks)."""
+    step = chunk_frames if chunk_frames > 0 else frames
+    step = min(step, frames)
+    n_full, tail = divmod(frames, step)
+    main = tail_plan = None
+    if n_full:
+        main = NoisePlan(step, rng.reserve(step * frame_numel, n_full, device, generator))
+    if tail:
+        tail_plan = NoisePlan(tail, rng.reserve(tail * frame_numel, 1, device, generator))
+    return main, tail_plan, n_full
+
+
+# ------------------------------------------------------------------------------------------------
+# grain
+# ------------------------------------------------------------------------------------------------
+
+def torch_stream_noise(frames: int, frame_numel: int, plan: NoisePlan, device) -> torch.Tensor:
+    """The raw N(0,1) stream of `frames` frames under `plan` (test / debug entry)."""
+    out = torch.empty((frames, frame_numel), dtype=torch.float32, device=device)
+    d = plan.desc()
+    _hip.check(_hip.lib().vrg_noise_f32(_hip.ptr(out), frames, frame_numel, C.byref(d), _hip.current_stream()), "vrg_noise_f32")
+    return out
+
+
+def _grain_call(x, out, f0, nf, plan: NoisePlan, I32, S32, T32):
+    F, H, W, _ = x.shape
+    fe = H * W * 3
+    d = plan.desc()
+    base_in = x.data_ptr() + f0 * fe * 4
+    base_out = out.data_ptr() + f0 * fe * 4
+    _hip.check(_hip.lib().vrg_grain_f32(C.c_void_p(base_in), C.c_void_p(base_out), nf, H, W, I32, S32, T32, C.byref(d),
+                                       _hip.current_stream()), "vrg_grain_f32")
+
+
+def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: float, chunk_frames: int = 0,
+               generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
+    """Film grain with in-register Philox noise, bit-identical to the reference run on this GPU with the same
+    generator state: chunks of `chunk_frames` frames each draw one ``torch.randn`` (0 = one draw for all)."""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    out = torch.empty_like(x)
+    if F == 0:
+        return out
+    fe = H * W * 3
+    main, tail, n_full = plans if plans is not None else plan_noise(F, fe, chunk_frames, x.device, generator)
+    I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
+    done = 0
+    if main is not None:
+        _grain_call(x, out, 0, n_full * main.chunk_frames, main, I32, S32, T32)
+        done = n_full * main.chunk_frames
+    if tail is not None:
+        _grain_call(x, out, done, tail.chunk_frames, tail, I32, S32, T32)
+    return out
+
+
+def film_grain_seeded_frames(images: torch.Tensor, grain_intensity: float, saturation_mix: float, seed: int,
+                             frame_start: int = 0) -> torch.Tensor:
+    """Per-frame seeded grain: frame i uses generator seed (seed + frame_start + i) & 0x7FFFFFFF, offset 0
+    (VRGDG_StandaloneVideoEnhancerNodes.py:262-278) -- independent of how frames are batched or sharded."""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    out = torch.empty_like(x)
+    if F == 0 or grain_intensity <= 0:
+        return x.clone() if F else out
+    fe = H * W * 3
+    I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
+    first = int(seed) + int(frame_start)
+    f = 0
+    while f < F:   # split where the 31-bit mask wraps (practically never)
+        s0 = (first + f) & 0x7FFFFFFF
+        run = min(F - f, 0x80000000 - s0)
+        plan = NoisePlan(1, rng.per_frame_seeded(fe, s0, x.device))
+        _grain_call(x, out, f, run, plan, I32, S32, T32)
+        f += run
+    return out
+
+
+def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensity: float, saturation_mix: float) -> torch.Tensor:
+    """Grain arithmetic with caller-supplied N(0,1) noise (same shape): the noise-injection parity form."""
+    x = _check_frames(images, channels=3)
+    n = _check_frames(noise, "noise", channels=3)
+    if n.shape != x.shape:
+        raise ValueError("noise must have the shape of images")
+    out = torch.empty_like(x)
+    px = x.numel() // 3
+    _hip.check(_hip.lib().vrg_grain_injected_f32(_hip.ptr(x), _hip.ptr(n), _hip.ptr(out), px, _f32(grain_intensity),
+                                                _f32(saturation_mix), _f32(1.0 - saturation_mix), _hip.current_stream()),
+               "vrg_grain_injected_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# 3D LUT
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class DeviceLut:
+    table: torch.Tensor        # [N,N,N,3] fp32 on the device, index [b][g][r]
+    size: int
+    domain_min: tuple
+    domain_max: tuple
+
+
+def upload_lut(lut_data: dict, device) -> DeviceLut:
+    table = lut_data["lut"].to(device=device, dtype=torch.float32).contiguous()
+    if table.ndim != 4 or table.shape[-1] != 3 or not (table.shape[0] == table.shape[1] == table.shape[2]):
+        raise ValueError("LUT table must be [N, N, N, 3]")
+    dmin = tuple(float(v) for v in lut_data["domain_min"].to(torch.float32).cpu().tolist())
+    dmax = tuple(float(v) for v in lut_data["domain_max"].to(torch.float32).cpu().tolist())
+    return DeviceLut(table, int(table.shape[0]), dmin, dmax)
+
+
+def blend_terms(strength: float):
+    """(blend_mode, B, 1-B) from the node's 0..10 strength (VRGDG_IV_Adjustments.py:355-359).
+    mode 0 = return the input, 1 = LUT only, 2 = x*(1-B) + y*B."""
+    blend = max(0.0, min(10.0, float(strength))) / 10.0
+    if blend <= 0.0:
+        return 0, 0.0, 1.0
+    if blend < 1.0:
+        return 2, _f32(blend), _f32(1.0 - blend)
+    return 1, 1.0, 0.0
+
+
+def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.Tensor:
+    if image.ndim != 4 or image.shape[-1] < 3:
+        raise ValueError("VRGDG_LUTS expects IMAGE input shaped like [batch, height, width, channels].")
+    x = _check_frames(image, "image")
+    mode, B, omB = blend_terms(strength)
+    if mode == 0:
+        return x
+    out = torch.empty_like(x)
+    px = x.numel() // x.shape[-1]
+    if px == 0:
+        return out
+    _hip.check(_hip.lib().vrg_lut3d_f32(_hip.ptr(x), _hip.ptr(out), px, x.shape[-1], _hip.ptr(lut.table), lut.size,
+                                       _F3(*lut.domain_min), _F3(*lut.domain_max), mode, B, omB, _hip.current_stream()),
+               "vrg_lut3d_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 stencils
+# ------------------------------------------------------------------------------------------------
+
+_STENCIL = {"unsharp": _hip.STENCIL_UNSHARP, "laplacian": _hip.STENCIL_LAPLACIAN, "sobel": _hip.STENCIL_SOBEL}
+
+
+def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool = False) -> torch.Tensor:
+    """unsharp / laplacian / sobel.  zero_border=False is the reference's default numpy path (edge replicate);
+    True is its ``use_gpu`` path (zero padding, and for laplacian/sobel the conv2d sign/epsilon conventions)."""
+    x = _check_frames(images)
+    out = torch.empty_like(x)
+    F, H, W, Cn = x.shape
+    if x.numel() == 0:
+        return out
+    _hip.check(_hip.lib().vrg_stencil3x3_f32(_hip.ptr(x), _hip.ptr(out), F, H, W, Cn, _STENCIL[op],
+                                            _hip.BORDER_ZERO if zero_border else _hip.BORDER_REPLICATE, _f32(strength),
+                                            _hip.current_stream()), "vrg_stencil3x3_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# colour match
+# ------------------------------------------------------------------------------------------------
+
+def _stats_scratch(frames: int, device) -> torch.Tensor:
+    nbytes = int(_hip.lib().vrg_lab_stats_scratch_bytes(frames))
+    return torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device=device)
+
+
+def lab_stats(images: torch.Tensor) -> torch.Tensor:
+    """Per-frame Lab statistics as fp64 ``[F, 3, 3]`` = (n, mean, M2) per channel L,a,b."""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    stats = torch.empty((F, 3, 3), dtype=torch.float64, device=x.device)
+    if F == 0:
+        return stats
+    scratch = _stats_scratch(F, x.device)
+    _hip.check(_hip.lib().vrg_lab_stats_f32(_hip.ptr(x), F, H, W, _hip.ptr(stats), _hip.ptr(scratch), _hip.current_stream()),
+               "vrg_lab_stats_f32")
+    return stats
+
+
+def finalize_stats(stats: torch.Tensor) -> torch.Tensor:
+    """(n, mean, M2) fp64 -> fp32 ``[F, 3, 2]`` = (mean, unbiased std + 1e-5) (nodes.py:99-100, 109-110)."""
+    F = stats.shape[0]
+    ms = torch.empty((F, 3, 2), dtype=torch.float32, device=stats.device)
+    if F:
+        _hip.check(_hip.lib().vrg_lab_stats_finalize(_hip.ptr(stats), _hip.ptr(ms), F, _hip.current_stream()),
+                   "vrg_lab_stats_finalize")
+    return ms
+
+
+def merge_stats(parts: torch.Tensor) -> torch.Tensor:
+    """Chan/Golub/LeVeque merge of (n, mean, M2) triples along dim 0, in index order (deterministic):
+    used to combine the slices of one reference frame reduced on different GPUs.  ``parts``: [R, ..., 3]."""
+    acc = parts[0].clone()
+    for r in range(1, parts.shape[0]):
+        nb, mb, m2b = parts[r][..., 0], parts[r][..., 1], parts[r][..., 2]
+        na, ma, m2a = acc[..., 0], acc[..., 1], acc[..., 2]
+        n = na + nb
+        delta = mb - ma
+        mean = ma + delta * (nb / n)
+        m2 = m2a + m2b + delta * delta * (na * nb / n)
+        acc = torch.stack([n, mean, m2], dim=-1)
+    return acc
+
+
+def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.Tensor, match_strength: float) -> torch.Tensor:
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    out = torch.empty_like(x)
+    if F == 0:
+        return out
+    R = int(ref_ms.shape[0])
+    if R != 1 and F % R != 0:
+        raise RuntimeError(f"The size of tensor a ({F}) must match the size of tensor b ({R}) at non-singleton dimension 0")
+    _hip.check(_hip.lib().vrg_colormatch_apply_f32(_hip.ptr(x), _hip.ptr(out), F, H, W, _hip.ptr(img_ms), _hip.ptr(ref_ms), R,
+                                                  _f32(match_strength), _f32(1.0 - match_strength), _hip.current_stream()),
+               "vrg_colormatch_apply_f32")
+    return out
+
+
+def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
+                ref_ms: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124), two passes over HBM."""
+    x = _check_frames(images, channels=3)
+    if ref_ms is None:
+        ref = _check_frames(reference_image, "reference_image", channels=3).to(x.device)
+        ref_ms = finalize_stats(lab_stats(ref))
+    img_ms = finalize_stats(lab_stats(x))
+    return colormatch_apply(x, img_ms, ref_ms, match_strength)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused chain
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class ChainSpec:
+    """grain -> LUT -> colour match -> sharpen; None disables a stage."""
+    grain: Optional[tuple] = None          # (intensity, saturation_mix, chunk_frames)
+    lut: Optional[tuple] = None            # (DeviceLut, strength 0..10)
+    colormatch: Optional[tuple] = None     # (ref_ms [R,3,2] fp32 device tensor, match_strength)
+    sharpen: Optional[tuple] = None        # (op name, strength, zero_border)
+    variant: int = 0
+
+
+def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
+    d = _hip.ChainDesc()
+    stages = 0
+    if spec.grain is not None:
+        I, s, _ = spec.grain
+        stages |= _hip.STAGE_GRAIN
+        d.intensity, d.sat, d.one_minus_sat = _f32(I), _f32(s), _f32(1.0 - s)
+        d.noise = plan.desc()
+    if spec.lut is not None:
+        lut, strength = spec.lut
+        mode, B, omB = blend_terms(strength)
+        if mode != 0:
+            stages |= _hip.STAGE_LUT
+            d.lut = lut.table.data_ptr(); d.lut_size = lut.size
+            d.domain_min = _F3(*lut.domain_min); d.domain_max = _F3(*lut.domain_max)
+            d.blend_mode, d.blend, d.one_minus_blend = mode, B, omB
+            keep.append(lut.table)
+    if spec.colormatch is not None:
+        ref_ms, k = spec.colormatch
+        stages |= _hip.STAGE_COLORMATCH
+        d.ref_ms = ref_ms.data_ptr(); d.ref_frames = int(ref_ms.shape[0])
+        d.k, d.one_minus_k = _f32(k), _f32(1.0 - k)
+        keep.append(ref_ms)
+    if spec.sharpen is not None:
+        op, strength, zero = spec.sharpen
+        stages |= _hip.STAGE_SHARPEN
+        d.stencil_op = _STENCIL[op]
+        d.border = _hip.BORDER_ZERO if zero else _hip.BORDER_REPLICATE
+        d.strength = _f32(strength)
+    d.stages = stages
+    d.variant = spec.variant
+    return d
+
+
+def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
+    """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
+    pass).  Bit-identical to applying the stand-alone operators in that order."""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    out = torch.empty_like(x)
+    if F == 0:
+        return out
+    fe = H * W * 3
+    segments = [(0, F, None)]
+    if spec.grain is not None:
+        main, tail, n_full = plans if plans is not None else plan_noise(F, fe, spec.grain[2], x.device, generator)
+        segments = []
+        if main is not None:
+            segments.append((0, n_full * main.chunk_frames, main))
+        if tail is not None:
+            segments.append((F - tail.chunk_frames, tail.chunk_frames, tail))
+    lib = _hip.lib()
+    st = _hip.current_stream()
+    for f0, nf, plan in segments:
+        keep = []
+        d = _chain_desc(spec, plan, keep)
+        if d.stages == 0:
+            out[f0:f0 + nf] = x[f0:f0 + nf]
+            continue
+        src = C.c_void_p(x.data_ptr() + f0 * fe * 4)
+        dst = C.c_void_p(out.data_ptr() + f0 * fe * 4)
+        if d.stages & _hip.STAGE_COLORMATCH:
+            if d.ref_frames != 1 and (nf % d.ref_frames or f0 % d.ref_frames):
+                raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
+            stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
+            scratch = _stats_scratch(nf, x.device)
+            _hip.check(lib.vrg_chain_stats_f32(src, nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
+                       "vrg_chain_stats_f32")
+            img_ms = finalize_stats(stats)
+            d.img_ms = img_ms.data_ptr()
+            keep.append(img_ms)
+        _hip.check(lib.vrg_fused_chain_f32(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# timing helper (HIP events on the stream the kernels run on)
+# ------------------------------------------------------------------------------------------------
+
+class HipEvent:
+    def __init__(self):
+        self._ev = C.c_void_p()
+        _hip.check(_hip.lib().vrg_event_create(C.byref(self._ev)), "vrg_event_create")
+
+    def record(self):
+        _hip.check(_hip.lib().vrg_event_record(self._ev, _hip.current_stream()), "vrg_event_record")
+
+    def elapsed_ms(self, stop: "HipEvent") -> float:
+        ms = C.c_float()
+        _hip.check(_hip.lib().vrg_event_elapsed_ms(self._ev, stop._ev, C.byref(ms)), "vrg_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._ev:
+                _hip.lib().vrg_event_destroy(self._ev)
+        except Exception:
+            pass

@@ -1,0 +1,186 @@
+/*
+ * vrgdg_hip.h -- C ABI of libvrgdg_hip.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * per-pixel video post-processing hot path of comfyui-vrgamedevgirl.
+ *
+ * This is the drop-in boundary: plain pointers, sizes and scalars, no torch types.  The Python
+ * node classes (comfyui-vrgamedevgirl_amd/nodes.py, VRGDG_IV_Adjustments.py) bind it with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.  All image pointers are
+ * DEVICE pointers to fp32 NHWC frames ([F][H][W][C], C innermost), values nominally in [0,1].
+ * `stream` is a hipStream_t passed as void* (0 = the null stream); every entry point only
+ * enqueues work on that stream and returns immediately.  No entry point allocates device memory;
+ * scratch is supplied by the caller (sizes from the *_scratch_bytes helpers).
+ *
+ * Return value: 0 = ok; VRG_ERR_* otherwise (vrg_error_string() gives the text; the Python layer
+ * raises RuntimeError / ValueError like the reference's nodes do).
+ *
+ * Arithmetic contract: every fp32 operation of the reference is performed
+ * as its own correctly rounded fp32 operation in the reference's order -- the kernels are built
+ * with -ffp-contract=off and use IEEE divide / sqrt.  Scalars that the reference computes in
+ * Python doubles (1.0 - s, strength/10, ...) are computed by the CALLER in double and passed
+ * here already rounded to fp32.
+ */
+#ifndef VRGDG_HIP_H_
+#define VRGDG_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRG_ABI_VERSION 1
+
+enum vrg_status {
+    VRG_OK = 0,
+    VRG_ERR_BAD_ARG = 1,      /* null pointer, negative size, C < 3 where RGB is required ... */
+    VRG_ERR_UNSUPPORTED = 2,  /* valid request this build does not implement */
+    VRG_ERR_LAUNCH = 3,       /* hipLaunchKernel / hipGetLastError failed */
+    VRG_ERR_NO_DEVICE = 4
+};
+
+enum vrg_border {
+    VRG_BORDER_REPLICATE = 0, /* reference CPU/numpy path: np.pad(mode="edge")            (nodes.py:188-192) */
+    VRG_BORDER_ZERO = 1       /* reference use_gpu=True path: avg_pool2d / conv2d padding=1 (nodes.py:171, 257) */
+};
+
+enum vrg_stencil_op {
+    VRG_STENCIL_UNSHARP = 0,        /* FastUnsharpSharpen.apply_unsharp     nodes.py:156-209 */
+    VRG_STENCIL_LAPLACIAN = 1,      /* FastLaplacianSharpen.apply_laplacian nodes.py:234-289 */
+    VRG_STENCIL_SOBEL = 2,          /* FastSobelSharpen.apply_sobel         nodes.py:314-384 */
+    VRG_STENCIL_NONE = 3
+};
+
+/*
+ * Noise stream description: the torch-HIP `randn` mapping (ATen DistributionTemplates.h:52-99,
+ * rocrand_philox4x32_10.h, rocrand_normal.h:52-68).  The frames are cut into RNG chunks of
+ * `chunk_frames` frames (FastFilmGrain: batch_size, nodes.py:46-51; per-frame seeding: 1,
+ * VRGDG_StandaloneVideoEnhancerNodes.py:268-271).  Chunk j (absolute index chunk0 + j) draws
+ *     randn(chunk_numel) with Philox key  seed0 + (chunk0+j)*seed_stride,
+ *                              offset      offset0 + (chunk0+j)*offset_stride   (multiple of 4)
+ * and element li of the chunk takes component (li / G) % 4 of call (li / G) / 4 of Philox
+ * subsequence li % G.  `grid_threads` = G = grid.x*256 of torch's calc_execution_policy for
+ * chunk_numel on this device.  All chunks of one call must have the same numel (the host issues
+ * a second call for a ragged tail chunk).
+ */
+typedef struct vrg_noise_desc {
+    uint64_t seed0;
+    uint64_t seed_stride;
+    uint64_t offset0;
+    uint64_t offset_stride;
+    int64_t  chunk0;        /* absolute index of the first chunk handled by this call */
+    int32_t  chunk_frames;  /* frames per RNG chunk (>= 1) */
+    uint32_t grid_threads;  /* G */
+} vrg_noise_desc;
+
+/* ---------------------------------------------------------------------------------------------
+ * a1/a2  Film grain.  Replaces FastFilmGrain.apply_grain (nodes.py:41-66),
+ * _apply_film_grain_tensor (VRGDG_LUTVideoTools.py:262-277) and _apply_seeded_grain
+ * (VRGDG_StandaloneVideoEnhancerNodes.py:262-278).
+ *   g_c = fl(fl(S*fl(k_c*n_c)) + fl(T*n_G)),  k = (2,1,3);  out = clamp(fl(x + fl(g_c*I)), 0, 1)
+ * `frames` must be a whole number of RNG chunks except that the last chunk may not be ragged
+ * (see vrg_noise_desc).  C is fixed at 3.
+ * ------------------------------------------------------------------------------------------- */
+int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
+                  float intensity, float sat, float one_minus_sat,
+                  const vrg_noise_desc* noise, void* stream);
+
+/* Same arithmetic with the N(0,1) noise supplied by the caller (device pointer, same shape as
+ * `in`): the noise-injection form used to prove arithmetic parity against the CPU reference. */
+int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels,
+                           float intensity, float sat, float one_minus_sat, void* stream);
+
+/* Raw N(0,1) stream of the given chunks, bit-identical to torch.randn on this device (debug /
+ * test entry: lets the tests compare the stream itself against torch). `frame_elems` = H*W*3. */
+int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
+                  const vrg_noise_desc* noise, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a4/a5/a6  3D LUT trilinear apply + strength blend.  Replaces VRGDG_LUTS._apply_cube_lut and
+ * the blend in apply_lut (VRGDG_IV_Adjustments.py:288-361), _apply_lut_tensor
+ * (VRGDG_LUTVideoTools.py:172-185).  `lut` = device fp32 [N][N][N][3] indexed [blue][green][red].
+ * `channels` >= 3; channels beyond RGB are copied through.  blend_mode: 1 = LUT only (blend>=1),
+ * 2 = fl(fl(x*one_minus_blend) + fl(y*blend)).  (blend <= 0 is the caller's no-op.)
+ * ------------------------------------------------------------------------------------------- */
+int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels,
+                  const float* lut, int32_t lut_size,
+                  const float domain_min[3], const float domain_max[3],
+                  int32_t blend_mode, float blend, float one_minus_blend, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9/a10/a11  3x3 stencils, any channel count.  out = clamp(x + strength*f(3x3), 0, 1).
+ * Sum orders: see csrc/vrg_pixel_math.hpp (reference order for the replicate border; raster
+ * (kh,kw) order over the non-zero taps for the zero border).
+ * ------------------------------------------------------------------------------------------- */
+int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
+                       int32_t channels, int32_t op, int32_t border, float strength, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7/a8  Colour match (nodes.py:91-124 + kornia.color Lab transforms).
+ * Pass 1: per-frame Lab statistics.  stats[f][c] = {n, mean, M2} in fp64 (M2 = sum (x-mean)^2),
+ * c = L,a,b.  Deterministic two-stage reduction (no atomics).  `scratch` must hold
+ * vrg_lab_stats_scratch_bytes(frames) bytes.
+ * Pass 2: out = clamp(lab_to_rgb(K*((lab-mu)/sigma*sigma_ref+mu_ref) + T*lab)).
+ *   img_ms / ref_ms: device fp32 [frames][3][2] = {mean, std_unbiased + 1e-5} (vrg_lab_stats_finalize
+ *   converts the fp64 triple); ref frame of image frame f = (ref_frames == 1) ? 0 : f % ref_frames.
+ * ------------------------------------------------------------------------------------------- */
+int64_t vrg_lab_stats_scratch_bytes(int64_t frames);
+int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
+                      double* stats, void* scratch, void* stream);
+int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames, void* stream);
+int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
+                             const float* img_ms, const float* ref_ms, int32_t ref_frames,
+                             float k, float one_minus_k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused chain: grain -> LUT -> colour match -> 3x3 sharpen in one pass over HBM (12 B/px read +
+ * 12 B/px written; colour match adds the 12 B/px statistics pass).  Bit-identical to running the
+ * stand-alone entry points one after the other.  Stages are switched by `stages`.
+ * ------------------------------------------------------------------------------------------- */
+#define VRG_STAGE_GRAIN      1
+#define VRG_STAGE_LUT        2
+#define VRG_STAGE_COLORMATCH 4
+#define VRG_STAGE_SHARPEN    8
+
+typedef struct vrg_chain_desc {
+    int32_t stages;               /* VRG_STAGE_* bits */
+    int32_t variant;              /* 0 = default kernel; >0 selects an alternative implementation (bench A/B) */
+    /* grain */
+    float intensity, sat, one_minus_sat;
+    vrg_noise_desc noise;
+    /* LUT */
+    const float* lut; int32_t lut_size;
+    float domain_min[3], domain_max[3];
+    int32_t blend_mode; float blend, one_minus_blend;
+    /* colour match (statistics of the LUT output are produced by vrg_chain_stats_f32) */
+    const float* img_ms; const float* ref_ms; int32_t ref_frames;
+    float k, one_minus_k;
+    /* sharpen */
+    int32_t stencil_op, border; float strength;
+} vrg_chain_desc;
+
+int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
+                        const vrg_chain_desc* desc, void* stream);
+/* Lab statistics of the grain->LUT output (the input of the colour-match stage), same layout and
+ * scratch as vrg_lab_stats_f32. */
+int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
+                        const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Introspection
+ * ------------------------------------------------------------------------------------------- */
+int vrg_abi_version(void);
+const char* vrg_error_string(int status);
+/* multiProcessorCount and maxThreadsPerMultiProcessor of the current device (what torch's
+ * calc_execution_policy reads); returns VRG_ERR_NO_DEVICE without a GPU. */
+int vrg_device_info(int32_t* cu_count, int32_t* max_threads_per_cu);
+/* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
+ * between two recorded events (torch.cuda.Event only sees torch's current stream). */
+int vrg_event_create(void** ev);
+int vrg_event_record(void* ev, void* stream);
+int vrg_event_elapsed_ms(void* start, void* stop, float* ms);
+int vrg_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRGDG_HIP_H_ */

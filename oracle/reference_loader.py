@@ -1,0 +1,155 @@
+"""Load the reference's own Python modules (TEST INFRASTRUCTURE ONLY).
+
+Works only where ``/root/reference`` exists (the build container).  The GPU box
+has no reference checkout: nothing under ``-m gpu`` tests, ``smoke()`` or
+``bench.py`` may call this at run time; they use the committed fixtures in
+``tests/golden/`` produced by ``oracle/make_golden.py``.
+
+The reference's ``nodes.py`` imports ComfyUI / kornia / audio libraries at the
+top (nodes.py:5-12) that are not installed; empty ``types.ModuleType`` stubs are
+put in ``sys.modules`` for the duration of the import.  ``kornia.color`` is
+stubbed with the restated Lab transforms of ``oracle.restated`` so that the
+reference's *own* ``match_color`` control flow (statistics, blend, clamp,
+permute) can be executed.
+"""
+from __future__ import annotations
+
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("VRGDG_REFERENCE_ROOT", "/root/reference")
+
+_STUB_NAMES = (
+    "comfy", "comfy.model_management", "kornia", "kornia.color", "librosa",
+    "torchaudio", "folder_paths", "av", "imageio", "requests",
+)
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, "nodes.py"))
+
+
+def _install_stubs():
+    import torch
+    from . import restated
+
+    saved = {}
+    for name in _STUB_NAMES:
+        saved[name] = sys.modules.get(name)
+    comfy = types.ModuleType("comfy")
+    mm = types.ModuleType("comfy.model_management")
+    mm.get_torch_device = lambda: torch.device("cpu")
+    mm.intermediate_device = lambda: torch.device("cpu")
+    comfy.model_management = mm
+    kornia = types.ModuleType("kornia")
+    kcolor = types.ModuleType("kornia.color")
+    kcolor.rgb_to_lab = restated.kornia_rgb_to_lab
+    kcolor.lab_to_rgb = restated.kornia_lab_to_rgb
+    kornia.color = kcolor
+    sys.modules["comfy"] = comfy
+    sys.modules["comfy.model_management"] = mm
+    sys.modules["kornia"] = kornia
+    sys.modules["kornia.color"] = kcolor
+    for name in ("librosa", "torchaudio", "folder_paths", "av", "imageio"):
+        if saved[name] is None:
+            sys.modules[name] = types.ModuleType(name)
+    if saved["requests"] is None:
+        try:
+            import requests  # noqa: F401
+        except Exception:
+            sys.modules["requests"] = types.ModuleType("requests")
+    return saved
+
+
+def _restore_stubs(saved):
+    for name, mod in saved.items():
+        if mod is None:
+            sys.modules.pop(name, None)
+        else:
+            sys.modules[name] = mod
+
+
+def _load_file(modname: str, filename: str):
+    path = os.path.join(REFERENCE_ROOT, filename)
+    spec = importlib.util.spec_from_file_location(modname, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_CACHE = {}
+
+
+def load_nodes():
+    """The reference's ``nodes.py`` (FastFilmGrain, ColorMatchToReference, Fast*Sharpen)."""
+    if "nodes" not in _CACHE:
+        saved = _install_stubs()
+        try:
+            import io
+            import contextlib
+            with contextlib.redirect_stdout(io.StringIO()):
+                mod = _load_file("_vrgdg_reference_nodes", "nodes.py")
+            # nodes.py imports numpy late (nodes.py:1325) as a module global; the
+            # sharpen CPU paths rely on it.
+            if not hasattr(mod, "np"):
+                import numpy
+                mod.np = numpy
+            # keep the comfy / kornia stubs reachable from the module's globals
+            _CACHE["nodes"] = mod
+        finally:
+            _restore_stubs(saved)
+    return _CACHE["nodes"]
+
+
+def load_iv_adjustments():
+    """The reference's ``VRGDG_IV_Adjustments.py`` (needs only os, numpy, torch)."""
+    if "iv" not in _CACHE:
+        _CACHE["iv"] = _load_file("_vrgdg_reference_iv", "VRGDG_IV_Adjustments.py")
+    return _CACHE["iv"]
+
+
+def _ast_extract(filename: str, names, namespace):
+    """Same AST-exec pattern the reference's own tests use
+    (tests/test_standalone_video_enhancer.py:20-36)."""
+    path = os.path.join(REFERENCE_ROOT, filename)
+    with open(path, "r", encoding="utf-8") as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), namespace)
+    return namespace
+
+
+def load_lut_video_tools():
+    """``_apply_film_grain_tensor``, ``_apply_lut_tensor`` (VRGDG_LUTVideoTools.py:172-185, 262-277)."""
+    if "lvt" not in _CACHE:
+        import torch
+        iv = load_iv_adjustments()
+        ns = {"torch": torch, "VRGDG_LUTS": iv.VRGDG_LUTS, "LUTS_DIR": iv.LUTS_DIR}
+        _ast_extract(
+            "VRGDG_LUTVideoTools.py",
+            {"_apply_film_grain_tensor", "_apply_lut_tensor", "_normalize_adjust_settings",
+             "_apply_adjust_tensor"},
+            ns,
+        )
+        _CACHE["lvt"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith("_apply") or k.startswith("_normalize")})
+    return _CACHE["lvt"]
+
+
+def load_standalone_enhancer():
+    """``_apply_unsharp``, ``_apply_seeded_grain``, ``_apply_effects_batch``
+    (VRGDG_StandaloneVideoEnhancerNodes.py:233-294)."""
+    if "sve" not in _CACHE:
+        import torch
+        import torch.nn.functional as F
+        ns = {"torch": torch, "F": F}
+        _ast_extract(
+            "VRGDG_StandaloneVideoEnhancerNodes.py",
+            {"_auto_batch_size", "_apply_unsharp", "_apply_seeded_grain", "_apply_effects_batch",
+             "_process_with_retry"},
+            ns,
+        )
+        _CACHE["sve"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith("_a") or k.startswith("_p")})
+    return _CACHE["sve"]

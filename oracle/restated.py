@@ -1,0 +1,419 @@
+"""CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py).
+
+Every function states the reference lines it follows (paths relative to
+``/root/reference``).  The restatement keeps the reference's *operation order and
+rounding points* (one fp32 rounding per tensor op, Python scalars rounded once
+to fp32 when they meet an fp32 tensor), because that is what "parity" means for
+the HIP kernels; it is organised differently from the reference (noise is an
+explicit argument, border mode is an argument, stats are a separate step) so
+that each stage can be checked in isolation.
+
+All functions take / return ``torch.float32`` CPU tensors in ComfyUI's IMAGE
+convention ``[F, H, W, C]`` unless noted.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# Film grain
+# --------------------------------------------------------------------------------------
+
+#: per-channel gains applied to the raw normal noise (nodes.py:53-54; G is left at 1)
+GRAIN_GAIN_R = 2.0
+GRAIN_GAIN_B = 3.0
+
+
+def grain_apply(x: torch.Tensor, noise: torch.Tensor, intensity: float, saturation_mix: float) -> torch.Tensor:
+    """Arithmetic of one grain chunk given the raw N(0,1) ``noise`` (nodes.py:53-60;
+    identical in VRGDG_LUTVideoTools.py:272-277 and
+    VRGDG_StandaloneVideoEnhancerNodes.py:274-277).
+
+    g_c = fl(fl(S*k_c*n_c) ...): the order is: scale R,B in place; gray = n_G (unscaled);
+    g = S*n + T*gray with S=(float)s, T=(float)(1.0-s) [double subtraction first];
+    out = clamp(x + g*I, 0, 1).
+    """
+    n = noise.clone()
+    n[..., 0] *= GRAIN_GAIN_R
+    n[..., 2] *= GRAIN_GAIN_B
+    gray = n[..., 1:2].expand(*n.shape[:-1], 3)
+    mixed = saturation_mix * n + (1.0 - saturation_mix) * gray
+    return (x + mixed * intensity).clamp(0.0, 1.0)
+
+
+def fast_film_grain(images, grain_intensity, saturation_mix, batch_size, noise_fn=None):
+    """FastFilmGrain.apply_grain (nodes.py:41-66).  ``noise_fn(chunk_start, shape)`` supplies
+    the N(0,1) tensor of each ``batch_size`` chunk (default: ``torch.randn`` from the global
+    CPU generator, which is what ``torch.randn_like`` consumes on CPU)."""
+    step = batch_size if batch_size > 0 else images.shape[0]  # nodes.py:46
+    outs = []
+    for i in range(0, images.shape[0], step):
+        chunk = images[i:i + step]
+        noise = torch.randn(chunk.shape, dtype=chunk.dtype) if noise_fn is None else noise_fn(i, tuple(chunk.shape))
+        outs.append(grain_apply(chunk, noise, grain_intensity, saturation_mix))
+    return torch.cat(outs, dim=0)
+
+
+def film_grain_tensor(image, grain_intensity=0.04, saturation_mix=0.5, seed=None, noise=None):
+    """_apply_film_grain_tensor (VRGDG_LUTVideoTools.py:262-277): clamps I and s to [0,1],
+    optional seeded generator for the whole tensor."""
+    intensity = max(0.0, min(1.0, float(grain_intensity)))
+    saturation = max(0.0, min(1.0, float(saturation_mix)))
+    if noise is None:
+        gen = None
+        if seed not in (None, ""):
+            gen = torch.Generator(device=image.device)
+            gen.manual_seed(int(seed))
+        noise = torch.randn(image.shape, dtype=image.dtype, device=image.device, generator=gen)
+    return grain_apply(image, noise, intensity, saturation)
+
+
+def seeded_grain_frame_seed(seed: int, frame_start: int, offset: int) -> int:
+    """Per-frame generator seed (VRGDG_StandaloneVideoEnhancerNodes.py:270)."""
+    return (int(seed) + int(frame_start) + int(offset)) & 0x7FFFFFFF
+
+
+def seeded_grain(images, intensity, saturation_mix, seed, frame_start, noise_fn=None):
+    """_apply_seeded_grain (VRGDG_StandaloneVideoEnhancerNodes.py:262-278): one generator per
+    frame seeded with (seed + frame_start + offset) & 0x7FFFFFFF; ``intensity <= 0`` is a no-op."""
+    if intensity <= 0:
+        return images
+    frames = []
+    for off in range(images.shape[0]):
+        fseed = seeded_grain_frame_seed(seed, frame_start, off)
+        if noise_fn is None:
+            gen = torch.Generator(device=images.device)
+            gen.manual_seed(fseed)
+            n = torch.randn(images[off].shape, generator=gen, device=images.device, dtype=images.dtype)
+        else:
+            n = noise_fn(fseed, tuple(images[off].shape))
+        frames.append(n)
+    noise = torch.stack(frames, dim=0)
+    return grain_apply(images, noise, intensity, saturation_mix)
+
+
+# --------------------------------------------------------------------------------------
+# 3D LUT
+# --------------------------------------------------------------------------------------
+
+def parse_cube_file(path: str) -> dict:
+    """VRGDG_LUTS._parse_cube_file (VRGDG_IV_Adjustments.py:221-282).
+
+    Returns ``{"size", "lut" [N,N,N,3] indexed [blue,green,red,rgb], "domain_min", "domain_max"}``.
+    Rules kept: blank / ``#`` lines skipped; ``TITLE `` skipped; ``LUT_1D_SIZE`` -> ValueError;
+    ``LUT_3D_SIZE n``; ``DOMAIN_MIN/MAX a b c``; every other line with exactly three
+    whitespace-separated tokens is a data row (Python ``float`` -> fp32); lines with any other
+    token count are ignored; count must equal N^3 * 3.
+    """
+    import os
+    size = None
+    dmin = np.zeros(3, dtype=np.float32)
+    dmax = np.ones(3, dtype=np.float32)
+    vals = []
+    with open(path, "r", encoding="utf-8", errors="ignore") as fh:
+        for raw in fh:
+            line = raw.strip()
+            if not line or line[0] == "#":
+                continue
+            up = line.upper()
+            if up.startswith("TITLE "):
+                continue
+            if up.startswith("LUT_1D_SIZE"):
+                raise ValueError(f"1D LUTs are not supported: {os.path.basename(path)}")
+            tok = line.split()
+            if up.startswith("LUT_3D_SIZE"):
+                if len(tok) != 2:
+                    raise ValueError(f"Invalid LUT_3D_SIZE line in {path}")
+                size = int(tok[1])
+                continue
+            if up.startswith("DOMAIN_MIN") or up.startswith("DOMAIN_MAX"):
+                if len(tok) != 4:
+                    raise ValueError(f"Invalid {tok[0]} line in {path}")
+                arr = np.array([float(tok[1]), float(tok[2]), float(tok[3])], dtype=np.float32)
+                if up.startswith("DOMAIN_MIN"):
+                    dmin = arr
+                else:
+                    dmax = arr
+                continue
+            if len(tok) != 3:
+                continue
+            vals.extend(float(t) for t in tok)
+    if size is None:
+        raise ValueError(f"Missing LUT_3D_SIZE in {path}")
+    want = size * size * size * 3
+    if len(vals) != want:
+        raise ValueError(f"Invalid LUT data length in {path}. Expected {want} floats, got {len(vals)}.")
+    lut = torch.from_numpy(np.asarray(vals, dtype=np.float32).reshape(size, size, size, 3))
+    return {"size": size, "lut": lut, "domain_min": torch.from_numpy(dmin), "domain_max": torch.from_numpy(dmax)}
+
+
+def apply_cube_lut(image, lut, domain_min, domain_max):
+    """VRGDG_LUTS._apply_cube_lut (VRGDG_IV_Adjustments.py:288-343).
+
+    t = clamp((x-dmin)/max(dmax-dmin,1e-6),0,1); c = t*(N-1); i0=floor(c) (int64);
+    i1=min(i0+1,N-1); f=c-i0; corners lut[b,g,r]; lerp order blue, green, red, each
+    a*(1-f)+b*f; clamp(0,1); channels >= 3 pass through.
+    """
+    if image.ndim != 4 or image.shape[-1] < 3:
+        raise ValueError("VRGDG_LUTS expects IMAGE input shaped like [batch, height, width, channels].")
+    rgb = image[..., :3].to(torch.float32)
+    span = torch.clamp(domain_max - domain_min, min=1e-6)
+    t = torch.clamp((rgb - domain_min) / span, 0.0, 1.0)
+    top = lut.shape[0] - 1
+    c = t * top
+    lo = torch.floor(c).long()
+    hi = torch.clamp(lo + 1, max=top)
+    frac = c - lo.float()
+    r0, g0, b0 = lo[..., 0], lo[..., 1], lo[..., 2]
+    r1, g1, b1 = hi[..., 0], hi[..., 1], hi[..., 2]
+    fr, fg, fb = frac[..., 0:1], frac[..., 1:2], frac[..., 2:3]
+
+    def along_blue(g, r):
+        return lut[b0, g, r] * (1.0 - fb) + lut[b1, g, r] * fb
+
+    def along_green(r):
+        return along_blue(g0, r) * (1.0 - fg) + along_blue(g1, r) * fg
+
+    out = torch.clamp(along_green(r0) * (1.0 - fr) + along_green(r1) * fr, 0.0, 1.0)
+    if image.shape[-1] == 3:
+        return out.to(image.dtype)
+    full = image.clone()
+    full[..., :3] = out.to(image.dtype)
+    return full
+
+
+def lut_blend_factor(strength) -> float:
+    """blend = clamp(strength, 0, 10) / 10 in double (VRGDG_IV_Adjustments.py:355)."""
+    return max(0.0, min(10.0, float(strength))) / 10.0
+
+
+def apply_lut_with_strength(image, lut_data, strength):
+    """VRGDG_LUTS.apply_lut minus device moves (VRGDG_IV_Adjustments.py:345-361), same as
+    _apply_lut_tensor (VRGDG_LUTVideoTools.py:172-185)."""
+    dmin = lut_data["domain_min"].to(image.dtype)
+    dmax = lut_data["domain_max"].to(image.dtype)
+    graded = apply_cube_lut(image, lut_data["lut"], dmin, dmax)
+    blend = lut_blend_factor(strength)
+    if blend <= 0.0:
+        return image
+    if blend < 1.0:
+        return (image * (1.0 - blend)) + (graded * blend)
+    return graded
+
+
+# --------------------------------------------------------------------------------------
+# 3x3 stencils (unsharp / laplacian / sobel)
+# --------------------------------------------------------------------------------------
+
+def _edge_padded(images: torch.Tensor) -> np.ndarray:
+    arr = images.contiguous().numpy()
+    return np.pad(arr, ((0, 0), (1, 1), (1, 1), (0, 0)), mode="edge")
+
+
+def _taps(p):
+    """The nine shifted views p[dy][dx] (dy,dx in 0..2) of an edge/zero padded NHWC array."""
+    H = p.shape[1] - 2
+    W = p.shape[2] - 2
+    return [[p[:, dy:dy + H, dx:dx + W] for dx in range(3)] for dy in range(3)]
+
+
+def unsharp(images, strength, use_gpu=False):
+    """FastUnsharpSharpen.apply_unsharp (nodes.py:156-209).
+
+    use_gpu=False (default): numpy, edge-replicate pad, nine-term row-major left-assoc sum, /9.0.
+    use_gpu=True: avg_pool2d(k=3,s=1,p=1) == zero pad, raster-order sum of in-bounds taps, /9.
+    Then out = clip(x + strength*(x-blur), 0, 1).
+    """
+    if use_gpu:
+        x = images.permute(0, 3, 1, 2)
+        blur = F.avg_pool2d(x, kernel_size=3, stride=1, padding=1)
+        return (x + strength * (x - blur)).clamp(0.0, 1.0).permute(0, 2, 3, 1)
+    img = images.contiguous().numpy()
+    t = _taps(_edge_padded(images))
+    acc = t[0][0] + t[0][1]
+    for dy, dx in ((0, 2), (1, 0), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2)):
+        acc = acc + t[dy][dx]
+    blur = acc / 9.0
+    out = img + strength * (img - blur)
+    np.clip(out, 0.0, 1.0, out=out)
+    return torch.from_numpy(out)
+
+
+def laplacian(images, strength, use_gpu=False):
+    """FastLaplacianSharpen.apply_laplacian (nodes.py:234-289).
+
+    CPU: lap = W + N + S + E - 4*x (that order), replicate border, out = clip(x + s*lap).
+    GPU flag: depthwise conv2d with [[0,-1,0],[-1,4,-1],[0,-1,0]], zero pad, out = clip(x + s*edges)
+    (opposite sign convention -- reproduced, not fixed).
+    """
+    if use_gpu:
+        x = images.permute(0, 3, 1, 2)
+        C = x.shape[1]
+        k = torch.tensor([[0, -1, 0], [-1, 4, -1], [0, -1, 0]], dtype=torch.float32).expand(C, 1, 3, 3)
+        edges = F.conv2d(x, k, padding=1, groups=C)
+        return (x + strength * edges).clamp(0.0, 1.0).permute(0, 2, 3, 1)
+    img = images.contiguous().numpy()
+    t = _taps(_edge_padded(images))
+    lap = t[1][0] + t[0][1] + t[2][1] + t[1][2] - 4.0 * img
+    out = img + strength * lap
+    np.clip(out, 0.0, 1.0, out=out)
+    return torch.from_numpy(out)
+
+
+def sobel(images, strength, use_gpu=False):
+    """FastSobelSharpen.apply_sobel (nodes.py:314-384).
+
+    CPU: gx, gy in the reference's term order, edges = sqrt(gx*gx + gy*gy), replicate border.
+    GPU flag: conv2d zero pad, edges = sqrt(gx*gx + gy*gy + 1e-6).
+    """
+    if use_gpu:
+        x = images.permute(0, 3, 1, 2)
+        C = x.shape[1]
+        kx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32).expand(C, 1, 3, 3)
+        ky = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32).expand(C, 1, 3, 3)
+        gx = F.conv2d(x, kx, padding=1, groups=C)
+        gy = F.conv2d(x, ky, padding=1, groups=C)
+        edges = torch.sqrt(gx * gx + gy * gy + 1e-6)
+        return (x + strength * edges).clamp(0.0, 1.0).permute(0, 2, 3, 1)
+    img = images.contiguous().numpy()
+    t = _taps(_edge_padded(images))
+    gx = (-t[0][0] - 2 * t[1][0] - t[2][0] + t[0][2] + 2 * t[1][2] + t[2][2])
+    gy = (-t[0][0] - 2 * t[0][1] - t[0][2] + t[2][0] + 2 * t[2][1] + t[2][2])
+    edges = np.sqrt(gx * gx + gy * gy)
+    out = img + strength * edges
+    np.clip(out, 0.0, 1.0, out=out)
+    return torch.from_numpy(out)
+
+
+# Explicit-order restatements of the zero-pad ("use_gpu") stencils.  torch's conv2d does not
+# define its accumulation order (MIOpen / oneDNN pick their own); the HIP kernels use raster
+# (kh,kw) order over the non-zero taps, which these functions state explicitly so that the
+# kernels can be checked bit-for-bit, while the conv2d versions above are checked to a few ulp.
+
+def _zero_padded(images: torch.Tensor) -> np.ndarray:
+    arr = images.contiguous().numpy()
+    return np.pad(arr, ((0, 0), (1, 1), (1, 1), (0, 0)), mode="constant")
+
+
+def laplacian_zero_raster(images, strength):
+    img = images.contiguous().numpy()
+    t = _taps(_zero_padded(images))
+    edges = (((-t[0][1]) - t[1][0]) + 4.0 * t[1][1]) - t[1][2] - t[2][1]
+    out = img + np.float32(strength) * edges
+    np.clip(out, 0.0, 1.0, out=out)
+    return torch.from_numpy(out)
+
+
+def sobel_zero_raster(images, strength):
+    img = images.contiguous().numpy()
+    t = _taps(_zero_padded(images))
+    gx = ((((-t[0][0]) + t[0][2]) - 2.0 * t[1][0]) + 2.0 * t[1][2]) - t[2][0] + t[2][2]
+    gy = ((((-t[0][0]) - 2.0 * t[0][1]) - t[0][2]) + t[2][0]) + 2.0 * t[2][1] + t[2][2]
+    edges = np.sqrt(gx * gx + gy * gy + np.float32(1e-6))
+    out = img + np.float32(strength) * edges
+    np.clip(out, 0.0, 1.0, out=out)
+    return torch.from_numpy(out)
+
+
+# --------------------------------------------------------------------------------------
+# kornia.color Lab transforms -- RESTATED, PARITY UNPINNED (kornia is an unpinned external
+# dependency of the reference: requirements.txt:1, call sites nodes.py:98,108,115).
+# Published algorithm of kornia.color.{rgb_to_lab, lab_to_rgb, rgb_to_linear_rgb,
+# linear_rgb_to_rgb, rgb_to_xyz, xyz_to_rgb} (kornia >= 0.6), NCHW layout [..., 3, H, W].
+# --------------------------------------------------------------------------------------
+
+D65_WHITE = (0.95047, 1.0, 1.08883)
+RGB2XYZ = ((0.412453, 0.357580, 0.180423),
+           (0.212671, 0.715160, 0.072169),
+           (0.019334, 0.119193, 0.950227))
+XYZ2RGB = ((3.2404813432005266, -1.5371515162713185, -0.4985363261688878),
+           (-0.9692549499965682, 1.8759900014898907, 0.0415559265582928),
+           (0.0556466391351772, -0.2040413383665112, 1.0573110696453443))
+
+
+def kornia_rgb_to_lab(image: torch.Tensor) -> torch.Tensor:
+    lin = torch.where(image > 0.04045, torch.pow((image + 0.055) / 1.055, 2.4), image / 12.92)
+    r, g, b = lin[..., 0, :, :], lin[..., 1, :, :], lin[..., 2, :, :]
+    xyz = torch.stack([RGB2XYZ[i][0] * r + RGB2XYZ[i][1] * g + RGB2XYZ[i][2] * b for i in range(3)], -3)
+    white = torch.tensor(D65_WHITE, device=xyz.device, dtype=xyz.dtype)[..., :, None, None]
+    xn = torch.div(xyz, white)
+    thr = 0.008856
+    f = torch.where(xn > thr, torch.pow(xn.clamp(min=thr), 1 / 3.0), 7.787 * xn + 4.0 / 29.0)
+    fx, fy, fz = f[..., 0, :, :], f[..., 1, :, :], f[..., 2, :, :]
+    return torch.stack([(116.0 * fy) - 16.0, 500.0 * (fx - fy), 200.0 * (fy - fz)], dim=-3)
+
+
+def kornia_lab_to_rgb(image: torch.Tensor, clip: bool = True) -> torch.Tensor:
+    L, a, b_ = image[..., 0, :, :], image[..., 1, :, :], image[..., 2, :, :]
+    fy = (L + 16.0) / 116.0
+    fx = (a / 500.0) + fy
+    fz = (fy - (b_ / 200.0)).clamp(min=0.0)
+    f = torch.stack([fx, fy, fz], dim=-3)
+    xyz = torch.where(f > 0.2068966, torch.pow(f, 3.0), (f - 4.0 / 29.0) / 7.787)
+    white = torch.tensor(D65_WHITE, device=xyz.device, dtype=xyz.dtype)[..., :, None, None]
+    xyz = xyz * white
+    x, y, z = xyz[..., 0, :, :], xyz[..., 1, :, :], xyz[..., 2, :, :]
+    lin = torch.stack([XYZ2RGB[i][0] * x + XYZ2RGB[i][1] * y + XYZ2RGB[i][2] * z for i in range(3)], dim=-3)
+    thr = 0.0031308
+    rgb = torch.where(lin > thr, 1.055 * torch.pow(lin.clamp(min=thr), 1 / 2.4) - 0.055, 12.92 * lin)
+    if clip:
+        rgb = torch.clamp(rgb, min=0.0, max=1.0)
+    return rgb
+
+
+# --------------------------------------------------------------------------------------
+# Colour match
+# --------------------------------------------------------------------------------------
+
+def lab_stats(lab_nchw: torch.Tensor):
+    """Per-(frame, channel) mean and unbiased std (+1e-5) over H*W (nodes.py:99-100, 109-110)."""
+    mean = lab_nchw.mean(dim=[2, 3], keepdim=True)
+    std = lab_nchw.std(dim=[2, 3], keepdim=True) + 1e-5
+    return mean, std
+
+
+def color_match_apply(lab_nchw, img_mean, img_std, ref_mean, ref_std, match_strength):
+    """matched=(lab-mu)/sigma*sigma_ref+mu_ref ; blended=k*matched+(1-k)*lab ; Lab->RGB
+    (nodes.py:112-115)."""
+    matched = (lab_nchw - img_mean) / img_std * ref_std + ref_mean
+    blended = match_strength * matched + (1.0 - match_strength) * lab_nchw
+    return kornia_lab_to_rgb(blended)
+
+
+def color_match(images, reference_image, match_strength, batch_size):
+    """ColorMatchToReference.match_color (nodes.py:91-124).  Returns a contiguous NHWC tensor
+    (the reference returns a permuted view of NCHW memory; values are identical)."""
+    x = images.permute(0, 3, 1, 2)
+    ref = reference_image.permute(0, 3, 1, 2)
+    ref_mean, ref_std = lab_stats(kornia_rgb_to_lab(ref))
+    outs = []
+    for i in range(0, x.shape[0], batch_size):
+        lab = kornia_rgb_to_lab(x[i:i + batch_size])
+        mean, std = lab_stats(lab)
+        outs.append(color_match_apply(lab, mean, std, ref_mean, ref_std, match_strength))
+    out = torch.cat(outs, dim=0).clamp(0.0, 1.0)
+    return out.permute(0, 2, 3, 1).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# Sequential composition used by the fused-chain parity tests
+# --------------------------------------------------------------------------------------
+
+def chain(images, noise=None, grain=None, lut=None, colormatch=None, sharpen=None):
+    """grain -> LUT -> colour match -> unsharp applied one after the other, each stage exactly
+    as its node would.  ``grain``=(I, s), ``lut``=(lut_data,
+    strength), ``colormatch``=(reference_image, k), ``sharpen``=(strength, use_gpu)."""
+    y = images
+    if grain is not None:
+        y = grain_apply(y, noise, grain[0], grain[1])
+    if lut is not None:
+        y = apply_lut_with_strength(y, lut[0], lut[1])
+    if colormatch is not None:
+        y = color_match(y, colormatch[0], colormatch[1], 1)
+    if sharpen is not None:
+        y = unsharp(y, sharpen[0], sharpen[1])
+        if not y.is_contiguous():
+            y = y.contiguous()
+    return y

@@ -1,0 +1,153 @@
+"""The CPU oracle (oracle/restated.py) against fixtures produced by the REFERENCE's own code
+(oracle/make_golden.py): bit-for-bit."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restated as R
+from oracle import reference_loader as RL
+from conftest import GOLDEN
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_grain_noise_injected_cases():
+    z = _npz("grain.npz")
+    x = _t(z["x"])
+    for tag in ("default", "strong_colour", "mono_all", "workflow_widgets"):
+        I, s, bs = float(z[f"{tag}.I"]), float(z[f"{tag}.s"]), int(z[f"{tag}.bs"])
+        noise = _t(z[f"{tag}.noise"])
+        out = R.fast_film_grain(x, I, s, bs, noise_fn=lambda i, shape: noise[i:i + shape[0]])
+        assert torch.equal(out, _t(z[f"{tag}.out"])), tag
+
+
+def test_grain_cpu_generator_paths():
+    z = _npz("grain.npz")
+    x = _t(z["x"])
+    assert torch.equal(R.film_grain_tensor(x, 0.04, 0.5, 7), _t(z["route_seed7.out"]))
+    assert torch.equal(R.film_grain_tensor(x, 7.0, -3.0, 11), _t(z["route_clamped.out"]))
+    fr = torch.full((4, 12, 16, 3), 0.5)
+    out = R.seeded_grain(R.unsharp(fr, 0.5, False), 0.04, 0.5, 42, 100)
+    assert torch.equal(out, _t(z["effects_batch.out"]))
+
+
+def test_seeded_grain_is_batch_boundary_invariant():
+    # the property the reference's own test pins (tests/test_standalone_video_enhancer.py:39-61)
+    fr = torch.full((4, 12, 16, 3), 0.5)
+    whole = R.seeded_grain(fr, 0.04, 0.5, 42, 100)
+    split = torch.cat((R.seeded_grain(fr[:2], 0.04, 0.5, 42, 100), R.seeded_grain(fr[2:], 0.04, 0.5, 42, 102)))
+    assert torch.equal(whole, split)
+
+
+@pytest.mark.parametrize("tag,fname", [("a", "synthetic_17.cube"), ("b", "synthetic_domain_9.cube")])
+def test_lut_parse_and_apply(tag, fname):
+    z = _npz("lut.npz")
+    lut = R.parse_cube_file(os.path.join(GOLDEN, fname))
+    assert torch.equal(lut["lut"], _t(z[f"{tag}.lut"]))
+    assert torch.equal(lut["domain_min"], _t(z[f"{tag}.dmin"]))
+    assert torch.equal(lut["domain_max"], _t(z[f"{tag}.dmax"]))
+    img, img4 = _t(z[f"{tag}.img"]), _t(z[f"{tag}.img4"])
+    for s in (10.0, 3.3, 0.0, 25.0):
+        assert torch.equal(R.apply_lut_with_strength(img, lut, s), _t(z[f"{tag}.out.s{s}"])), s
+    assert torch.equal(R.apply_lut_with_strength(img4, lut, 10.0), _t(z[f"{tag}.out4.s10.0"]))
+    assert torch.equal(R.apply_lut_with_strength(img, lut, 6.5), _t(z[f"{tag}.route.s6.5"]))
+
+
+def test_cube_parser_errors(tmp_path):
+    p = tmp_path / "bad1.cube"
+    p.write_text("LUT_1D_SIZE 4\n0 0 0\n")
+    with pytest.raises(ValueError):
+        R.parse_cube_file(str(p))
+    p.write_text("0 0 0\n")
+    with pytest.raises(ValueError):
+        R.parse_cube_file(str(p))
+    p.write_text("LUT_3D_SIZE 2\n0 0 0\n")
+    with pytest.raises(ValueError):
+        R.parse_cube_file(str(p))
+
+
+def test_stencils():
+    z = _npz("stencil.npz")
+    for tag in ("rand", "odd", "one", "row", "col", "c4", "const"):
+        x = _t(z[f"{tag}.x"])
+        for s in (0.5, 3.75):
+            for gpu in (False, True):
+                got = R.unsharp(x, s, gpu).contiguous()
+                assert torch.equal(got, _t(z[f"{tag}.unsharp.{s}.{int(gpu)}"])), (tag, s, gpu)
+        for gpu in (False, True):
+            if gpu and x.shape[-1] != 3:
+                continue
+            assert torch.equal(R.laplacian(x, 0.8, gpu).contiguous(), _t(z[f"{tag}.laplacian.0.8.{int(gpu)}"])), (tag, gpu)
+            assert torch.equal(R.sobel(x, 0.8, gpu).contiguous(), _t(z[f"{tag}.sobel.0.8.{int(gpu)}"])), (tag, gpu)
+    x = _t(z["rand.x"])
+    assert torch.equal(R.unsharp(x, 0.9, False), _t(z["enh.unsharp_cpu"]))
+    assert torch.equal(R.unsharp(x, 0.9, True).contiguous(), _t(z["enh.unsharp_gpuflag"]))
+
+
+def test_zero_border_raster_restatement_matches_conv2d_to_an_ulp():
+    # the explicit (kh,kw)-raster order the HIP kernels use vs whatever order torch's conv2d picked here
+    z = _npz("stencil.npz")
+    for tag in ("rand", "odd", "one", "row", "col", "const"):
+        x = _t(z[f"{tag}.x"])
+        ref_l = _t(z[f"{tag}.laplacian.0.8.1"])
+        ref_s = _t(z[f"{tag}.sobel.0.8.1"])
+        assert (R.laplacian_zero_raster(x, 0.8) - ref_l).abs().max() <= 5e-7
+        assert (R.sobel_zero_raster(x, 0.8) - ref_s).abs().max() <= 5e-7
+
+
+def test_colour_match_control_flow():
+    z = _npz("colormatch.npz")
+    x, ref1, ref4 = _t(z["x"]), _t(z["ref1"]), _t(z["ref4"])
+    assert torch.equal(R.color_match(x, ref1, 1.0, 1), _t(z["out.ref1.k1.bs1"]))
+    assert torch.equal(R.color_match(x, ref1, 0.35, 3), _t(z["out.ref1.k0.35.bs3"]))
+    assert torch.equal(R.color_match(x, ref4, 0.8, 4), _t(z["out.ref4.k0.8.bs4"]))
+
+
+def test_lab_restated_self_consistency():
+    # kornia is absent (parity unpinned): check the published algorithm's invariants instead
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.rand(2, 3, 16, 16, generator=g)
+    lab = R.kornia_rgb_to_lab(rgb)
+    back = R.kornia_lab_to_rgb(lab)
+    assert (back - rgb).abs().max() < 2e-5
+    white = R.kornia_rgb_to_lab(torch.ones(1, 3, 1, 1))
+    assert abs(white[0, 0, 0, 0].item() - 100.0) < 1e-3 and white[0, 1:].abs().max() < 1e-2
+    assert R.kornia_rgb_to_lab(torch.zeros(1, 3, 1, 1)).abs().max() == 0
+
+
+@pytest.mark.skipif(not RL.reference_available(), reason="reference checkout (third-party LUT assets) not present")
+def test_shipped_lut_assets_by_digest():
+    with open(os.path.join(GOLDEN, "shipped_lut_digests.json")) as fh:
+        meta = json.load(fh)
+    g = torch.Generator().manual_seed(meta["probe_seed"])
+    probe = torch.rand(*meta["probe_shape"], generator=g) * meta["probe_affine"][0] + meta["probe_affine"][1]
+    luts_dir = os.path.join(RL.REFERENCE_ROOT, "LUTS")
+    assert len(meta["luts"]) == 12
+    for name, want in meta["luts"].items():
+        lut = R.parse_cube_file(os.path.join(luts_dir, name))
+        assert lut["size"] == want["size"]
+        assert hashlib.sha256(lut["lut"].numpy().tobytes()).hexdigest() == want["lut_sha256"], name
+        out = R.apply_cube_lut(probe, lut["lut"], lut["domain_min"], lut["domain_max"])
+        assert hashlib.sha256(out.numpy().tobytes()).hexdigest() == want["out_sha256"], name
+
+
+@pytest.mark.skipif(not RL.reference_available(), reason="reference checkout not present")
+def test_restatement_against_live_reference_random_shapes():
+    nodes = RL.load_nodes()
+    g = torch.Generator().manual_seed(77)
+    for shape in ((1, 3, 5, 3), (2, 17, 9, 3), (1, 32, 48, 3)):
+        x = torch.rand(*shape, generator=g) * 1.2 - 0.1
+        for s, gpu in ((0.5, False), (2.5, True)):
+            assert torch.equal(R.unsharp(x, s, gpu).contiguous(), nodes.FastUnsharpSharpen().apply_unsharp(x, s, gpu)[0].contiguous())
+            assert torch.equal(R.laplacian(x, s, gpu).contiguous(), nodes.FastLaplacianSharpen().apply_laplacian(x, s, gpu)[0].contiguous())
+            assert torch.equal(R.sobel(x, s, gpu).contiguous(), nodes.FastSobelSharpen().apply_sobel(x, s, gpu)[0].contiguous())
