@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Headline benchmark: Mpixels/s of the fused grain -> 33^3 LUT -> colour match -> unsharp chain at 4K.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N=1: plain python; N>1: launched by torchrun
+
+Workload (BASELINE.json metric / configs[4] per-GPU shard): every rank holds `--frames` (default 256) synthetic
+4K fp32 RGB frames resident in HBM (generated on device, never touched by the host), chain = Fast Film Grain
+(I=0.04, s=0.5, one torch.randn draw per 4 frames) -> 3D LUT 33^3 (strength 10) -> Color Match to a 4K
+reference frame (k=1) -> Fast Unsharp (0.5, edge-replicate).  A step = one pass of that chain over the rank's
+batch: reference-frame statistics (rows split across ranks + all-reduce when N>1), the statistics pass over the
+batch, and the fused apply pass.  Weak scaling: per-GPU work is fixed, value = all ranks' pixels / max time.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fused apply pass, 24 B/px
+algorithmic: 12 read + 12 written), timed with HIP events on the stream it is launched on; `cpu_baseline` is the
+oracle (a port of the reference's eager torch/numpy ops) on the host cores over a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a copy kernel
+WORKLOADS = {
+    # name: (H, W, stages)
+    "chain4_4k": (2160, 3840, ("grain", "lut", "colormatch", "sharpen")),      # headline (configs[4] per-GPU shard)
+    "chain3_4k": (2160, 3840, ("grain", "lut", "sharpen")),                    # configs[2]
+    "grain_lut_1080p": (1080, 1920, ("grain", "lut")),                         # configs[1]
+    "colormatch_4k": (2160, 3840, ("colormatch",)),                            # configs[3]
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default 256; 128 for the 1080p workload)")
+    ap.add_argument("--workload", default="chain4_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--dist", default="uniform", choices=["uniform", "video"], help="synthetic pixel distribution")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="4K frames of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def make_frames(n, H, W, dev, seed, dist):
+    """Synthetic frames generated on the device.  uniform: iid U[0,1) (worst case for LUT gathers);
+    video: smooth low-frequency field + N(0, 0.02) texture, clamped (LUT-coherent like real footage)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    if dist == "uniform":
+        x = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
+        for i in range(0, n, 16):
+            x[i:i + 16].copy_(torch.rand((min(16, n - i), H, W, 3), generator=g, device=dev))
+        return x
+    yy = torch.linspace(0, 1, H, device=dev).view(1, H, 1, 1)
+    xx = torch.linspace(0, 1, W, device=dev).view(1, 1, W, 1)
+    x = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
+    for i in range(n):
+        ph = torch.rand((1, 1, 1, 3), generator=g, device=dev) * 6.28
+        fr = 0.5 + 0.25 * torch.sin(6.0 * xx + ph) * torch.cos(4.0 * yy + 0.5 * ph) + 0.15 * torch.sin(9.0 * yy - ph)
+        fr = fr + 0.02 * torch.randn((1, H, W, 3), generator=g, device=dev)
+        x[i] = fr.clamp_(0, 1)[0]
+    return x
+
+
+def cpu_baseline(stages, cpu_frames, H, W, lut_cpu):
+    """Oracle (port of the reference's eager ops) on the host cores, bounded sample."""
+    from oracle import restated as R
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand((cpu_frames, H, W, 3), generator=g)
+    ref = torch.rand((1, H, W, 3), generator=g)
+    t0 = time.perf_counter()
+    y = x
+    if "grain" in stages:
+        y = R.fast_film_grain(y, 0.04, 0.5, 4)
+    if "lut" in stages:
+        y = R.apply_lut_with_strength(y, lut_cpu, 10.0)
+    if "colormatch" in stages:
+        y = R.color_match(y, ref, 1.0, 1)
+    if "sharpen" in stages:
+        y = R.unsharp(y, 0.5, False)
+    dt = time.perf_counter() - t0
+    mpix = cpu_frames * H * W / 1e6
+    return {"value": round(mpix / dt, 2), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{cpu_frames} frames {W}x{H}, same chain via oracle/restated.py (torch-CPU eager ops, numpy unsharp is "
+                      f"single-threaded), {dt:.1f} s, host os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    args = parse_args()
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_vrgamedevgirl_amd import ops, sharding
+    from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
+    from comfyui_vrgamedevgirl_amd import cube
+    import torch.distributed as dist
+
+    rank, local, world = sharding.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    H, W, stages = WORKLOADS[args.workload]
+    frames = args.frames or (128 if H == 1080 else 256)
+    chunk = 4
+
+    lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
+    lut = ops.upload_lut(lut_cpu, dev)
+    x = make_frames(frames, H, W, dev, 1234 + rank, args.dist)
+    out = torch.empty_like(x)
+    ref = make_frames(1, H, W, dev, 4321, args.dist)          # same reference frame on every rank
+    fe = H * W * 3
+
+    # one job-wide generator state: rank r takes chunks [r*frames/chunk, ...) of the same stream, so the result
+    # does not depend on the number of GPUs
+    geom_stream = None
+    if "grain" in stages:
+        gen = torch.Generator(device=dev).manual_seed(42)
+        geom_stream = ops.rng.reserve(chunk * fe, world * frames // chunk, dev, gen)
+
+    def step(kernel_events=None):
+        ref_ms = None
+        if "colormatch" in stages:
+            ref_ms = sharding.reference_stats_sharded(ref, rank, world)
+        plans = None
+        if geom_stream is not None:
+            plans = (ops.NoisePlan(chunk, geom_stream, chunk0=rank * (frames // chunk)), None, frames // chunk)
+        spec = ops.ChainSpec(grain=(0.04, 0.5, chunk) if "grain" in stages else None,
+                             lut=(lut, 10.0) if "lut" in stages else None,
+                             colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
+                             sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None)
+        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    px_rank = frames * H * W
+    value = world * px_rank * args.steps / elapsed / 1e6
+    kern_ms = [a.elapsed_ms(b) for a, b in events]
+    kern_avg_ms = sum(kern_ms) / max(len(kern_ms), 1)
+    algo_bytes = 24 * px_rank                       # fused apply pass: 12 B/px read + 12 B/px written
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    bytes_per_px_chain = 36 if "colormatch" in stages else 24
+
+    if rank == 0:
+        line = {
+            "metric": "Mpixels/s (grain+LUT+colormatch+sharpen) at 4K" if args.workload == "chain4_4k" else f"Mpixels/s ({'+'.join(stages)})",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic-{args.dist} (generated on device, resident in HBM)",
+            "config": {"workload": f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)} fused chain, LUT 33^3, grain chunk {chunk} "
+                                   f"(BASELINE configs[4] per-GPU shard)" if args.workload == "chain4_4k"
+                       else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
+                       "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
+                       "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain},
+            "chain_hbm_frac": round(value / world * bytes_per_px_chain * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": "k_chain_tile / k_chain_pointwise (fused apply pass)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(stages, args.cpu_frames if H > 1080 else 4 * args.cpu_frames, H, W, lut_cpu)
+            except Exception as exc:      # never lose the GPU line to a host-side problem
+                line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+                                        "sample": f"failed: {type(exc).__name__}: {exc}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

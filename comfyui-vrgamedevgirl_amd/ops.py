@@ -341,12 +341,19 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
     return d
 
 
-def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
+def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
+                out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
-    pass).  Bit-identical to applying the stand-alone operators in that order."""
+    pass).  Bit-identical to applying the stand-alone operators in that order.
+
+    `out` may supply the destination (bench: no allocation in the timed region); `kernel_events`, if a list,
+    receives (start, stop) HipEvent pairs bracketing each vrg_fused_chain_f32 launch on the current stream."""
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous float32 tensor shaped like images on the same device")
     if F == 0:
         return out
     fe = H * W * 3
@@ -378,7 +385,13 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             img_ms = finalize_stats(stats)
             d.img_ms = img_ms.data_ptr()
             keep.append(img_ms)
+        if kernel_events is not None:
+            e0, e1 = HipEvent(), HipEvent()
+            e0.record()
         _hip.check(lib.vrg_fused_chain_f32(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_f32")
+        if kernel_events is not None:
+            e1.record()
+            kernel_events.append((e0, e1))
     return out
 
 

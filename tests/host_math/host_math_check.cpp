@@ -1,0 +1,79 @@
+// Arithmetic-order checker (TEST SCAFFOLDING, built by tests/test_host_math.py with g++, no GPU).
+//
+// Instantiates the kernels' per-pixel math header (csrc/vrg_pixel_math.hpp) on the host so that
+// operation order, rounding points, index arithmetic and the Philox integer pipeline can be compared
+// with the oracle before any GPU time is spent.  It is NOT a CPU fallback: nothing in the package can
+// load it, and the three hardware transcendentals of the Box-Muller transform are replaced by libm
+// stand-ins (so normals are only checked to a tolerance here; the bit-exact check is -m gpu).
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#define VRG_HW_LOG2(x) log2f(x)
+#define VRG_HW_SIN_REV(x) sinf((x) * 6.28318530717958647692f)
+#define VRG_HW_COS_REV(x) cosf((x) * 6.28318530717958647692f)
+#include "vrg_pixel_math.hpp"
+
+using namespace vrg;
+
+extern "C" {
+
+void hm_philox(uint64_t seed, uint64_t subsequence, uint64_t counter, uint32_t out[4]) {
+    const u32x4 r = philox_for(seed, subsequence, counter);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+void hm_randn(uint64_t seed, uint64_t offset, uint32_t G, int64_t numel, float* out) {
+    for (int64_t i = 0; i < numel; ++i) out[i] = torch_randn_element(seed, offset, G, (uint64_t)i);
+}
+
+void hm_grain(const float* x, const float* n, float* o, int64_t pixels, float I, float S, float T) {
+    for (int64_t p = 0; p < pixels; ++p) grain_pixel(x + 3 * p, n + 3 * p, I, S, T, o + 3 * p);
+}
+
+void hm_lut(const float* x, float* o, int64_t pixels, const float* table, int n, const float* dmin, const float* dmax,
+            int blend_mode, float blend, float one_minus_blend) {
+    LutParams P;
+    P.table = table; P.n = n; P.top = (float)(n - 1); P.unit_domain = 1;
+    for (int c = 0; c < 3; ++c) {
+        P.dmin[c] = dmin[c];
+        const float span = dmax[c] - dmin[c];
+        P.span[c] = span < 1e-6f ? 1e-6f : span;
+        if (!(P.dmin[c] == 0.0f && P.span[c] == 1.0f)) P.unit_domain = 0;
+    }
+    P.blend_mode = blend_mode; P.blend = blend; P.one_minus_blend = one_minus_blend;
+    for (int64_t p = 0; p < pixels; ++p) lut_pixel(P, x + 3 * p, o + 3 * p);
+}
+
+void hm_stencil(const float* in, float* out, int F, int H, int W, int C, int op, int zero_border, float strength) {
+    for (int f = 0; f < F; ++f)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int c = 0; c < C; ++c) {
+                    float p[3][3];
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            int yy = y + dy, xx = x + dx;
+                            const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                            const float v = in[(((int64_t)f * H + yy) * W + xx) * C + c];
+                            p[dy + 1][dx + 1] = (zero_border && !inside) ? 0.0f : v;
+                        }
+                    out[(((int64_t)f * H + y) * W + x) * C + c] = stencil_value(op, p, strength, zero_border);
+                }
+}
+
+void hm_rgb_to_lab(const float* x, float* o, int64_t pixels) {
+    for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p);
+}
+
+void hm_lab_to_rgb(const float* x, float* o, int64_t pixels) {
+    for (int64_t p = 0; p < pixels; ++p) lab_to_rgb(x + 3 * p, o + 3 * p);
+}
+
+// ms arrays: [3][2] = {mean, std+1e-5}
+void hm_colormatch(const float* x, float* o, int64_t pixels, const float* img_ms, const float* ref_ms, float K, float T) {
+    for (int64_t p = 0; p < pixels; ++p) colormatch_pixel(x + 3 * p, img_ms, ref_ms, K, T, o + 3 * p);
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""The C-ABI library loads and exports every symbol include/vrgdg_hip.h declares; argument validation
+works without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import PKG_DIR, ROOT
+
+
+@pytest.fixture(scope="module")
+def hip(pkg):
+    from comfyui_vrgamedevgirl_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        from comfyui_vrgamedevgirl_amd import build_ext
+        build_ext.build(verbose=False)
+    return _hip
+
+
+def test_header_symbols_are_exported(hip):
+    header = open(os.path.join(ROOT, "include", "vrgdg_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(vrg_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes found"
+    lib = hip.load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in vrgdg_hip.h but not exported"
+    assert declared == set(hip.EXPORTED_SYMBOLS), "ctypes prototypes out of sync with the header"
+
+
+def test_struct_layouts_match_the_header(hip):
+    # vrg_noise_desc: 4*u64 + i64 + i32 + u32 = 48 bytes
+    assert C.sizeof(hip.NoiseDesc) == 48
+    assert hip.ChainDesc.noise.offset % 8 == 0 and hip.ChainDesc.lut.offset % 8 == 0
+    assert hip.ChainDesc.img_ms.offset % 8 == 0
+
+
+def test_versions_and_error_strings(hip):
+    lib = hip.load_library()
+    assert lib.vrg_abi_version() == 1
+    assert lib.vrg_error_string(0) == b"ok"
+    assert b"argument" in lib.vrg_error_string(1)
+    assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8
+    assert lib.vrg_lab_stats_scratch_bytes(-1) == 0
+
+
+def test_argument_validation_without_device(hip):
+    lib = hip.load_library()
+    null = C.c_void_p(0)
+    one = C.c_void_p(16)   # never dereferenced: validation fails or sizes are zero
+    nd = hip.NoiseDesc(seed0=1, chunk_frames=1, grid_threads=256)
+    f3 = (C.c_float * 3)(0, 0, 0)
+    g3 = (C.c_float * 3)(1, 1, 1)
+    assert lib.vrg_grain_f32(null, one, 1, 4, 4, 0.1, 0.5, 0.5, C.byref(nd), null) == 1
+    assert lib.vrg_grain_f32(one, one, 0, 4, 4, 0.1, 0.5, 0.5, C.byref(nd), null) == 0          # zero frames: no launch
+    bad = hip.NoiseDesc(seed0=1, chunk_frames=1, grid_threads=100)
+    assert lib.vrg_grain_f32(one, one, 1, 4, 4, 0.1, 0.5, 0.5, C.byref(bad), null) == 1
+    nd2 = hip.NoiseDesc(seed0=1, chunk_frames=2, grid_threads=256)
+    assert lib.vrg_grain_f32(one, one, 3, 4, 4, 0.1, 0.5, 0.5, C.byref(nd2), null) == 1         # ragged chunk
+    assert lib.vrg_lut3d_f32(one, one, 0, 3, one, 17, f3, g3, 1, 1.0, 0.0, null) == 0
+    assert lib.vrg_lut3d_f32(one, one, 4, 2, one, 17, f3, g3, 1, 1.0, 0.0, null) == 1            # C < 3
+    assert lib.vrg_lut3d_f32(one, one, 4, 3, one, 17, f3, g3, 7, 1.0, 0.0, null) == 1            # bad blend mode
+    assert lib.vrg_stencil3x3_f32(one, one, 0, 4, 4, 3, 0, 0, 0.5, null) == 0
+    assert lib.vrg_stencil3x3_f32(one, one, 1, 4, 4, 3, 9, 0, 0.5, null) == 1
+    assert lib.vrg_stencil3x3_f32(one, one, 1, 4, 4, 3, 0, 5, 0.5, null) == 1
+    assert lib.vrg_colormatch_apply_f32(one, one, 1, 4, 4, null, one, 1, 1.0, 0.0, null) == 1
+    cd = hip.ChainDesc(stages=0)
+    assert lib.vrg_fused_chain_f32(one, one, 1, 4, 4, C.byref(cd), null) == 1
+    cd = hip.ChainDesc(stages=8, variant=99, stencil_op=0, border=0)
+    assert lib.vrg_fused_chain_f32(one, one, 1, 4, 4, C.byref(cd), null) == 2                    # unknown variant
+    assert lib.vrg_fused_chain_f32(one, one, 0, 4, 4, C.byref(cd), null) == 0

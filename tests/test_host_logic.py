@@ -1,0 +1,163 @@
+"""Host-side logic that needs no GPU: generator bookkeeping, .cube I/O, blend terms, staging groups,
+statistics merging."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox as PH
+from oracle import restated as R
+from conftest import GOLDEN
+
+
+class FakeGen:
+    def __init__(self, seed=1234, offset=0):
+        self.seed, self.offset = seed, offset
+
+    def initial_seed(self):
+        return self.seed
+
+    def get_offset(self):
+        return self.offset
+
+    def set_offset(self, v):
+        self.offset = v
+
+
+def test_rng_geometry_matches_oracle_restatement(pkg):
+    from comfyui_vrgamedevgirl_amd import rng
+    geom = rng.DeviceGeometry(256, 2048)
+    assert geom.max_grid == 2048
+    for numel in (1, 255, 256, 257, 3 * 512 * 512, 4 * 1080 * 1920 * 3, 4 * 2160 * 3840 * 3, 536870911):
+        G = rng.grid_threads(numel, geom)
+        assert G == PH.torch_grid_threads(numel, 256)
+        assert rng.counter_offset(numel, G) == PH.torch_counter_offset(numel, G)
+        plan, new_off = PH.torch_randn_plan(numel, 40, 256)
+        assert plan == [(0, numel, G, 40)] and new_off == 40 + rng.counter_offset(numel, G)
+    assert rng.grid_threads(4 * 2160 * 3840 * 3, geom) == 524288
+
+
+def test_rng_reserve_advances_generator_like_successive_randn_calls(pkg):
+    from comfyui_vrgamedevgirl_amd import rng
+    geom = rng.DeviceGeometry(256, 2048)
+    gen = FakeGen(seed=99, offset=12)
+    numel = 4 * 64 * 64 * 3
+    s = rng.reserve(numel, 5, torch.device("cpu"), generator=gen, geom=geom)
+    G = PH.torch_grid_threads(numel, 256)
+    step = PH.torch_counter_offset(numel, G)
+    assert (s.seed, s.offset0, s.offset_stride, s.grid_threads, s.seed_stride) == (99, 12, step, G, 0)
+    assert gen.offset == 12 + 5 * step
+    with pytest.raises(NotImplementedError):
+        rng.reserve(rng.MAX_CHUNK_NUMEL + 1, 1, torch.device("cpu"), generator=gen, geom=geom)
+
+
+def test_oracle_split_plan_for_oversized_randn():
+    # documents what torch does above 32-bit indexing (the in-register path refuses these chunks)
+    n = 3 * 536870911
+    parts = PH.split_32bit(n)
+    assert sum(l for _, l in parts) == n and all(l <= 536870911 + 1 for _, l in parts)
+    assert [s for s, _ in parts] == sorted(s for s, _ in parts)
+    plan, off = PH.torch_randn_plan(n, 0, 256)
+    assert len(plan) == len(parts) and plan[0][3] > 0       # the outer call consumed an offset first
+
+
+def test_plan_noise_full_and_tail_chunks(pkg, monkeypatch):
+    from comfyui_vrgamedevgirl_amd import ops, rng
+    geom = rng.DeviceGeometry(256, 2048)
+    monkeypatch.setattr(rng, "device_geometry", lambda device=None: geom)
+    gen = FakeGen(seed=5, offset=0)
+    fe = 12 * 16 * 3
+    main, tail, n_full = ops.plan_noise(7, fe, 3, torch.device("cpu"), gen)
+    assert n_full == 2 and main.chunk_frames == 3 and tail.chunk_frames == 1
+    assert main.stream.offset0 == 0 and tail.stream.offset0 == 2 * main.stream.offset_stride
+    assert gen.offset == tail.stream.offset0 + rng.counter_offset(fe, rng.grid_threads(fe, geom))
+    main, tail, n_full = ops.plan_noise(4, fe, 0, torch.device("cpu"), FakeGen())
+    assert n_full == 1 and main.chunk_frames == 4 and tail is None
+    main, tail, n_full = ops.plan_noise(2, fe, 8, torch.device("cpu"), FakeGen())
+    assert n_full == 1 and main.chunk_frames == 2 and tail is None      # batch_size > F: one chunk of F
+
+
+def test_blend_terms(pkg):
+    from comfyui_vrgamedevgirl_amd import ops
+    assert ops.blend_terms(0.0)[0] == 0 and ops.blend_terms(-3)[0] == 0
+    assert ops.blend_terms(10.0) == (1, 1.0, 0.0) and ops.blend_terms(99)[0] == 1
+    mode, B, omB = ops.blend_terms(3.3)
+    assert mode == 2 and B == float(np.float32(0.33)) and omB == float(np.float32(1.0 - 0.33))
+    assert R.lut_blend_factor(3.3) == 3.3 / 10.0 and B == float(np.float32(3.3 / 10.0)) and omB == float(np.float32(1.0 - 3.3 / 10.0))
+
+
+@pytest.mark.parametrize("fname", ["synthetic_17.cube", "synthetic_domain_9.cube"])
+def test_cube_parser_matches_oracle(pkg, fname):
+    from comfyui_vrgamedevgirl_amd import cube
+    a = cube.parse_cube_file(os.path.join(GOLDEN, fname))
+    b = R.parse_cube_file(os.path.join(GOLDEN, fname))
+    assert a["size"] == b["size"]
+    for k in ("lut", "domain_min", "domain_max"):
+        assert torch.equal(a[k], b[k]) and a[k].dtype == torch.float32
+
+
+def test_cube_writer_roundtrip_and_errors(pkg, tmp_path):
+    from comfyui_vrgamedevgirl_amd import cube
+    table = cube.build_palette_lut("#0b1d51, #1f6aa5, #f3d27a", 9)
+    assert table.shape == (9, 9, 9, 3) and table.dtype == torch.float32 and 0 <= table.min() and table.max() <= 1
+    path = str(tmp_path / "sub" / "x.cube")
+    cube.write_cube_file(table, path)
+    back = cube.parse_cube_file(path)
+    assert back["size"] == 9 and (back["lut"] - table).abs().max() <= 5.1e-7      # %.6f text
+    assert torch.equal(back["lut"], R.parse_cube_file(path)["lut"])
+    assert cube.next_available_lut_path(str(tmp_path / "sub"), "x").endswith("x_2.cube")
+    assert cube.sanitize_filename_part("  #FF 88/00 ") == "ff_88_00" and cube.sanitize_filename_part("") == "custom"
+    assert np.allclose(cube.parse_hex_color("teal"), [0, 128 / 255, 128 / 255]) and np.allclose(cube.parse_hex_color("#fff"), 1)
+    for bad in ("#12345", "nope", "#gggggg"):
+        with pytest.raises(ValueError):
+            cube.parse_hex_color(bad)
+    with pytest.raises(ValueError):
+        cube.parse_color_list(" , ")
+    p = tmp_path / "b.cube"
+    for text in ("LUT_1D_SIZE 2\n", "0 0 0\n", "LUT_3D_SIZE 2\n0 0 0\n", "LUT_3D_SIZE 2 2\n", "LUT_3D_SIZE 2\nDOMAIN_MIN 0 0\n"):
+        p.write_text(text)
+        with pytest.raises(ValueError):
+            cube.parse_cube_file(str(p))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/LUTS"), reason="reference assets not present")
+def test_cube_parser_on_shipped_reference_assets(pkg):
+    from comfyui_vrgamedevgirl_amd import cube
+    for name in sorted(os.listdir("/root/reference/LUTS")):
+        if name.endswith(".cube"):
+            a = cube.parse_cube_file(os.path.join("/root/reference/LUTS", name))
+            b = R.parse_cube_file(os.path.join("/root/reference/LUTS", name))
+            assert torch.equal(a["lut"], b["lut"]) and torch.equal(a["domain_min"], b["domain_min"]), name
+
+
+def test_palette_lut_matches_reference_generator(pkg):
+    from oracle import reference_loader as RL
+    if not RL.reference_available():
+        pytest.skip("reference not present")
+    from comfyui_vrgamedevgirl_amd import cube
+    iv = RL.load_iv_adjustments()
+    for colors, n in (("#0b1d51, #1f6aa5, #f3d27a", 8), ("red", 9), ("teal, orange", 11)):
+        assert torch.equal(cube.build_palette_lut(colors, n), iv._build_palette_lut(colors, n))
+
+
+def test_frame_groups(pkg):
+    from comfyui_vrgamedevgirl_amd import _devices as D
+    fb = 2160 * 3840 * 3 * 4
+    groups = list(D.frame_groups(37, fb, multiple_of=4))
+    assert groups[0][0] == 0 and groups[-1][1] == 37
+    assert all(a1 == b0 for (_, a1), (b0, _) in zip(groups, groups[1:]))
+    assert all((e - s) % 4 == 0 for s, e in groups[:-1]) and all((e - s) * fb <= max(D.STAGE_BYTES, 4 * fb) for s, e in groups)
+    assert list(D.frame_groups(0, fb)) == []
+
+
+def test_merge_stats_is_chan(pkg):
+    from comfyui_vrgamedevgirl_amd import ops
+    g = np.random.default_rng(0)
+    data = g.normal(50, 20, size=(4, 1000))
+    parts = torch.tensor([[len(d), d.mean(), ((d - d.mean()) ** 2).sum()] for d in data], dtype=torch.float64)
+    merged = ops.merge_stats(parts)
+    allv = data.reshape(-1)
+    assert merged[0].item() == allv.size
+    assert abs(merged[1].item() - allv.mean()) < 1e-10
+    assert abs(merged[2].item() - ((allv - allv.mean()) ** 2).sum()) < 1e-6

@@ -1,0 +1,153 @@
+"""Kernel arithmetic checked without a GPU: csrc/vrg_pixel_math.hpp compiled for the host by g++ (test
+scaffolding, see tests/host_math/host_math_check.cpp) against the oracle and the golden fixtures.
+
+What this pins before any GPU minute is spent: operation order and rounding points of grain / LUT /
+stencils (bit-exact), the Philox4x32-10 integer pipeline and torch's element->(subsequence, call, component)
+mapping (bit-exact against oracle/philox.py), the Lab transforms (to libm-vs-torch pow tolerance)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox as PH
+from oracle import restated as R
+from conftest import GOLDEN, PKG_DIR, ROOT
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+
+F32P = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+@pytest.fixture(scope="module")
+def hm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("host_math") / "libhost_math.so"
+    src = os.path.join(ROOT, "tests", "host_math", "host_math_check.cpp")
+    cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-msse2", "-mfpmath=sse", "-fPIC", "-shared",
+           "-I", os.path.join(PKG_DIR, "csrc"), src, "-o", str(out)]
+    subprocess.run(cmd, check=True)
+    lib = C.CDLL(str(out))
+    lib.hm_philox.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.hm_randn.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_int64, F32P]
+    lib.hm_grain.argtypes = [F32P, F32P, F32P, C.c_int64, C.c_float, C.c_float, C.c_float]
+    lib.hm_lut.argtypes = [F32P, F32P, C.c_int64, F32P, C.c_int, F32P, F32P, C.c_int, C.c_float, C.c_float]
+    lib.hm_stencil.argtypes = [F32P, F32P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    lib.hm_rgb_to_lab.argtypes = [F32P, F32P, C.c_int64]
+    lib.hm_lab_to_rgb.argtypes = [F32P, F32P, C.c_int64]
+    lib.hm_colormatch.argtypes = [F32P, F32P, C.c_int64, F32P, F32P, C.c_float, C.c_float]
+    return lib
+
+
+def f32(v):
+    return float(np.float32(v))
+
+
+def test_philox_known_answers(hm):
+    # Random123 kat_vectors for philox4x32_10
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = PH.philox4x32_10(*[np.array([c], dtype=np.uint32) for c in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
+        out = (C.c_uint32 * 4)()
+        hm.hm_philox(key[0] | (key[1] << 32), ctr[2] | (ctr[3] << 32), ctr[0] | (ctr[1] << 32), out)
+        assert tuple(out) == want
+
+
+@pytest.mark.parametrize("numel,G,offset", [(1000, 256, 0), (5000, 512, 8), (3 * 7 * 5, 256, 4), (9000, 1024, 4096)])
+def test_torch_element_mapping(hm, numel, G, offset):
+    seed = 0x1234567887654321
+    out = np.empty(numel, dtype=np.float32)
+    hm.hm_randn(seed, offset, G, numel, out)
+    want = PH.torch_stream_normals_f64(numel, seed, offset, G)
+    # libm stand-ins for v_log/v_sin/v_cos: agreement to a few 1e-6 proves seed/offset/idx/call/component wiring
+    assert np.max(np.abs(out.astype(np.float64) - want)) < 2e-5
+    assert abs(out.mean()) < 0.2 and 0.8 < out.std() < 1.2
+
+
+def test_grain_bit_exact(hm):
+    z = np.load(os.path.join(GOLDEN, "grain.npz"))
+    x = np.ascontiguousarray(z["x"])
+    for tag in ("default", "strong_colour", "mono_all", "workflow_widgets"):
+        I, s = float(z[f"{tag}.I"]), float(z[f"{tag}.s"])
+        n = np.ascontiguousarray(z[f"{tag}.noise"])
+        o = np.empty_like(x)
+        hm.hm_grain(x, n, o, x.size // 3, f32(I), f32(s), f32(1.0 - s))
+        assert np.array_equal(o, z[f"{tag}.out"]), tag
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_lut_bit_exact(hm, tag):
+    z = np.load(os.path.join(GOLDEN, "lut.npz"))
+    img = np.ascontiguousarray(z[f"{tag}.img"])
+    table = np.ascontiguousarray(z[f"{tag}.lut"])
+    dmin, dmax = np.ascontiguousarray(z[f"{tag}.dmin"]), np.ascontiguousarray(z[f"{tag}.dmax"])
+    for s, key in ((10.0, "out.s10.0"), (25.0, "out.s25.0"), (3.3, "out.s3.3"), (6.5, "route.s6.5")):
+        blend = max(0.0, min(10.0, s)) / 10.0
+        mode = 1 if blend >= 1.0 else 2
+        o = np.empty_like(img)
+        hm.hm_lut(img, o, img.size // 3, table, table.shape[0], dmin, dmax, mode, f32(blend), f32(1.0 - blend))
+        assert np.array_equal(o, z[f"{tag}.{key}"]), (tag, s)
+
+
+def test_lut_random_vs_oracle(hm):
+    g = torch.Generator().manual_seed(3)
+    lut = R.parse_cube_file(os.path.join(GOLDEN, "synthetic_17.cube"))
+    img = (torch.rand(1, 64, 64, 3, generator=g) * 1.3 - 0.15).contiguous()
+    want = R.apply_cube_lut(img, lut["lut"], lut["domain_min"], lut["domain_max"]).numpy()
+    o = np.empty_like(want)
+    hm.hm_lut(img.numpy(), o, img.numel() // 3, lut["lut"].numpy(), 17, lut["domain_min"].numpy(), lut["domain_max"].numpy(),
+              1, 1.0, 0.0)
+    assert np.array_equal(o, want)
+
+
+def test_stencils_bit_exact(hm):
+    z = np.load(os.path.join(GOLDEN, "stencil.npz"))
+    ops = {"unsharp": 0, "laplacian": 1, "sobel": 2}
+    for tag in ("rand", "odd", "one", "row", "col", "c4", "const"):
+        x = np.ascontiguousarray(z[f"{tag}.x"])
+        F, H, W, Cn = x.shape
+        for s in (0.5, 3.75):
+            for zero in (0, 1):
+                o = np.empty_like(x)
+                hm.hm_stencil(x, o, F, H, W, Cn, 0, zero, f32(s))
+                assert np.array_equal(o, z[f"{tag}.unsharp.{s}.{zero}"]), (tag, s, zero)
+        for name in ("laplacian", "sobel"):
+            o = np.empty_like(x)
+            hm.hm_stencil(x, o, F, H, W, Cn, ops[name], 0, f32(0.8))
+            assert np.array_equal(o, z[f"{tag}.{name}.0.8.0"]), (tag, name)
+            # zero border: kernel order = explicit raster restatement (bit-exact) ~ conv2d (1 ulp)
+            xt = torch.from_numpy(x)
+            hm.hm_stencil(x, o, F, H, W, Cn, ops[name], 1, f32(0.8))
+            want = (R.laplacian_zero_raster if name == "laplacian" else R.sobel_zero_raster)(xt, 0.8).numpy()
+            assert np.array_equal(o, want), (tag, name, "zero")
+            if Cn == 3:
+                assert np.max(np.abs(o - z[f"{tag}.{name}.0.8.1"])) <= 5e-7
+
+
+def test_lab_and_colormatch_close_to_oracle(hm):
+    g = torch.Generator().manual_seed(11)
+    rgb = torch.rand(1, 40, 40, 3, generator=g).contiguous()
+    lab = np.empty((1600, 3), dtype=np.float32)
+    hm.hm_rgb_to_lab(rgb.numpy(), lab, 1600)
+    want = R.kornia_rgb_to_lab(rgb.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(-1, 3).numpy()
+    assert np.max(np.abs(lab - want)) < 1.5e-4        # libm vs Sleef powf differ by an ulp; a,b = 500*(fx-fy), 200*(fy-fz) amplify it
+    back = np.empty_like(lab)
+    hm.hm_lab_to_rgb(np.ascontiguousarray(want), back, 1600)
+    want_rgb = R.kornia_lab_to_rgb(torch.from_numpy(want).reshape(1, 40, 40, 3).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(-1, 3).numpy()
+    assert np.max(np.abs(back - want_rgb)) < 2e-6
+    # whole colour-match pixel function given the oracle's statistics
+    ref = torch.rand(1, 8, 8, 3, generator=g)
+    x_nchw = rgb.permute(0, 3, 1, 2)
+    mu, sd = R.lab_stats(R.kornia_rgb_to_lab(x_nchw))
+    rmu, rsd = R.lab_stats(R.kornia_rgb_to_lab(ref.permute(0, 3, 1, 2)))
+    ims = torch.stack([mu.flatten(), sd.flatten()], dim=-1).contiguous().numpy()
+    rms = torch.stack([rmu.flatten(), rsd.flatten()], dim=-1).contiguous().numpy()
+    out = np.empty((1600, 3), dtype=np.float32)
+    hm.hm_colormatch(rgb.numpy(), out, 1600, ims, rms, f32(0.8), f32(1.0 - 0.8))
+    want = R.color_match(rgb, ref, 0.8, 1).reshape(-1, 3).numpy()
+    assert np.max(np.abs(out - want)) < 5e-6

@@ -1,0 +1,165 @@
+"""GPU-box diagnostics + per-kernel micro-benchmarks in one go (writes gpurun_out/diag.json and prints a table).
+
+    python tools/gpu_diag.py [--frames 32] [--quick]
+
+Each section is independent (a failure is recorded, not fatal) so that one gpurun call yields as much
+information as possible: device properties, noise-stream agreement with torch.randn (with mismatch anatomy),
+and HIP-event timings of every stand-alone kernel and fused chain at 1080p / 4K with achieved algorithmic GB/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+OUT_DIR = os.path.join(ROOT, "gpurun_out")
+RESULT = {"sections": {}}
+
+
+def section(name):
+    def deco(fn):
+        def run(*a, **k):
+            t0 = time.time()
+            try:
+                RESULT["sections"][name] = {"ok": True, "data": fn(*a, **k)}
+            except Exception as exc:
+                RESULT["sections"][name] = {"ok": False, "error": f"{type(exc).__name__}: {exc}", "trace": traceback.format_exc()[-2000:]}
+                print(f"[diag] section {name} FAILED: {exc}", flush=True)
+            RESULT["sections"][name]["seconds"] = round(time.time() - t0, 2)
+        return run
+    return deco
+
+
+@section("device")
+def device_info():
+    p = torch.cuda.get_device_properties(0)
+    d = {"name": p.name, "cus": p.multi_processor_count, "max_threads_per_cu": p.max_threads_per_multi_processor,
+         "total_mem_gb": round(p.total_memory / 2 ** 30, 1), "torch": torch.__version__, "hip": torch.version.hip,
+         "gcn_arch": getattr(p, "gcnArchName", "?"), "host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads()}
+    print("[diag] device:", d, flush=True)
+    return d
+
+
+@section("noise")
+def noise_check(ops):
+    dev = torch.device("cuda", 0)
+    res = {}
+    for frames, fe, chunk in ((1, 105, 1), (2, 3 * 64 * 64, 1), (8, 3 * 512 * 512, 4)):
+        torch.manual_seed(1)
+        want = torch.cat([torch.randn(chunk * fe, device=dev) for _ in range(frames // chunk)])
+        torch.manual_seed(1)
+        main, tail, n_full = ops.plan_noise(frames, fe, chunk, dev)
+        got = ops.torch_stream_noise(frames, fe, main, dev).flatten()
+        neq = got != want
+        info = {"mismatch": int(neq.sum()), "numel": got.numel(), "max_abs": float((got - want).abs().max())}
+        if info["mismatch"]:
+            idx = torch.nonzero(neq).flatten()[:8].tolist()
+            info["first"] = [(i, float(got[i]), float(want[i])) for i in idx]
+            # anatomy: are the values close (Box-Muller rounding) or unrelated (mapping bug)?
+            info["close_frac"] = float(((got - want).abs() < 1e-4).float().mean())
+        res[f"{frames}x{fe}/{chunk}"] = info
+        print("[diag] noise", frames, fe, chunk, info, flush=True)
+    return res
+
+
+def time_it(fn, iters, ops):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = ops.HipEvent(), ops.HipEvent()
+        a.record()
+        fn()
+        b.record()
+        ts.append(a.elapsed_ms(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+@section("kernels")
+def kernel_bench(ops, frames_4k, iters):
+    from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
+    from comfyui_vrgamedevgirl_amd import cube
+    dev = torch.device("cuda", 0)
+    rows = []
+    lut33 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
+    lut25 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_WarmFilm_25.cube")), dev)
+    for label, H, W, F in (("1080p", 1080, 1920, frames_4k * 4), ("4K", 2160, 3840, frames_4k)):
+        g = torch.Generator(device=dev).manual_seed(3)
+        x = torch.rand((F, H, W, 3), generator=g, device=dev)
+        smooth = (x * 0.05 + 0.5 * (torch.linspace(0, 1, W, device=dev).view(1, 1, W, 1) + torch.linspace(0, 1, H, device=dev).view(1, H, 1, 1)) * 0.9).contiguous()
+        out = torch.empty_like(x)
+        px = F * H * W
+        ref_ms = ops.finalize_stats(ops.lab_stats(x[:1]))
+        gen = torch.Generator(device=dev).manual_seed(5)
+        img_ms = ops.finalize_stats(ops.lab_stats(x))
+
+        def chain(stages_spec, src=x):
+            return lambda: ops.fused_chain(src, stages_spec, generator=gen, out=out)
+
+        cases = [
+            ("copy (torch)", 24, lambda: out.copy_(x)),
+            ("grain bs=4", 24, lambda: ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen)),
+            ("grain injected", 36, lambda: ops.film_grain_injected(x, x, 0.04, 0.5)),
+            ("lut33 uniform", 24, lambda: ops.lut3d(x, lut33, 10.0)),
+            ("lut33 smooth", 24, lambda: ops.lut3d(smooth, lut33, 10.0)),
+            ("lut25 uniform", 24, lambda: ops.lut3d(x, lut25, 10.0)),
+            ("lut33 blend 0.5", 24, lambda: ops.lut3d(x, lut33, 5.0)),
+            ("unsharp replicate", 24, lambda: ops.stencil3x3(x, "unsharp", 0.5, False)),
+            ("unsharp zero", 24, lambda: ops.stencil3x3(x, "unsharp", 0.5, True)),
+            ("laplacian", 24, lambda: ops.stencil3x3(x, "laplacian", 0.5, False)),
+            ("sobel", 24, lambda: ops.stencil3x3(x, "sobel", 0.5, False)),
+            ("lab stats", 12, lambda: ops.lab_stats(x)),
+            ("colormatch apply", 24, lambda: ops.colormatch_apply(x, img_ms, ref_ms, 1.0)),
+            ("colormatch 2-pass", 36, lambda: ops.color_match(x, None, 1.0, ref_ms=ref_ms)),
+            ("fused tile sharpen only", 24, chain(ops.ChainSpec(sharpen=("unsharp", 0.5, False)))),
+            ("fused lut+sharpen", 24, chain(ops.ChainSpec(lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)))),
+            ("fused lut+sharpen smooth", 24, chain(ops.ChainSpec(lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)), smooth)),
+            ("fused grain+lut", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0)))),
+            ("fused grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)))),
+            ("fused grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)))),
+            ("fused 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)))),
+        ]
+        for name, bpp, fn in cases:
+            try:
+                med, best = time_it(fn, iters, ops)
+                row = {"size": label, "frames": F, "kernel": name, "ms": round(med, 4), "best_ms": round(best, 4),
+                       "mpix_s": round(px / med / 1e3, 1), "algo_gbs": round(px * bpp / med / 1e6, 1),
+                       "frac_8tbs": round(px * bpp / med / 1e6 / 8000.0, 4)}
+            except Exception as exc:
+                row = {"size": label, "kernel": name, "error": f"{type(exc).__name__}: {exc}"}
+            rows.append(row)
+            print("[diag]", row, flush=True)
+        del x, smooth, out
+        torch.cuda.empty_cache()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16, help="4K frames per timing batch (1080p uses 4x)")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--out", default=os.path.join(OUT_DIR, "diag.json"))
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    load_package()
+    from comfyui_vrgamedevgirl_amd import ops
+    device_info()
+    noise_check(ops)
+    kernel_bench(ops, args.frames, args.iters)
+    with open(args.out, "w") as fh:
+        json.dump(RESULT, fh, indent=1)
+    print("[diag] written", args.out)
+
+
+if __name__ == "__main__":
+    main()
