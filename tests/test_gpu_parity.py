@@ -284,7 +284,9 @@ def test_colour_match_apply_with_oracle_statistics(ops, dev):
     rms = torch.stack([rmu.flatten(1), rsd.flatten(1)], dim=-1).contiguous().to(dev)
     got = ops.colormatch_apply(x.to(dev), ims, rms, 0.8).cpu()
     want = R.color_match(x, ref, 0.8, 1)
-    assert (got - want).abs().max() <= 3e-6, (got - want).abs().max()
+    # same statistics on both sides: what is left is ocml powf vs Sleef powf (an ulp per call, amplified by the
+    # 500/200 Lab gains and the inverse transform); measured 7.7e-6 on MI355X
+    assert (got - want).abs().max() <= CM_ABS_TOL, (got - want).abs().max()
 
 
 def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
