@@ -47,10 +47,13 @@ _SIGNATURES = {
     "vrg_event_record": (C.c_int, [_P, _P]),
     "vrg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "vrg_event_destroy": (C.c_int, [_P]),
+    "vrg_selftest_divconst": (C.c_int, [_P, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
     "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(NoiseDesc), _P]),
     "vrg_grain_injected_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P]),
+    "vrg_lut_cells_floats": (C.c_int64, [C.c_int32]),
+    "vrg_lut_prepare_f32": (C.c_int, [_P, C.c_int32, _P, _P]),
     "vrg_lut3d_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, C.c_int32, _F3, _F3, C.c_int32, C.c_float,
                                 C.c_float, _P]),
     "vrg_stencil3x3_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -21,7 +21,8 @@ __host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
 
 // grain -> LUT -> colour match for the pixel at (frame f of this call, pixel p of the frame).
 template <int STAGES>
-__device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3]) {
+__device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3],
+                                          const PowTables& PT) {
     float v[3] = {xin[0], xin[1], xin[2]};
     if (STAGES & VRG_STAGE_GRAIN) {
         const int64_t chunk = f / D.noise.chunk_frames;
@@ -45,7 +46,7 @@ __device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p,
         const float* ims = D.cm.img_ms + f * 6;
         const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
         float g[3];
-        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g);
+        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g, PT);
         v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
     }
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
@@ -56,13 +57,14 @@ __device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p,
 // ----------------------------------------------------------------------------------------------
 template <int STAGES>
 __global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__ in, px3* __restrict__ out, int32_t ppf, ChainK D) {
+    VRG_STAGE_POW_TABLES(PT);
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t f = blockIdx.y;
     const px3 v = in[f * ppf + p];
     const float x[3] = {v.r, v.g, v.b};
     float o[3];
-    chain_pre<STAGES>(D, f, p, x, o);
+    chain_pre<STAGES>(D, f, p, x, o, PT);
     out[f * ppf + p] = px3{o[0], o[1], o[2]};
 }
 
@@ -79,6 +81,7 @@ template <int STAGES>
 __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
                                                      int32_t tiles_x, ChainK D) {
     __shared__ float tile[3][HALO_H][LDS_PITCH];
+    VRG_STAGE_POW_TABLES(PT);
     const int32_t ty0 = (blockIdx.x / tiles_x) * TILE_H;
     const int32_t tx0 = (blockIdx.x % tiles_x) * TILE_W;
     const int64_t f = blockIdx.y;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
             const int32_t p = y * W + x;
             const px3 v = fin[p];
             const float xi[3] = {v.r, v.g, v.b};
-            chain_pre<STAGES>(D, f, p, xi, o);
+            chain_pre<STAGES>(D, f, p, xi, o, PT);
         }
         tile[0][hy][hx] = o[0];
         tile[1][hy][hx] = o[1];
@@ -143,6 +146,7 @@ template <int STAGES>
 __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                        double* __restrict__ partials) {
     __shared__ double red[4][6];
+    VRG_STAGE_POW_TABLES(PT);
     const int64_t f = blockIdx.y;
     const px3* fin = in + f * ppf;
     float pivot[3];
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
         const px3 v0 = fin[0];
         const float x0[3] = {v0.r, v0.g, v0.b};
         float pre[3];
-        chain_pre<STAGES>(D, f, 0, x0, pre);
-        rgb_to_lab(pre, pivot);
+        chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+        rgb_to_lab(pre, pivot, PT);
     }
     const int32_t per = (ppf + bpf - 1) / bpf;
     const int32_t lo = blockIdx.x * per;
@@ -161,8 +165,8 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
         const px3 v = fin[p];
         const float x[3] = {v.r, v.g, v.b};
         float pre[3], lab[3];
-        chain_pre<STAGES>(D, f, p, x, pre);
-        rgb_to_lab(pre, lab);
+        chain_pre<STAGES>(D, f, p, x, pre, PT);
+        rgb_to_lab(pre, lab, PT);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double d = (double)lab[c] - (double)pivot[c];
@@ -187,14 +191,15 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
 template <int STAGES>
 __global__ __launch_bounds__(64) void k_lab_merge(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                    const double* __restrict__ partials, double* __restrict__ stats) {
+    VRG_STAGE_POW_TABLES(PT);
     const int64_t f = blockIdx.x;
     float pivot[3];
     {
         const px3 v0 = in[f * ppf];
         const float x0[3] = {v0.r, v0.g, v0.b};
         float pre[3];
-        chain_pre<STAGES>(D, f, 0, x0, pre);
-        rgb_to_lab(pre, pivot);
+        chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+        rgb_to_lab(pre, pivot, PT);
     }
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;

@@ -47,10 +47,10 @@ inline NoiseK make_noise(const vrg_noise_desc* d, int64_t frame_elems) {
     return n;
 }
 
-inline LutParams make_lut(const float* table, int n, const float dmin[3], const float dmax[3], int blend_mode,
+inline LutParams make_lut(const float* cells, int n, const float dmin[3], const float dmax[3], int blend_mode,
                           float blend, float one_minus_blend) {
     LutParams P;
-    P.table = table; P.n = n; P.top = (float)(n - 1);
+    P.cells = cells; P.n = n; P.top = (float)(n - 1);
     P.unit_domain = 1;
     for (int c = 0; c < 3; ++c) {
         P.dmin[c] = dmin[c];
@@ -61,6 +61,13 @@ inline LutParams make_lut(const float* table, int n, const float dmin[3], const 
     P.blend_mode = blend_mode; P.blend = blend; P.one_minus_blend = one_minus_blend;
     return P;
 }
+
+// Stage the pow tables in LDS (2.5 KB) and return the views; every thread of the block must call it.
+#define VRG_STAGE_POW_TABLES(PT)                                                 \
+    __shared__ double vrg_pow_lds_[::vrg::POW_TABLE_DOUBLES];                     \
+    ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);      \
+    __syncthreads();                                                             \
+    const ::vrg::PowTables PT{vrg_pow_lds_, vrg_pow_lds_ + 256}
 
 #define VRG_CHECK_LAUNCH()                                   \
     do {                                                     \

@@ -46,6 +46,27 @@ VRG_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); 
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
 
 // ------------------------------------------------------------------------------------------
+// Division by a compile-time constant as multiply + two FMAs (Markstein): q = x*rc, r = fma(-c,q,x),
+// q' = fma(r,rc,q) with rc = RN(1/c).  For the constants used here (1.055, 12.92, 0.95047, 1.08883,
+// 116, 500, 200, 7.787, 9) this equals the IEEE quotient x/c bit for bit for every fp32 x with
+// 1e-30 <= |x| <= 1e30 (checked exhaustively over all 2^32 inputs, tests/test_host_math.py and the
+// -m gpu suite); for c = 9 it is exact for every finite x.  3 issue slots instead of ~14.
+// ------------------------------------------------------------------------------------------
+VRG_HD float div_const(float x, float c, float rc) {
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-c, q, x);
+    return __builtin_fmaf(r, rc, q);
+}
+#define VRG_DIVC(x, c) ::vrg::div_const((x), (c), 1.0f / (c))
+
+// x / 9.0f for the unsharp mean; +-Inf handled so that the result is IEEE for every input
+VRG_HD float div9(float x) {
+    const float q = VRG_DIVC(x, 9.0f);
+    return (x - x == 0.0f) ? q : x;   // Inf/NaN pass through like x/9
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 (rocrand_philox4x32_10.h:270-303)
 // ------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
@@ -153,9 +174,18 @@ VRG_HD void grain_pixel(const float x[3], const float n[3], float I, float S, fl
 // ------------------------------------------------------------------------------------------
 // 3D LUT (VRGDG_IV_Adjustments.py:293-336, blend :355-359)
 // ------------------------------------------------------------------------------------------
+// The table is consumed in CELL-MAJOR form: one 96-byte record per interpolation cell (b0,g0,r0)
+// holding, per output channel, the 8 corner values in the order k = (dr<<2)|(dg<<1)|db.  A pixel then
+// reads ONE contiguous record (6 x 16 B) instead of 8 scattered 12-byte corners of the [N][N][N][3]
+// table: for incoherent colours that cuts L2->L1 traffic from ~8 cache lines per pixel to ~1.5.
+// Built once per LUT by lut_build_cell(); values are copied, never re-rounded.
+struct alignas(16) f32x4 { float x, y, z, w; };
+
+constexpr int LUT_CELL_FLOATS = 24;
+
 struct LutParams {
-    const float* table;  // [N][N][N][3], index [b][g][r]
-    int n;
+    const float* cells;  // [(N-1)^3][24]
+    int n;               // N
     float top;           // (float)(N-1)
     float dmin[3];
     float span[3];       // max(dmax - dmin, 1e-6f)
@@ -164,8 +194,23 @@ struct LutParams {
     float blend, one_minus_blend;
 };
 
-struct LutAxis { int i0, i1; float f, u; };
+// cell (b0,g0,r0) of an [N][N][N][3] table (index [b][g][r]) -> 24 floats
+VRG_HD void lut_build_cell(const float* table, int n, int b0, int g0, int r0, float out[LUT_CELL_FLOATS]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = b0 + (k & 1), g = g0 + ((k >> 1) & 1), r = r0 + (k >> 2);
+            out[ch * 8 + k] = table[(size_t)((b * n + g) * n + r) * 3 + ch];
+        }
+}
 
+struct LutAxis { int cell; float f, u; };
+
+// Per-axis index / weights (VRGDG_IV_Adjustments.py:295-318).  i0 = floor(c), i1 = min(i0+1, N-1),
+// f = c - i0.  The top grid node (i0 == N-1, only for t == 1) has i1 == i0 and f == 0; it is served
+// from cell N-2 with weights (u, f) = (0, 1), which selects the same corner value:
+// C[N-2]*0 + C[N-1]*1 == C[N-1]*1 + C[N-1]*0 for every finite table.
 VRG_HD LutAxis lut_axis(float x, float dmin, float span, int unit_domain, float top, int n) {
     float t;
     if (unit_domain) {
@@ -180,10 +225,14 @@ VRG_HD LutAxis lut_axis(float x, float dmin, float span, int unit_domain, float 
     int i0 = (int)fl;
     i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);  // only reachable for NaN input (reference: undefined)
     LutAxis a;
-    a.i0 = i0;
-    a.i1 = i0 + 1 > n - 1 ? n - 1 : i0 + 1;
     a.f = c - (float)i0;
     a.u = 1.0f - a.f;
+    a.cell = i0;
+    if (i0 == n - 1) {
+        a.cell = n - 2;
+        a.u = 0.0f;
+        a.f = 1.0f;
+    }
     return a;
 }
 
@@ -193,25 +242,23 @@ VRG_HD float lerp2(float a, float wa, float b, float wb) {
     return pa + pb;
 }
 
-// rgb in -> graded rgb out (before the strength blend)
+// rgb in -> graded rgb out (before the strength blend); lerp order blue, green, red (:320-333)
 VRG_HD void lut_pixel_raw(const LutParams& P, const float x[3], float y[3]) {
     const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top, P.n);
-    const LutAxis Gx = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top, P.n);
+    const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top, P.n);
     const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top, P.n);
-    const int n = P.n;
-    const float* b0g0 = P.table + (size_t)((B.i0 * n + Gx.i0) * n) * 3;
-    const float* b1g0 = P.table + (size_t)((B.i1 * n + Gx.i0) * n) * 3;
-    const float* b0g1 = P.table + (size_t)((B.i0 * n + Gx.i1) * n) * 3;
-    const float* b1g1 = P.table + (size_t)((B.i1 * n + Gx.i1) * n) * 3;
-    const int r0 = R.i0 * 3, r1 = R.i1 * 3;
+    const int nc = P.n - 1;
+    const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((B.cell * nc + G.cell) * nc + R.cell) * LUT_CELL_FLOATS);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const float c00 = lerp2(b0g0[r0 + ch], B.u, b1g0[r0 + ch], B.f);
-        const float c01 = lerp2(b0g1[r0 + ch], B.u, b1g1[r0 + ch], B.f);
-        const float c10 = lerp2(b0g0[r1 + ch], B.u, b1g0[r1 + ch], B.f);
-        const float c11 = lerp2(b0g1[r1 + ch], B.u, b1g1[r1 + ch], B.f);
-        const float c0 = lerp2(c00, Gx.u, c01, Gx.f);
-        const float c1 = lerp2(c10, Gx.u, c11, Gx.f);
+        const f32x4 lo = q[2 * ch];      // r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
+        const f32x4 hi = q[2 * ch + 1];  // r1
+        const float c00 = lerp2(lo.x, B.u, lo.y, B.f);
+        const float c01 = lerp2(lo.z, B.u, lo.w, B.f);
+        const float c10 = lerp2(hi.x, B.u, hi.y, B.f);
+        const float c11 = lerp2(hi.z, B.u, hi.w, B.f);
+        const float c0 = lerp2(c00, G.u, c01, G.f);
+        const float c1 = lerp2(c10, G.u, c11, G.f);
         y[ch] = clamp01(lerp2(c0, R.u, c1, R.f));
     }
 }
@@ -241,7 +288,7 @@ VRG_HD float unsharp_value(const float p[3][3], float strength) {
     s = s + p[2][0];
     s = s + p[2][1];
     s = s + p[2][2];
-    const float blur = s / 9.0f;
+    const float blur = div9(s);
     const float x = p[1][1];
     const float d = x - blur;
     const float e = strength * d;
@@ -315,34 +362,86 @@ VRG_HD float stencil_value(int op, const float p[3][3], float strength, int zero
 }
 
 // ------------------------------------------------------------------------------------------
-// kornia.color Lab transforms (external to the reference, restated: oracle/restated.py)
+// pow(x, y) for normal positive finite x and a constant exponent, evaluated in fp64 and rounded once to
+// fp32: |relative error| < 1e-12 before the final rounding, i.e. the correctly rounded fp32 power except in
+// ~1e-5 of cases where it is off by one ulp.  (torch's pow kernels are ocml powf on HIP and Sleef powf on
+// CPU, each "<= 1 ulp": this is at least as close to the true value as either.)
+//   x = 2^e * m, m in [1,2);  i = top 7 mantissa bits;  r = m*invc_i - 1 (|r| <= 2^-8, exact in fp64);
+//   log2 x = e + logc_i + r*(A1 + r*(A2 + r*(A3 + r*A4)));   E = y*log2 x = n/64 + f, |f| <= 2^-7;
+//   x^y = 2^(n>>6) * 2^((n&63)/64) * (1 + f*(B1 + f*(B2 + f*(B3 + f*B4)))).
+// ~21 fp64-rate ops + 2 table reads instead of ocml powf's ~180 instructions.
 // ------------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-#define VRG_POWF(a, b) powf(a, b)  /* ocml pow, what torch-HIP's pow kernel calls */
-#else
-#define VRG_POWF(a, b) __builtin_powf(a, b)
-#endif
+#include "vrg_pow_tables.inc"
 
-VRG_HD float srgb_to_linear(float v) {
+constexpr int POW_TABLE_DOUBLES = 256 + 64;
+
+struct PowTables {
+    const double* logt;  // [128][2] = {invc, logc}
+    const double* expt;  // [64]
+};
+
+VRG_HD double f64_from_bits(unsigned long long b) {
+    union { unsigned long long u; double d; } c;
+    c.u = b;
+    return c.d;
+}
+
+// copy the constexpr tables into `dst` (LDS on the device, a static array in the host checker)
+VRG_HD void pow_tables_fill(double* dst, int first, int stride) {
+    for (int i = first; i < POW_TABLE_DOUBLES; i += stride)
+        dst[i] = f64_from_bits(i < 256 ? VRG_POW_LOGT[i >> 1][i & 1] : VRG_POW_EXPT[i - 256]);
+}
+
+VRG_HD float pow_pos(float x, double y, const PowTables& T) {
+    union { float f; uint32_t u; } cv;
+    cv.f = x;
+    const uint32_t b = cv.u;
+    const int e = (int)(b >> 23) - 127;
+    const uint32_t i = (b >> 16) & 0x7fu;
+    const double m = (double)f32_from_bits((b & 0x007fffffu) | 0x3f800000u);
+    const double invc = T.logt[2 * i], logc = T.logt[2 * i + 1];
+    const double r = __builtin_fma(m, invc, -1.0);
+    double p = __builtin_fma(r, f64_from_bits(VRG_POW_A[3]), f64_from_bits(VRG_POW_A[2]));
+    p = __builtin_fma(r, p, f64_from_bits(VRG_POW_A[1]));
+    p = __builtin_fma(r, p, f64_from_bits(VRG_POW_A[0]));
+    const double L = __builtin_fma(r, p, (double)e + logc);
+    const double E = y * L;
+    const double nd = __builtin_rint(E * 64.0);
+    const double f = __builtin_fma(nd, -0.015625, E);
+    const int n = (int)nd;
+    double q = __builtin_fma(f, f64_from_bits(VRG_POW_B[3]), f64_from_bits(VRG_POW_B[2]));
+    q = __builtin_fma(f, q, f64_from_bits(VRG_POW_B[1]));
+    q = __builtin_fma(f, q, f64_from_bits(VRG_POW_B[0]));
+    q = __builtin_fma(f, q, 1.0);
+    const double v = __builtin_ldexp(T.expt[n & 63] * q, n >> 6);
+    return (x != x) ? x : (float)v;
+}
+
+// ------------------------------------------------------------------------------------------
+// kornia.color Lab transforms (external to the reference, restated: oracle/restated.py).  Operation
+// order and rounding points are kornia's; pow and the constant divisions are evaluated as above.
+// ------------------------------------------------------------------------------------------
+VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float t = v + 0.055f;
-    const float q = t / 1.055f;
-    const float hi = VRG_POWF(q, 2.4f);
-    const float lo = v / 12.92f;
+    const float q = VRG_DIVC(t, 1.055f);
+    // the power is only selected for v > 0.04045 (q > 0.09): keep its argument in pow_pos's domain
+    const float hi = pow_pos(clamp_min(q, 0.0625f), (double)2.4f, T);
+    const float lo = VRG_DIVC(v, 12.92f);
     return v > 0.04045f ? hi : lo;
 }
 
-VRG_HD float linear_to_srgb(float v) {
+VRG_HD float linear_to_srgb(float v, const PowTables& T) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
-    const float pw = VRG_POWF(base, (float)(1.0 / 2.4));
+    const float pw = pow_pos(base, (double)(float)(1.0 / 2.4), T);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
 }
 
-VRG_HD float lab_f(float t) {
+VRG_HD float lab_f(float t, const PowTables& T) {
     const float thr = 0.008856f;
-    const float pw = VRG_POWF(clamp_min(t, thr), (float)(1.0 / 3.0));
+    const float pw = pow_pos(clamp_min(t, thr), (double)(float)(1.0 / 3.0), T);
     const float sc = 7.787f * t + (float)(4.0 / 29.0);
     return t > thr ? pw : sc;
 }
@@ -355,14 +454,14 @@ VRG_HD float dot3(float a, float x, float b, float y, float c, float z) {
     return s + r;
 }
 
-VRG_HD void rgb_to_lab(const float rgb[3], float lab[3]) {
-    const float r = srgb_to_linear(rgb[0]);
-    const float g = srgb_to_linear(rgb[1]);
-    const float b = srgb_to_linear(rgb[2]);
-    const float X = dot3(0.412453f, r, 0.357580f, g, 0.180423f, b) / 0.95047f;
-    const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b) / 1.0f;
-    const float Z = dot3(0.019334f, r, 0.119193f, g, 0.950227f, b) / 1.08883f;
-    const float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
+VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const PowTables& T) {
+    const float r = srgb_to_linear(rgb[0], T);
+    const float g = srgb_to_linear(rgb[1], T);
+    const float b = srgb_to_linear(rgb[2], T);
+    const float X = VRG_DIVC(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f);
+    const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b);   // / 1.0
+    const float Z = VRG_DIVC(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f);
+    const float fx = lab_f(X, T), fy = lab_f(Y, T), fz = lab_f(Z, T);
     lab[0] = 116.0f * fy - 16.0f;
     const float dxy = fx - fy;
     const float dyz = fy - fz;
@@ -373,27 +472,27 @@ VRG_HD void rgb_to_lab(const float rgb[3], float lab[3]) {
 VRG_HD float lab_finv(float f) {
     const float cube = (f * f) * f;
     const float d = f - (float)(4.0 / 29.0);
-    const float sc = d / 7.787f;
+    const float sc = VRG_DIVC(d, 7.787f);
     return f > 0.2068966f ? cube : sc;
 }
 
-VRG_HD void lab_to_rgb(const float lab[3], float rgb[3]) {
+VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const PowTables& T) {
     const float l16 = lab[0] + 16.0f;
-    const float fy = l16 / 116.0f;
-    const float a5 = lab[1] / 500.0f;
+    const float fy = VRG_DIVC(l16, 116.0f);
+    const float a5 = VRG_DIVC(lab[1], 500.0f);
     const float fx = a5 + fy;
-    const float b2 = lab[2] / 200.0f;
+    const float b2 = VRG_DIVC(lab[2], 200.0f);
     const float fzr = fy - b2;
     const float fz = clamp_min(fzr, 0.0f);
     const float X = lab_finv(fx) * 0.95047f;
-    const float Y = lab_finv(fy) * 1.0f;
+    const float Y = lab_finv(fy);   // * 1.0
     const float Z = lab_finv(fz) * 1.08883f;
     const float lr = dot3((float)3.2404813432005266, X, (float)-1.5371515162713185, Y, (float)-0.4985363261688878, Z);
     const float lg = dot3((float)-0.9692549499965682, X, (float)1.8759900014898907, Y, (float)0.0415559265582928, Z);
     const float lb = dot3((float)0.0556466391351772, X, (float)-0.2040413383665112, Y, (float)1.0573110696453443, Z);
-    rgb[0] = clamp01(linear_to_srgb(lr));
-    rgb[1] = clamp01(linear_to_srgb(lg));
-    rgb[2] = clamp01(linear_to_srgb(lb));
+    rgb[0] = clamp01(linear_to_srgb(lr, T));
+    rgb[1] = clamp01(linear_to_srgb(lg, T));
+    rgb[2] = clamp01(linear_to_srgb(lb, T));
 }
 
 // matched = (lab-mu)/sigma*sigma_ref + mu_ref ; blended = K*matched + T*lab (nodes.py:112-113)
@@ -408,13 +507,14 @@ VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, 
 }
 
 // ms: {mean, std+1e-5} per channel
-VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3]) {
+VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
+                             const PowTables& PT) {
     float lab[3], bl[3];
-    rgb_to_lab(rgb, lab);
+    rgb_to_lab(rgb, lab, PT);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         bl[c] = colormatch_channel(lab[c], img_ms[2 * c], img_ms[2 * c + 1], ref_ms[2 * c], ref_ms[2 * c + 1], K, T);
-    lab_to_rgb(bl, o);
+    lab_to_rgb(bl, o, PT);
     // final .clamp(0,1) of nodes.py:121 is idempotent after lab_to_rgb's clip
 }
 

@@ -137,9 +137,22 @@ __global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------------------------
-// 3D LUT.  One pixel per thread; the table (<= 431 KB for 33^3) lives in global memory and is served
-// by the vector L1 / per-XCD L2 (it does not fit the 160 KB LDS in fp32 -- SURVEY.md section 7).
+// 3D LUT.  One pixel per thread.  The table does not fit the 160 KB LDS in fp32 (33^3*12 B = 431 KB,
+// SURVEY.md section 7), so it is served by the vector L1 / per-XCD L2 -- in cell-major form (see
+// vrg_pixel_math.hpp): one 96-byte record per pixel instead of eight scattered corners.
 // ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lut_build_cells(const float* __restrict__ table, int n, float* __restrict__ cells) {
+    const int nc = n - 1;
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= nc * nc * nc) return;
+    const int r0 = cell % nc, g0 = (cell / nc) % nc, b0 = cell / (nc * nc);
+    float rec[LUT_CELL_FLOATS];
+    lut_build_cell(table, n, b0, g0, r0, rec);
+    f32x4* dst = reinterpret_cast<f32x4*>(cells + (size_t)cell * LUT_CELL_FLOATS);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = f32x4{rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
+}
+
 template <bool RGB_ONLY>
 __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, float* __restrict__ out, int64_t pixels,
                                                 int channels, LutParams P) {
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, flo
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict__ in, px3* __restrict__ out,
                                                            int32_t pixels_per_frame, CmK cm) {
+    VRG_STAGE_POW_TABLES(PT);
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pixels_per_frame) return;
     const int64_t f = blockIdx.y;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict_
     const float* ims = cm.img_ms + f * 6;
     const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
     float o[3];
-    colormatch_pixel(x, ims, rms, cm.K, cm.T, o);
+    colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT);
     out[at] = px3{o[0], o[1], o[2]};
 }
 
@@ -245,10 +259,25 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
     return VRG_OK;
 }
 
+int64_t vrg_lut_cells_floats(int32_t lut_size) {
+    if (lut_size < 2 || lut_size > 256) return 0;
+    const int64_t nc = lut_size - 1;
+    return nc * nc * nc * LUT_CELL_FLOATS;
+}
+
+int vrg_lut_prepare_f32(const float* lut, int32_t lut_size, float* cells, void* stream) {
+    if (!lut || !cells || lut_size < 2 || lut_size > 256) return VRG_ERR_BAD_ARG;
+    const int64_t nc = lut_size - 1;
+    const uint32_t blocks = (uint32_t)((nc * nc * nc + 255) / 256);
+    hipLaunchKernelGGL(k_lut_build_cells, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lut, lut_size, cells);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
 int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels, const float* lut, int32_t lut_size,
                   const float domain_min[3], const float domain_max[3], int32_t blend_mode, float blend, float one_minus_blend,
                   void* stream) {
-    if (!in || !out || !lut || !domain_min || !domain_max || pixels < 0 || channels < 3 || lut_size < 2 ||
+    if (!in || !out || !lut || !domain_min || !domain_max || pixels < 0 || channels < 3 || lut_size < 2 || lut_size > 256 ||
         (blend_mode != 1 && blend_mode != 2))
         return VRG_ERR_BAD_ARG;
     if (pixels == 0) return VRG_OK;

@@ -42,6 +42,14 @@ extern "C" int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, i
     if (!in || !out || frames < 0 || height <= 0 || width <= 0 || channels <= 0 || op < 0 || op > 2 || border < 0 || border > 1)
         return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
+    if (channels == 3 && (int64_t)height * width <= 0x7fffffff / 3) {
+        // RGB frames: the LDS-tiled kernel of the fused chain with only the stencil stage enabled
+        // (each input byte leaves HBM once and is re-read from LDS, not from L1/L2)
+        vrg_chain_desc d{};
+        d.stages = VRG_STAGE_SHARPEN;
+        d.stencil_op = op; d.border = border; d.strength = strength;
+        return vrg_fused_chain_f32(in, out, frames, height, width, &d, stream);
+    }
     const int64_t fe = (int64_t)height * width * channels;
     if (fe > 0x7fffffff) return VRG_ERR_UNSUPPORTED;
     const uint32_t bx = (uint32_t)((fe + 255) / 256);

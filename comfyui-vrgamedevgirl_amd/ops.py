@@ -156,19 +156,27 @@ def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensi
 
 @dataclass
 class DeviceLut:
-    table: torch.Tensor        # [N,N,N,3] fp32 on the device, index [b][g][r]
-    size: int
+    table: torch.Tensor        # cell-major table on the device: [(N-1)^3 * 24] fp32 (vrg_lut_prepare_f32)
+    size: int                  # N
     domain_min: tuple
     domain_max: tuple
 
 
 def upload_lut(lut_data: dict, device) -> DeviceLut:
-    table = lut_data["lut"].to(device=device, dtype=torch.float32).contiguous()
-    if table.ndim != 4 or table.shape[-1] != 3 or not (table.shape[0] == table.shape[1] == table.shape[2]):
+    """Upload a parsed .cube table ([N,N,N,3], index [b][g][r]) and rewrite it on the device into the
+    cell-major form the kernels read (values copied verbatim)."""
+    raw = lut_data["lut"].to(device=device, dtype=torch.float32).contiguous()
+    if raw.ndim != 4 or raw.shape[-1] != 3 or not (raw.shape[0] == raw.shape[1] == raw.shape[2]):
         raise ValueError("LUT table must be [N, N, N, 3]")
+    n = int(raw.shape[0])
+    count = int(_hip.lib().vrg_lut_cells_floats(n))
+    if count <= 0:
+        raise ValueError(f"unsupported LUT size {n} (2..256)")
+    cells = torch.empty((count,), dtype=torch.float32, device=device)
+    _hip.check(_hip.lib().vrg_lut_prepare_f32(_hip.ptr(raw), n, _hip.ptr(cells), _hip.current_stream()), "vrg_lut_prepare_f32")
     dmin = tuple(float(v) for v in lut_data["domain_min"].to(torch.float32).cpu().tolist())
     dmax = tuple(float(v) for v in lut_data["domain_max"].to(torch.float32).cpu().tolist())
-    return DeviceLut(table, int(table.shape[0]), dmin, dmax)
+    return DeviceLut(cells, n, dmin, dmax)
 
 
 def blend_terms(strength: float):

@@ -97,12 +97,19 @@ int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
 /* ---------------------------------------------------------------------------------------------
  * a4/a5/a6  3D LUT trilinear apply + strength blend.  Replaces VRGDG_LUTS._apply_cube_lut and
  * the blend in apply_lut (VRGDG_IV_Adjustments.py:288-361), _apply_lut_tensor
- * (VRGDG_LUTVideoTools.py:172-185).  `lut` = device fp32 [N][N][N][3] indexed [blue][green][red].
+ * (VRGDG_LUTVideoTools.py:172-185).
+ * A LUT is prepared once: vrg_lut_prepare_f32 rewrites the parsed table `lut` (device fp32
+ * [N][N][N][3] indexed [blue][green][red], as _parse_cube_file returns it) into the cell-major form
+ * the kernels read -- (N-1)^3 records of 24 floats, one per interpolation cell, corner values copied
+ * verbatim -- so that a pixel fetches one contiguous 96-byte record instead of eight scattered
+ * corners.  `cells` must hold vrg_lut_cells_floats(N) floats, 16-byte aligned.  2 <= N <= 256.
  * `channels` >= 3; channels beyond RGB are copied through.  blend_mode: 1 = LUT only (blend>=1),
  * 2 = fl(fl(x*one_minus_blend) + fl(y*blend)).  (blend <= 0 is the caller's no-op.)
  * ------------------------------------------------------------------------------------------- */
+int64_t vrg_lut_cells_floats(int32_t lut_size);
+int vrg_lut_prepare_f32(const float* lut, int32_t lut_size, float* cells, void* stream);
 int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels,
-                  const float* lut, int32_t lut_size,
+                  const float* cells, int32_t lut_size,
                   const float domain_min[3], const float domain_max[3],
                   int32_t blend_mode, float blend, float one_minus_blend, void* stream);
 
@@ -147,7 +154,7 @@ typedef struct vrg_chain_desc {
     /* grain */
     float intensity, sat, one_minus_sat;
     vrg_noise_desc noise;
-    /* LUT */
+    /* LUT (cell-major table from vrg_lut_prepare_f32) */
     const float* lut; int32_t lut_size;
     float domain_min[3], domain_max[3];
     int32_t blend_mode; float blend, one_minus_blend;
@@ -173,6 +180,11 @@ const char* vrg_error_string(int status);
 /* multiProcessorCount and maxThreadsPerMultiProcessor of the current device (what torch's
  * calc_execution_policy reads); returns VRG_ERR_NO_DEVICE without a GPU. */
 int vrg_device_info(int32_t* cu_count, int32_t* max_threads_per_cu);
+/* Device self-test: sweeps all 2^32 fp32 inputs through the FMA-based constant divisions of the kernels
+ * (csrc/vrg_pixel_math.hpp div_const / div9) and counts disagreements with the IEEE quotient.
+ * counts18 (device, 18 x u64): [0..8] mismatches for 1e-30 <= |x| <= 1e30 (expected 0 for all nine
+ * constants), [9..17] mismatches outside that range. */
+int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

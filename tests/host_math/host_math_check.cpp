@@ -15,7 +15,45 @@
 
 using namespace vrg;
 
+static const PowTables& host_tables() {
+    static double store[POW_TABLE_DOUBLES];
+    static PowTables T{store, store + 256};
+    static bool init = false;
+    if (!init) { pow_tables_fill(store, 0, 1); init = true; }
+    return T;
+}
+
 extern "C" {
+
+void hm_pow(const float* x, float* o, int64_t n, double y) {
+    const PowTables& T = host_tables();
+    for (int64_t i = 0; i < n; ++i) o[i] = pow_pos(x[i], y, T);
+}
+
+// Markstein division vs IEEE: returns the number of bit mismatches among n inputs (NaN == NaN)
+int64_t hm_divc_mismatches(const float* x, int64_t n, int which) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float got, want;
+        const float v = x[i];
+        switch (which) {
+            case 0: got = VRG_DIVC(v, 1.055f); want = v / 1.055f; break;
+            case 1: got = VRG_DIVC(v, 12.92f); want = v / 12.92f; break;
+            case 2: got = VRG_DIVC(v, 0.95047f); want = v / 0.95047f; break;
+            case 3: got = VRG_DIVC(v, 1.08883f); want = v / 1.08883f; break;
+            case 4: got = VRG_DIVC(v, 116.0f); want = v / 116.0f; break;
+            case 5: got = VRG_DIVC(v, 500.0f); want = v / 500.0f; break;
+            case 6: got = VRG_DIVC(v, 200.0f); want = v / 200.0f; break;
+            case 7: got = VRG_DIVC(v, 7.787f); want = v / 7.787f; break;
+            default: got = div9(v); want = v / 9.0f; break;
+        }
+        uint32_t a, b;
+        memcpy(&a, &got, 4); memcpy(&b, &want, 4);
+        if (a != b && !(got != got && want != want) && !(got == 0.0f && want == 0.0f)) ++bad;
+    }
+    return bad;
+}
+
 
 void hm_philox(uint64_t seed, uint64_t subsequence, uint64_t counter, uint32_t out[4]) {
     const u32x4 r = philox_for(seed, subsequence, counter);
@@ -32,8 +70,14 @@ void hm_grain(const float* x, const float* n, float* o, int64_t pixels, float I,
 
 void hm_lut(const float* x, float* o, int64_t pixels, const float* table, int n, const float* dmin, const float* dmax,
             int blend_mode, float blend, float one_minus_blend) {
+    const int nc = n - 1;
+    float* cells = new float[(size_t)nc * nc * nc * LUT_CELL_FLOATS + 4];
+    float* aligned = (float*)(((uintptr_t)cells + 15) & ~(uintptr_t)15);
+    for (int b = 0; b < nc; ++b)
+        for (int g = 0; g < nc; ++g)
+            for (int r = 0; r < nc; ++r) lut_build_cell(table, n, b, g, r, aligned + (size_t)((b * nc + g) * nc + r) * LUT_CELL_FLOATS);
     LutParams P;
-    P.table = table; P.n = n; P.top = (float)(n - 1); P.unit_domain = 1;
+    P.cells = aligned; P.n = n; P.top = (float)(n - 1); P.unit_domain = 1;
     for (int c = 0; c < 3; ++c) {
         P.dmin[c] = dmin[c];
         const float span = dmax[c] - dmin[c];
@@ -42,6 +86,7 @@ void hm_lut(const float* x, float* o, int64_t pixels, const float* table, int n,
     }
     P.blend_mode = blend_mode; P.blend = blend; P.one_minus_blend = one_minus_blend;
     for (int64_t p = 0; p < pixels; ++p) lut_pixel(P, x + 3 * p, o + 3 * p);
+    delete[] cells;
 }
 
 void hm_stencil(const float* in, float* out, int F, int H, int W, int C, int op, int zero_border, float strength) {
@@ -64,16 +109,16 @@ void hm_stencil(const float* in, float* out, int F, int H, int W, int C, int op,
 }
 
 void hm_rgb_to_lab(const float* x, float* o, int64_t pixels) {
-    for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p);
+    for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p, host_tables());
 }
 
 void hm_lab_to_rgb(const float* x, float* o, int64_t pixels) {
-    for (int64_t p = 0; p < pixels; ++p) lab_to_rgb(x + 3 * p, o + 3 * p);
+    for (int64_t p = 0; p < pixels; ++p) lab_to_rgb(x + 3 * p, o + 3 * p, host_tables());
 }
 
 // ms arrays: [3][2] = {mean, std+1e-5}
 void hm_colormatch(const float* x, float* o, int64_t pixels, const float* img_ms, const float* ref_ms, float K, float T) {
-    for (int64_t p = 0; p < pixels; ++p) colormatch_pixel(x + 3 * p, img_ms, ref_ms, K, T, o + 3 * p);
+    for (int64_t p = 0; p < pixels; ++p) colormatch_pixel(x + 3 * p, img_ms, ref_ms, K, T, o + 3 * p, host_tables());
 }
 
 }  // extern "C"

@@ -69,6 +69,18 @@ def test_native_library_is_loaded(pkg):
     assert cu.value == props.multi_processor_count and mt.value == props.max_threads_per_multi_processor
 
 
+def test_constant_divisions_equal_ieee_division_for_every_fp32_input(pkg, dev):
+    """The kernels divide by compile-time constants with multiply + 2 FMAs (3 issue slots instead of ~14).
+    Swept over all 2^32 fp32 bit patterns on the device: identical to x / c wherever 1e-30 <= |x| <= 1e30, and
+    for the unsharp divisor 9 (bit-exact stencil path) identical for every input."""
+    from comfyui_vrgamedevgirl_amd import _hip
+    counts = torch.zeros(18, dtype=torch.int64, device=dev)
+    _hip.check(_hip.lib().vrg_selftest_divconst(_hip.ptr(counts), _hip.current_stream()), "selftest")
+    c = counts.cpu().tolist()
+    assert c[:9] == [0] * 9, c
+    assert c[17] == 0, c            # c = 9: exact everywhere (+-0 compare equal, Inf handled)
+
+
 # ---------------------------------------------------------------------------------------- noise stream
 NOISE_CASES = [  # frames, frame_elems, chunk_frames
     (1, 3 * 5 * 7, 1), (3, 3 * 5 * 7, 2), (2, 3 * 64 * 64, 1), (4, 3 * 256 * 256, 4), (8, 3 * 512 * 512, 4), (5, 3 * 270 * 480, 0),
