@@ -8,6 +8,7 @@
 //   * once per pixel inside the reduction (statistics of the grain->LUT output).
 // That makes every fused result bit-identical to running the stand-alone kernels back to back.
 #include "vrg_common.hpp"
+#include "vrg_chain_stages.hpp"
 
 namespace vrg {
 
@@ -17,39 +18,6 @@ constexpr int STATS_PX_PER_BLOCK = 16384;
 __host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
     int64_t b = (pixels + STATS_PX_PER_BLOCK - 1) / STATS_PX_PER_BLOCK;
     return (int)(b < 1 ? 1 : (b > STATS_BPF_MAX ? STATS_BPF_MAX : b));
-}
-
-// grain -> LUT -> colour match for the pixel at (frame f of this call, pixel p of the frame).
-template <int STAGES>
-__device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3],
-                                          const PowTables& PT) {
-    float v[3] = {xin[0], xin[1], xin[2]};
-    if (STAGES & VRG_STAGE_GRAIN) {
-        const int64_t chunk = f / D.noise.chunk_frames;
-        const int64_t fl = f - chunk * D.noise.chunk_frames;
-        const uint64_t li = (uint64_t)(fl * D.noise.frame_elems) + (uint64_t)p * 3u;
-        const uint64_t seed = chunk_seed(D.noise, chunk);
-        const uint64_t off = chunk_offset(D.noise, chunk);
-        float n[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, D.noise.G, li + c);
-        float g[3];
-        grain_pixel(v, n, D.I, D.S, D.T, g);
-        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
-    }
-    if (STAGES & VRG_STAGE_LUT) {
-        float g[3];
-        lut_pixel(D.lut, v, g);
-        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
-    }
-    if (STAGES & VRG_STAGE_COLORMATCH) {
-        const float* ims = D.cm.img_ms + f * 6;
-        const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
-        float g[3];
-        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g, PT);
-        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
-    }
-    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -303,6 +271,8 @@ static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) 
     return VRG_OK;
 }
 
+int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st);
+
 }  // namespace vrg
 
 using namespace vrg;
@@ -366,11 +336,13 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
-    if (desc->variant != 0) return VRG_ERR_UNSUPPORTED;
+    if (desc->variant != 0 && desc->variant != 1) return VRG_ERR_UNSUPPORTED;
     ChainK D;
     const int rc = fill_chain(desc, height, width, D);
     if (rc) return rc;
     const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
+    // variant 0: register-resident wave march (vrg_march.hip); variant 1: LDS tile / point-wise kernels below
+    if (desc->variant == 0) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
     VRG_DISPATCH_PRE(desc->stages, CALL)
 #undef CALL

@@ -1,0 +1,52 @@
+// vrg_chain_stages.hpp -- the "pre" stages of the fused chain (grain, LUT, colour match) as pure
+// per-pixel device functions shared by the tile / point-wise kernels (vrg_chain.hip), the statistics
+// reduction and the wave-march kernel (vrg_march.hip).
+#pragma once
+#include "vrg_common.hpp"
+
+namespace vrg {
+
+// grain (with the pixel's three raw normals n) -> LUT -> colour match for a pixel of frame f (of this call)
+template <int STAGES>
+__device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, const float xin[3], const float n[3], float o[3],
+                                                   const PowTables& PT) {
+    float v[3] = {xin[0], xin[1], xin[2]};
+    if (STAGES & VRG_STAGE_GRAIN) {
+        float g[3];
+        grain_pixel(v, n, D.I, D.S, D.T, g);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    if (STAGES & VRG_STAGE_LUT) {
+        float g[3];
+        lut_pixel(D.lut, v, g);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    if (STAGES & VRG_STAGE_COLORMATCH) {
+        const float* ims = D.cm.img_ms + f * 6;
+        const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
+        float g[3];
+        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g, PT);
+        v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+    }
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+}
+
+// Same, drawing the pixel's normals with the general per-element routine (one Philox call per element):
+// for the pixel at (frame f of this call, pixel p of the frame).
+template <int STAGES>
+__device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3],
+                                          const PowTables& PT) {
+    float n[3] = {0.0f, 0.0f, 0.0f};
+    if (STAGES & VRG_STAGE_GRAIN) {
+        const int64_t chunk = f / D.noise.chunk_frames;
+        const int64_t fl = f - chunk * D.noise.chunk_frames;
+        const uint64_t li = (uint64_t)(fl * D.noise.frame_elems) + (uint64_t)p * 3u;
+        const uint64_t seed = chunk_seed(D.noise, chunk);
+        const uint64_t off = chunk_offset(D.noise, chunk);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, D.noise.G, li + c);
+    }
+    chain_apply_stages<STAGES>(D, f, xin, n, o, PT);
+}
+
+}  // namespace vrg

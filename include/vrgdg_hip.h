@@ -150,7 +150,7 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
 
 typedef struct vrg_chain_desc {
     int32_t stages;               /* VRG_STAGE_* bits */
-    int32_t variant;              /* 0 = default kernel; >0 selects an alternative implementation (bench A/B) */
+    int32_t variant;              /* 0 = wave-march kernel (default); 1 = LDS-tile / point-wise kernels (A/B, cross-check) */
     /* grain */
     float intensity, sat, one_minus_sat;
     vrg_noise_desc noise;
@@ -185,6 +185,9 @@ int vrg_device_info(int32_t* cu_count, int32_t* max_threads_per_cu);
  * counts18 (device, 18 x u64): [0..8] mismatches for 1e-30 <= |x| <= 1e30 (expected 0 for all nine
  * constants), [9..17] mismatches outside that range. */
 int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
+/* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
+ * out128[64+i] = value held by lane i+1, for lane values 0..63. */
+int vrg_selftest_lanes(float* out128, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

@@ -81,6 +81,16 @@ def test_constant_divisions_equal_ieee_division_for_every_fp32_input(pkg, dev):
     assert c[17] == 0, c            # c = 9: exact everywhere (+-0 compare equal, Inf handled)
 
 
+def test_dpp_lane_shifts(pkg, dev):
+    """The wave-march kernel takes 3x3 taps and misaligned normals from neighbouring lanes with DPP wave shifts."""
+    from comfyui_vrgamedevgirl_amd import _hip
+    out = torch.full((128,), -1.0, device=dev)
+    _hip.check(_hip.lib().vrg_selftest_lanes(_hip.ptr(out), _hip.current_stream()), "selftest lanes")
+    o = out.cpu().tolist()
+    assert o[1:64] == [float(i - 1) for i in range(1, 64)], "lane_prev must read lane-1"
+    assert o[64:127] == [float(i + 1) for i in range(0, 63)], "lane_next must read lane+1"
+
+
 # ---------------------------------------------------------------------------------------- noise stream
 NOISE_CASES = [  # frames, frame_elems, chunk_frames
     (1, 3 * 5 * 7, 1), (3, 3 * 5 * 7, 2), (2, 3 * 64 * 64, 1), (4, 3 * 256 * 256, 4), (8, 3 * 512 * 512, 4), (5, 3 * 270 * 480, 0),
@@ -339,13 +349,19 @@ CHAIN_CASES = [
 ]
 
 
+CHAIN_SHAPES = [(5, 45, 70, 3), (4, 64, 128, 3), (2, 1, 1, 3), (1, 3, 1, 3), (1, 1, 5, 3), (3, 5, 7, 3), (2, 64, 61, 3), (2, 33, 62, 3),
+                (1, 7, 123, 3), (1, 15, 17, 3), (1, 10, 33, 3), (4, 30, 200, 3)]
+
+
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("case", CHAIN_CASES)
-@pytest.mark.parametrize("shape", [(5, 45, 70, 3), (4, 64, 128, 3)])
-def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shape):
+@pytest.mark.parametrize("shape", CHAIN_SHAPES)
+def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shape, variant):
     data, dlut = _lut_pair(ops, dev)
     x = _rand(shape, 51, -0.05, 1.05)
     xd = x.to(dev)
-    spec = ops.ChainSpec(grain=case["grain"], lut=(dlut, case["lut"]) if case["lut"] is not None else None, sharpen=case["sharpen"])
+    spec = ops.ChainSpec(grain=case["grain"], lut=(dlut, case["lut"]) if case["lut"] is not None else None, sharpen=case["sharpen"],
+                         variant=variant)
     torch.manual_seed(77)
     fused = ops.fused_chain(xd, spec)
     torch.manual_seed(77)
@@ -376,13 +392,37 @@ def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shap
     assert_bit_equal(fused, o, "fused vs oracle")
 
 
-def test_fused_chain_with_colour_match(ops, dev):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("bs,shape", [(4, (3, 720, 1280, 3)), (0, (2, 600, 700, 3)), (1, (2, 540, 960, 3))])
+def test_fused_chain_across_several_philox_groups(ops, dev, variant, bs, shape):
+    """Chunks larger than 4*G elements: several Philox call indices, ragged quarter rows, sibling strips that wrap
+    around row ends and cross frame boundaries."""
+    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
+    x = _rand(shape, 52)
+    spec = ops.ChainSpec(grain=(0.08, 0.4, bs), lut=(dlut, 10.0), sharpen=("unsharp", 0.7, False), variant=variant)
+    torch.manual_seed(11)
+    fused = ops.fused_chain(x.to(dev), spec)
+    torch.manual_seed(11)
+    o = R.fast_film_grain(x, 0.08, 0.4, bs, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    o = R.unsharp(R.apply_lut_with_strength(o, data, 10.0), 0.7, False)
+    assert_bit_equal(fused, o, f"fused variant {variant} vs oracle, {shape} bs={bs}")
+    # point-wise chain (no stencil) through the same kernels
+    spec = ops.ChainSpec(grain=(0.08, 0.4, bs), lut=(dlut, 6.0), variant=variant)
+    torch.manual_seed(12)
+    fused = ops.fused_chain(x.to(dev), spec)
+    torch.manual_seed(12)
+    o = R.fast_film_grain(x, 0.08, 0.4, bs, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    assert_bit_equal(fused, R.apply_lut_with_strength(o, data, 6.0), f"point-wise variant {variant}")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fused_chain_with_colour_match(ops, dev, variant):
     data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
     x = _rand((4, 48, 80, 3), 61)
     ref = _rand((1, 30, 30, 3), 62)
     xd = x.to(dev)
     ref_ms = ops.finalize_stats(ops.lab_stats(ref.to(dev)))
-    spec = ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.5, False))
+    spec = ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.5, False), variant=variant)
     torch.manual_seed(5)
     fused = ops.fused_chain(xd, spec)
     torch.manual_seed(5)
@@ -409,10 +449,14 @@ def test_full_size_4k_properties(ops, dev):
     spec = ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False))
     torch.manual_seed(9)
     fused = ops.fused_chain(x, spec)
-    # (1) fused == stand-alone kernels back to back, bit for bit, at full size
+    # (1) fused == stand-alone kernels back to back, bit for bit, at full size -- and both fused kernels agree
     torch.manual_seed(9)
     y = ops.stencil3x3(ops.lut3d(ops.film_grain(x, 0.04, 0.5, chunk_frames=2), dlut, 10.0), "unsharp", 0.5, False)
     assert torch.equal(fused, y)
+    torch.manual_seed(9)
+    tile = ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=1))
+    assert torch.equal(fused, tile)
+    del tile
     # (2) the grain stream at full size is torch's
     torch.manual_seed(9)
     n = torch.cat([torch.randn((2, H, W, 3), device=dev) for _ in range(2)])

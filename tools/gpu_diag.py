@@ -93,7 +93,7 @@ def kernel_bench(ops, frames_4k, iters):
     rows = []
     lut33 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
     lut25 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_WarmFilm_25.cube")), dev)
-    for label, H, W, F in (("1080p", 1080, 1920, frames_4k * 4), ("4K", 2160, 3840, frames_4k)):
+    for label, H, W, F in (("4K", 2160, 3840, frames_4k), ("1080p", 1080, 1920, frames_4k * 4)):
         g = torch.Generator(device=dev).manual_seed(3)
         x = torch.rand((F, H, W, 3), generator=g, device=dev)
         smooth = (x * 0.05 + 0.5 * (torch.linspace(0, 1, W, device=dev).view(1, 1, W, 1) + torch.linspace(0, 1, H, device=dev).view(1, H, 1, 1)) * 0.9).contiguous()
@@ -128,6 +128,12 @@ def kernel_bench(ops, frames_4k, iters):
             ("fused grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)))),
             ("fused grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)))),
             ("fused 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)))),
+            ("v1 tile sharpen only", 24, chain(ops.ChainSpec(sharpen=("unsharp", 0.5, False), variant=1))),
+            ("v1 tile lut+sharpen", 24, chain(ops.ChainSpec(lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False), variant=1))),
+            ("v1 pointwise grain+lut", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), variant=1))),
+            ("v1 tile grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False), variant=1))),
+            ("v1 tile 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=1))),
+            ("fused grain+lut+sharpen smooth", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)), smooth)),
         ]
         for name, bpp, fn in cases:
             try:

@@ -1,0 +1,43 @@
+"""Tiny driver for rocprofv3 runs: executes selected kernels a few times on 16 4K frames.
+
+    python tools/prof_driver.py lut|chain3|chain3_v1|chain4|grain|cm|sharpen [--smooth]
+"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+load_package()
+from comfyui_vrgamedevgirl_amd import ops, cube
+from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
+
+which = sys.argv[1] if len(sys.argv) > 1 else "lut"
+dev = torch.device("cuda", 0)
+F, H, W = 16, 2160, 3840
+g = torch.Generator(device=dev).manual_seed(3)
+x = torch.rand((F, H, W, 3), generator=g, device=dev)
+if "--smooth" in sys.argv:
+    x = (x * 0.05 + 0.5 * (torch.linspace(0, 1, W, device=dev).view(1, 1, W, 1) + torch.linspace(0, 1, H, device=dev).view(1, H, 1, 1)) * 0.9).contiguous()
+out = torch.empty_like(x)
+lut = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
+ref_ms = ops.finalize_stats(ops.lab_stats(x[:1]))
+gen = torch.Generator(device=dev).manual_seed(5)
+specs = {
+    "chain3": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False)),
+    "chain3_v1": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False), variant=1),
+    "chain4": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)),
+    "lutsharp": ops.ChainSpec(lut=(lut, 10.0), sharpen=("unsharp", 0.5, False)),
+    "grainsharp": ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)),
+    "sharpen": ops.ChainSpec(sharpen=("unsharp", 0.5, False)),
+}
+for _ in range(3):
+    if which == "lut":
+        ops.lut3d(x, lut, 10.0)
+    elif which == "grain":
+        ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen)
+    elif which == "cm":
+        ops.color_match(x, None, 1.0, ref_ms=ref_ms)
+    else:
+        ops.fused_chain(x, specs[which], generator=gen, out=out)
+torch.cuda.synchronize()
+print("done", which)
