@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
 VRG_OK = 0
 BORDER_REPLICATE, BORDER_ZERO = 0, 1
 STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
-STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN = 1, 2, 4, 8
+STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 
 
 class NoiseDesc(C.Structure):
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vrg_event_destroy": (C.c_int, [_P]),
     "vrg_selftest_divconst": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
+    "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
     "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(NoiseDesc), _P]),
@@ -66,6 +67,7 @@ _SIGNATURES = {
                                            C.c_float, _P]),
     "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
+    "vrg_chain_stats_lab_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

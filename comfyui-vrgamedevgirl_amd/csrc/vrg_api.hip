@@ -29,9 +29,70 @@ __global__ __launch_bounds__(256) void k_selftest_divconst(unsigned long long* c
     }
 }
 
+// ---- micro-benchmark of LUT record fetch patterns (timing only; results are checksums, not pixels) ----------
+//  mode 0: every lane reads its own 96-B record as 6 x 16 B                       (what k_lut3d does)
+//  mode 1: every lane reads half of its record (3 x 16 B)                          (is the L1 request rate the bound?)
+//  mode 2: quad-cooperative: the 4 lanes of a quad read 64 contiguous bytes of ONE record per round
+//          (rounds: chunks 0-3 of pixels 0,1,2,3; then chunks 4,5 of pixels 0|1 and 2|3) -- same bytes as mode 0
+//  mode 3: like 0 with 64-B record stride (cells buffer must be sized for it)
+__device__ __forceinline__ int dbg_quad_bcast(int v, int pattern) {   // pattern: compile-time quad_perm
+    switch (pattern) {
+        case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xf, 0xf, false);   // [0,0,0,0]
+        case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xf, 0xf, false);   // [1,1,1,1]
+        case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xf, 0xf, false);   // [2,2,2,2]
+        case 3: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xf, 0xf, false);   // [3,3,3,3]
+        case 4: return __builtin_amdgcn_update_dpp(0, v, 0x50, 0xf, 0xf, false);   // [0,0,1,1]
+        default: return __builtin_amdgcn_update_dpp(0, v, 0xFA, 0xf, 0xf, false);  // [2,2,3,3]
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ in, float* __restrict__ out, int64_t pixels,
+                                                         const float* __restrict__ cells, int n) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pc = p < pixels ? p : pixels - 1;
+    const px3 v = in[pc];
+    const float top = (float)(n - 1);
+    const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
+    const int nc = n - 1;
+    const int cell = (B.cell * nc + G.cell) * n + R.cell;
+    constexpr int STRIDE = MODE == 3 ? 16 : 12;   // floats per record
+    float acc = 0.0f;
+    if (MODE == 0 || MODE == 3 || MODE == 1) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(cells + (size_t)cell * STRIDE);
+        constexpr int NQ = MODE == 1 ? 3 : 6;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { const f32x4 t = q[i]; acc += (t.x + t.y) + (t.z + t.w); }
+    } else {
+        const int ql = threadIdx.x & 3;
+#pragma unroll
+        for (int rnd = 0; rnd < 6; ++rnd) {
+            const int served = dbg_quad_bcast(cell, rnd);                       // cell of the pixel this round serves
+            const int chunk = rnd < 4 ? ql : 4 + (ql & 1);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(cells + (size_t)served * STRIDE + chunk * 4);
+            acc += (t.x + t.y) + (t.z + t.w);
+        }
+    }
+    if (p < pixels) out[p] = acc;
+}
+
 }  // namespace vrg
 
 extern "C" {
+
+int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 3) return VRG_ERR_BAD_ARG;
+    const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
+    const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        case 1: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        case 2: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+    }
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
 
 int vrg_selftest_divconst(unsigned long long* counts18, void* stream) {
     if (!counts18) return VRG_ERR_BAD_ARG;

@@ -112,7 +112,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 template <int STAGES>
 __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
-                                                       double* __restrict__ partials) {
+                                                       double* __restrict__ partials, px3* __restrict__ lab_out) {
     __shared__ double red[4][6];
     VRG_STAGE_POW_TABLES(PT);
     const int64_t f = blockIdx.y;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
         float pre[3], lab[3];
         chain_pre<STAGES>(D, f, p, x, pre, PT);
         rgb_to_lab(pre, lab, PT);
+        if (lab_out) lab_out[f * ppf + p] = px3{lab[0], lab[1], lab[2]};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double d = (double)lab[c] - (double)pivot[c];
@@ -198,7 +199,7 @@ __global__ void k_stats_finalize(const double* __restrict__ stats, float* __rest
 
 template <int STAGES>
 static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, const ChainK& D, double* stats, void* scratch,
-                        hipStream_t st) {
+                        hipStream_t st, float* lab_out = nullptr) {
     const int64_t ppf = (int64_t)H * W;
     const int bpf = stats_blocks_per_frame(ppf);
     double* partials = reinterpret_cast<double*>(scratch);
@@ -211,7 +212,7 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
         }
         const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
         hipLaunchKernelGGL(k_lab_partials<STAGES>, dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
-                           partials + f0 * bpf * 6);
+                           partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
         hipLaunchKernelGGL(k_lab_merge<STAGES>, dim3((uint32_t)nf), dim3(64), 0, st, src, (int32_t)ppf, bpf, d,
                            partials + f0 * bpf * 6, stats + f0 * 9);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
@@ -313,6 +314,11 @@ int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames,
 
 int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc, double* stats,
                         void* scratch, void* stream) {
+    return vrg_chain_stats_lab_f32(in, nullptr, frames, height, width, desc, stats, scratch, stream);
+}
+
+int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int32_t height, int32_t width,
+                            const vrg_chain_desc* desc, double* stats, void* scratch, void* stream) {
     if (!in || !desc || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
@@ -322,27 +328,35 @@ int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t
     const int rc = fill_chain(&pre, height, width, D);
     if (rc) return rc;
     switch (pre.stages & 3) {
-        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
-        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
-        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
-        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
+        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
+        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
+        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
+        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
     }
 }
 
 int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc,
                         void* stream) {
     if (!in || !out || !desc || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
-    if (desc->stages == 0 || (desc->stages & ~15)) return VRG_ERR_BAD_ARG;
+    if (desc->stages == 0 || (desc->stages & ~31)) return VRG_ERR_BAD_ARG;
+    if ((desc->stages & VRG_STAGE_FROM_LAB) && (desc->stages & 7) != VRG_STAGE_COLORMATCH) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
-    if (desc->variant != 0 && desc->variant != 1) return VRG_ERR_UNSUPPORTED;
+    if (desc->variant < 0 || desc->variant > 2) return VRG_ERR_UNSUPPORTED;
     ChainK D;
     const int rc = fill_chain(desc, height, width, D);
     if (rc) return rc;
     const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
-    // variant 0: register-resident wave march (vrg_march.hip); variant 1: LDS tile / point-wise kernels below
-    if (desc->variant == 0) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
+    // variant 2: register-resident wave march (vrg_march.hip); variant 1: LDS tile / point-wise kernels below.
+    // variant 0 picks by measurement (profiles/): chains with a LUT or a colour-match stage are bound by the
+    // L1/L2 gather path resp. fp64 issue, where the higher occupancy of the tile kernels wins; a chain whose
+    // only pre-stage is grain is ALU bound and the march (Philox shared across four strips, no LDS) wins.
+    int variant = desc->variant;
+    if (variant == 0) variant = ((desc->stages & VRG_STAGE_GRAIN) && !(desc->stages & (VRG_STAGE_LUT | VRG_STAGE_COLORMATCH))) ? 2 : 1;
+    if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
+    if (desc->stages & VRG_STAGE_FROM_LAB)
+        return launch_chain<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream);
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
     VRG_DISPATCH_PRE(desc->stages, CALL)
 #undef CALL

@@ -25,7 +25,10 @@ __device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, c
         const float* ims = D.cm.img_ms + f * 6;
         const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
         float g[3];
-        colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g, PT);
+        if (STAGES & VRG_STAGE_FROM_LAB)
+            colormatch_from_lab(v, ims, rms, D.cm.K, D.cm.T, g, PT);     // the input pixel is already Lab
+        else
+            colormatch_pixel(v, ims, rms, D.cm.K, D.cm.T, g, PT);
         v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
     }
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];

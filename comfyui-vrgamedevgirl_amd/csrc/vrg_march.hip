@@ -33,6 +33,8 @@ struct MarchK {
     uint32_t chunks;
     int32_t s[4];           // s_m = (3 - (G*m)%3)%3 : element shift that re-aligns sibling m to pixels
     int32_t delta[4];       // (G*m + s_m) / 3 : sibling m's pixel offset
+    int64_t elems_before;   // addressable elements of the caller's buffer before chunk 0 / after the last chunk
+    int64_t elems_after;
 };
 
 __device__ __forceinline__ float lane_prev(float v) {   // value held by lane-1
@@ -82,15 +84,24 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
     const int r_first = r_lo - (SHARPEN ? 1 : 0);
     const int r_last = r_hi + (SHARPEN ? 1 : 0);
 
+    // All element arithmetic below is 32-bit and relative to the chunk base (chunk elements < 2^31 - margin).
     const float* cin = in + (int64_t)chunk * M.numel;
     float* cout = out + (int64_t)chunk * M.numel;
     const uint64_t seed = chunk_seed(D.noise, chunk);
     const uint64_t off = chunk_offset(D.noise, chunk);
     const uint64_t ctr = (off >> 2) + k;
     const bool zero = D.zero_border != 0;
+    const uint32_t G = M.G;
+    const uint32_t px_limit = (uint32_t)(M.numel - 2);              // li is a whole pixel of the chunk iff (u32)li < px_limit
+    // loads are issued for every lane; addresses are clamped to memory that exists (the neighbouring chunks of
+    // this launch are addressable, the outside of the caller's buffer is not)
+    const int64_t before = (int64_t)chunk * M.numel + M.elems_before;
+    const int64_t after = (int64_t)(M.chunks - 1 - chunk) * M.numel + M.elems_after;
+    const int li_min = -(int)(before < 0x30000000ll ? before : 0x30000000ll);
+    const int li_max = M.numel - 3 + (int)(after < 0x08000000ll ? after : 0x08000000ll);
 
     // true coordinates of the pixel this lane computes for sibling m at the current step
-    int xm[4], yc[4], fc[4];
+    int xm[4], yc[4], fc[4], offm[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int t0 = xp + M.delta[m];
@@ -99,6 +110,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
         const int rho_m = r_first + a;
         fc[m] = floor_div32(rho_m, H);
         yc[m] = rho_m - fc[m] * H;
+        offm[m] = (int)(G * (uint32_t)m) + M.s[m] + 3 * lane;      // element offset of the lane's sibling-m pixel in a row step
     }
     float U[4][3], Mi[4][3];
     int yM[4];
@@ -110,32 +122,32 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
     }
 
     // Straight-line schedule: the four siblings are independent, so all four input loads are issued together
-    // (clamped addresses instead of divergent guards) and the loads of the NEXT row are issued before the
-    // current row is processed -- the LUT gathers and the HBM stream then overlap across siblings and steps.
-    const int64_t last_px = (int64_t)M.numel - 3;
+    // and the loads of the NEXT row are issued before the current row is processed -- the LUT gathers and the
+    // HBM stream then overlap across siblings and steps.
+    int rowbase = r_first * E + 3 * x0;                                // element of lane 0's primary pixel
+    const int q0s = (int)q0;
     px3 xin[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        int64_t li = (int64_t)r_first * E + 3 * (int64_t)x0 + (int64_t)M.G * m + M.s[m] + 3 * lane;
-        li = li < 0 ? 0 : (li > last_px ? last_px : li);
+        int li = rowbase + offm[m];
+        li = li < li_min ? li_min : (li > li_max ? li_max : li);
         xin[m] = *reinterpret_cast<const px3*>(cin + li);
     }
 
-    for (int rho = r_first; rho <= r_last; ++rho) {
-        const int64_t rowbase = (int64_t)rho * E + 3 * (int64_t)x0;      // element of lane 0's primary pixel
+    for (int rho = r_first; rho <= r_last; ++rho, rowbase += E) {
         px3 xnext[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            int64_t li = rowbase + E + (int64_t)M.G * m + M.s[m] + 3 * lane;
-            li = li < 0 ? 0 : (li > last_px ? last_px : li);
+            int li = rowbase + E + offm[m];
+            li = li < li_min ? li_min : (li > li_max ? li_max : li);
             xnext[m] = *reinterpret_cast<const px3*>(cin + li);
         }
         // ---------------- noise: three Philox calls per lane feed all four siblings
         float nz[3][4], nx[2][4];
         bool fast = false;
+        const int b0 = rowbase - q0s;
         if (STAGES & VRG_STAGE_GRAIN) {
-            const int64_t b0 = rowbase - q0;
-            fast = (b0 >= 0) && (b0 + 3 * 63 + 4 < (int64_t)M.G);
+            fast = (b0 >= 0) && ((uint32_t)(b0 + 3 * 63 + 4) < G);
             if (fast) {
                 const uint32_t idx0 = (uint32_t)b0 + 3u * (uint32_t)lane;
 #pragma unroll
@@ -156,8 +168,8 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
         float Dn[4][3];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const int64_t li = rowbase + (int64_t)M.G * m + M.s[m] + 3 * lane;
-            const bool valid = (uint64_t)li < (uint64_t)(M.numel - 2);     // whole pixel inside the chunk
+            const int li = rowbase + offm[m];
+            const bool valid = (uint32_t)li < px_limit;               // whole pixel inside the chunk
             const float x[3] = {xin[m].r, xin[m].g, xin[m].b};
             float n[3] = {0.0f, 0.0f, 0.0f};
             if (STAGES & VRG_STAGE_GRAIN) {
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                     }
                 } else if (valid) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, M.G, (uint64_t)(li + c));
+                    for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, G, (uint64_t)(uint32_t)(li + c));
                 }
             }
             int fidx = fc[m];
@@ -184,12 +196,12 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
         // ---------------- output
         if (SHARPEN) {
             if (rho >= r_first + 2) {
-                const int64_t outbase = rowbase - E;                         // the middle row
-                const int64_t bo = outbase - q0;
+                const int bo = b0 - E;                                         // middle row, relative to the quarter
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const bool top = yM[m] == 0, bottom = yM[m] == H - 1;
                     const bool left = xm[m] == 0, right = xm[m] == W - 1;
+                    const bool any_edge = __builtin_amdgcn_ballot_w64(top || bottom || left || right) != 0;   // wave-uniform
                     float res[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
@@ -197,23 +209,24 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                         p[0][0] = lane_prev(U[m][c]);  p[0][1] = U[m][c];  p[0][2] = lane_next(U[m][c]);
                         p[1][0] = lane_prev(Mi[m][c]); p[1][1] = Mi[m][c]; p[1][2] = lane_next(Mi[m][c]);
                         p[2][0] = lane_prev(Dn[m][c]); p[2][1] = Dn[m][c]; p[2][2] = lane_next(Dn[m][c]);
+                        if (any_edge) {                                        // rare: some lane of the wave sits on a frame border
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            if (top) p[0][j] = zero ? 0.0f : p[1][j];
-                            if (bottom) p[2][j] = zero ? 0.0f : p[1][j];
-                        }
+                            for (int j = 0; j < 3; ++j) {
+                                if (top) p[0][j] = zero ? 0.0f : p[1][j];
+                                if (bottom) p[2][j] = zero ? 0.0f : p[1][j];
+                            }
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            if (left) p[i][0] = zero ? 0.0f : p[i][1];
-                            if (right) p[i][2] = zero ? 0.0f : p[i][1];
+                            for (int i = 0; i < 3; ++i) {
+                                if (left) p[i][0] = zero ? 0.0f : p[i][1];
+                                if (right) p[i][2] = zero ? 0.0f : p[i][1];
+                            }
                         }
                         res[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
                     }
-                    const int64_t li = outbase + (int64_t)M.G * m + M.s[m] + 3 * lane;
-                    const int64_t idx = bo + M.s[m] + 3 * lane;               // subsequence of channel 0
-                    if (lane_out && (uint64_t)li < (uint64_t)(M.numel - 2)) {
-                        const bool a0 = (uint64_t)idx < (uint64_t)M.G, a1 = (uint64_t)(idx + 1) < (uint64_t)M.G,
-                                   a2 = (uint64_t)(idx + 2) < (uint64_t)M.G;
+                    const int li = rowbase - E + offm[m];
+                    const uint32_t idx = (uint32_t)(bo + M.s[m] + 3 * lane);   // subsequence of channel 0 (wraps to huge if negative)
+                    if (lane_out && (uint32_t)li < px_limit) {
+                        const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
                         if (a0 && a1 && a2) {
                             *reinterpret_cast<px3*>(cout + li) = px3{res[0], res[1], res[2]};
                         } else {
@@ -231,14 +244,12 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                 for (int c = 0; c < 3; ++c) { U[m][c] = Mi[m][c]; Mi[m][c] = Dn[m][c]; }
             }
         } else {
-            const int64_t bo = rowbase - q0;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int64_t li = rowbase + (int64_t)M.G * m + M.s[m] + 3 * lane;
-                const int64_t idx = bo + M.s[m] + 3 * lane;
-                if (lane_out && (uint64_t)li < (uint64_t)(M.numel - 2)) {
-                    const bool a0 = (uint64_t)idx < (uint64_t)M.G, a1 = (uint64_t)(idx + 1) < (uint64_t)M.G,
-                               a2 = (uint64_t)(idx + 2) < (uint64_t)M.G;
+                const int li = rowbase + offm[m];
+                const uint32_t idx = (uint32_t)(b0 + M.s[m] + 3 * lane);
+                if (lane_out && (uint32_t)li < px_limit) {
+                    const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
                     if (a0 && a1 && a2) {
                         *reinterpret_cast<px3*>(cout + li) = px3{Dn[m][0], Dn[m][1], Dn[m][2]};
                     } else {
@@ -283,7 +294,7 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
         G = D0.noise.G;
         if (frames % cf) return VRG_ERR_BAD_ARG;
     } else {
-        cf = 0x7fff0000ll / fe;
+        cf = 0x60000000ll / fe;
         if (cf < 1) return VRG_ERR_UNSUPPORTED;
         if (cf > frames) cf = frames;
         if ((stages & VRG_STAGE_COLORMATCH) && D0.cm.ref_frames != 1) {   // keep reference pairing aligned
@@ -291,9 +302,9 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
             if (cf < 1) return VRG_ERR_UNSUPPORTED;
         }
         const int64_t band = 48ll * W * 3;
-        G = (uint32_t)(band < 0x40000000ll ? band : 0x40000000ll);
+        G = (uint32_t)(band < 0x08000000ll ? band : 0x08000000ll);
     }
-    if (cf * fe > 0x7fff0000ll) return VRG_ERR_UNSUPPORTED;
+    if (cf * fe > 0x60000000ll) return VRG_ERR_UNSUPPORTED;
     constexpr int CWs = 61, CWp = 63;
     int64_t done = 0;
     while (done < frames) {
@@ -310,6 +321,8 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
             M.s[m] = (int32_t)((3 - gm % 3) % 3);
             M.delta[m] = (int32_t)((gm + M.s[m]) / 3);
         }
+        M.elems_before = done * fe;
+        M.elems_after = (frames - done - nchunks * cfr) * fe;
         ChainK D = D0;
         const int64_t chunk_index0 = done / cf;
         if (grain) D.noise.chunk0 += chunk_index0;
@@ -317,7 +330,9 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
         const float* src = in + done * fe;
         float* dst = out + done * fe;
         int rc;
-        switch (stages & 7) {
+        if (stages & VRG_STAGE_FROM_LAB) {
+            rc = launch_march_s<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(src, dst, M, D, sharpen, st);
+        } else switch (stages & 7) {
             case 0: rc = launch_march_s<0>(src, dst, M, D, sharpen, st); break;
             case 1: rc = launch_march_s<1>(src, dst, M, D, sharpen, st); break;
             case 2: rc = launch_march_s<2>(src, dst, M, D, sharpen, st); break;

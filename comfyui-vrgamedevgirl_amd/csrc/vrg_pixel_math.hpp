@@ -44,6 +44,14 @@ VRG_HD float f32_from_bits(uint32_t b) {
 VRG_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 // clamp(v, min=lo)
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
+// clamp(v, 0, 1) in one v_med3_f32 where NaN cannot occur or the reference leaves NaN undefined (LUT index)
+VRG_HD float clamp01_finite(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+#else
+    return __builtin_fminf(__builtin_fmaxf(v, 0.0f), 1.0f);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------
 // Division by a compile-time constant as multiply + two FMAs (Markstein): q = x*rc, r = fma(-c,q,x),
@@ -174,17 +182,18 @@ VRG_HD void grain_pixel(const float x[3], const float n[3], float I, float S, fl
 // ------------------------------------------------------------------------------------------
 // 3D LUT (VRGDG_IV_Adjustments.py:293-336, blend :355-359)
 // ------------------------------------------------------------------------------------------
-// The table is consumed in CELL-MAJOR form: one 96-byte record per interpolation cell (b0,g0,r0)
-// holding, per output channel, the 8 corner values in the order k = (dr<<2)|(dg<<1)|db.  A pixel then
-// reads ONE contiguous record (6 x 16 B) instead of 8 scattered 12-byte corners of the [N][N][N][3]
-// table: for incoherent colours that cuts L2->L1 traffic from ~8 cache lines per pixel to ~1.5.
-// Built once per LUT by lut_build_cell(); values are copied, never re-rounded.
+// The table is consumed in a GATHER-FRIENDLY form: one 48-byte record per (b0, g0, r) -- for each output
+// channel the four (g,b) corners {g0b0, g0b1, g1b0, g1b1} at red grid node r.  The records of r and r+1
+// are adjacent, so a pixel reads ONE contiguous 96-byte run (6 x 16 B) instead of 8 scattered 12-byte corners
+// of the [N][N][N][3] table: for incoherent colours that cuts L2->L1 traffic from ~8 cache lines per pixel to
+// ~1.6, and the table (N*(N-1)^2*48 B = 1.6 MB for 33^3) stays L2 resident next to the streaming frames.
+// Built once per LUT by lut_build_record(); values are copied, never re-rounded.
 struct alignas(16) f32x4 { float x, y, z, w; };
 
-constexpr int LUT_CELL_FLOATS = 24;
+constexpr int LUT_REC_FLOATS = 12;
 
 struct LutParams {
-    const float* cells;  // [(N-1)^3][24]
+    const float* cells;  // [(N-1)][(N-1)][N][12]
     int n;               // N
     float top;           // (float)(N-1)
     float dmin[3];
@@ -194,24 +203,24 @@ struct LutParams {
     float blend, one_minus_blend;
 };
 
-// cell (b0,g0,r0) of an [N][N][N][3] table (index [b][g][r]) -> 24 floats
-VRG_HD void lut_build_cell(const float* table, int n, int b0, int g0, int r0, float out[LUT_CELL_FLOATS]) {
+// record (b0,g0,r) of an [N][N][N][3] table (index [b][g][r]) -> 12 floats: [ch][dg*2 + db]
+VRG_HD void lut_build_record(const float* table, int n, int b0, int g0, int r, float out[LUT_REC_FLOATS]) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int b = b0 + (k & 1), g = g0 + ((k >> 1) & 1), r = r0 + (k >> 2);
-            out[ch * 8 + k] = table[(size_t)((b * n + g) * n + r) * 3 + ch];
+        for (int k = 0; k < 4; ++k) {
+            const int b = b0 + (k & 1), g = g0 + (k >> 1);
+            out[ch * 4 + k] = table[(size_t)((b * n + g) * n + r) * 3 + ch];
         }
 }
 
 struct LutAxis { int cell; float f, u; };
 
 // Per-axis index / weights (VRGDG_IV_Adjustments.py:295-318).  i0 = floor(c), i1 = min(i0+1, N-1),
-// f = c - i0.  The top grid node (i0 == N-1, only for t == 1) has i1 == i0 and f == 0; it is served
-// from cell N-2 with weights (u, f) = (0, 1), which selects the same corner value:
-// C[N-2]*0 + C[N-1]*1 == C[N-1]*1 + C[N-1]*0 for every finite table.
-VRG_HD LutAxis lut_axis(float x, float dmin, float span, int unit_domain, float top, int n) {
+// f = c - i0.  The cell index is min(i0, N-2): only the top grid node (c == N-1, i.e. t == 1) is affected,
+// and there f = (N-1) - (N-2) = 1 exactly, u = 0, which selects the same corner value the reference's
+// i0 == i1 == N-1, f == 0 does (C[N-2]*0 + C[N-1]*1 == C[N-1]*1 + C[N-1]*0 for every finite table).
+VRG_HD LutAxis lut_axis(float x, float dmin, float span, int unit_domain, float top) {
     float t;
     if (unit_domain) {
         t = x;
@@ -219,20 +228,13 @@ VRG_HD LutAxis lut_axis(float x, float dmin, float span, int unit_domain, float 
         const float d = x - dmin;
         t = d / span;
     }
-    t = clamp01(t);
+    t = clamp01_finite(t);                       // NaN input: the reference indexes with garbage; we use cell 0
     const float c = t * top;
-    const float fl = __builtin_floorf(c);
-    int i0 = (int)fl;
-    i0 = i0 < 0 ? 0 : (i0 > n - 1 ? n - 1 : i0);  // only reachable for NaN input (reference: undefined)
+    const float fl = __builtin_fminf(__builtin_floorf(c), top - 1.0f);
     LutAxis a;
-    a.f = c - (float)i0;
+    a.cell = (int)fl;
+    a.f = c - fl;
     a.u = 1.0f - a.f;
-    a.cell = i0;
-    if (i0 == n - 1) {
-        a.cell = n - 2;
-        a.u = 0.0f;
-        a.f = 1.0f;
-    }
     return a;
 }
 
@@ -244,22 +246,22 @@ VRG_HD float lerp2(float a, float wa, float b, float wb) {
 
 // rgb in -> graded rgb out (before the strength blend); lerp order blue, green, red (:320-333)
 VRG_HD void lut_pixel_raw(const LutParams& P, const float x[3], float y[3]) {
-    const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top, P.n);
-    const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top, P.n);
-    const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top, P.n);
+    const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
+    const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
+    const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
     const int nc = P.n - 1;
-    const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((B.cell * nc + G.cell) * nc + R.cell) * LUT_CELL_FLOATS);
+    const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((B.cell * nc + G.cell) * P.n + R.cell) * LUT_REC_FLOATS);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const f32x4 lo = q[2 * ch];      // r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
-        const f32x4 hi = q[2 * ch + 1];  // r1
+        const f32x4 lo = q[ch];      // red node r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
+        const f32x4 hi = q[3 + ch];  // red node r0 + 1
         const float c00 = lerp2(lo.x, B.u, lo.y, B.f);
         const float c01 = lerp2(lo.z, B.u, lo.w, B.f);
         const float c10 = lerp2(hi.x, B.u, hi.y, B.f);
         const float c11 = lerp2(hi.z, B.u, hi.w, B.f);
         const float c0 = lerp2(c00, G.u, c01, G.f);
         const float c1 = lerp2(c10, G.u, c11, G.f);
-        y[ch] = clamp01(lerp2(c0, R.u, c1, R.f));
+        y[ch] = clamp01_finite(lerp2(c0, R.u, c1, R.f));    // finite table => finite value
     }
 }
 
@@ -506,16 +508,22 @@ VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, 
     return a + b;
 }
 
-// ms: {mean, std+1e-5} per channel
-VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
-                             const PowTables& PT) {
-    float lab[3], bl[3];
-    rgb_to_lab(rgb, lab, PT);
+// ms: {mean, std+1e-5} per channel.  Lab of the pixel -> matched, blended, back to RGB.
+VRG_HD void colormatch_from_lab(const float lab[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
+                                const PowTables& PT) {
+    float bl[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         bl[c] = colormatch_channel(lab[c], img_ms[2 * c], img_ms[2 * c + 1], ref_ms[2 * c], ref_ms[2 * c + 1], K, T);
     lab_to_rgb(bl, o, PT);
     // final .clamp(0,1) of nodes.py:121 is idempotent after lab_to_rgb's clip
+}
+
+VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
+                             const PowTables& PT) {
+    float lab[3];
+    rgb_to_lab(rgb, lab, PT);
+    colormatch_from_lab(lab, img_ms, ref_ms, K, T, o, PT);
 }
 
 }  // namespace vrg

@@ -139,18 +139,18 @@ __global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ 
 // ----------------------------------------------------------------------------------------------
 // 3D LUT.  One pixel per thread.  The table does not fit the 160 KB LDS in fp32 (33^3*12 B = 431 KB,
 // SURVEY.md section 7), so it is served by the vector L1 / per-XCD L2 -- in cell-major form (see
-// vrg_pixel_math.hpp): one 96-byte record per pixel instead of eight scattered corners.
+// vrg_pixel_math.hpp): one contiguous 96-byte run per pixel instead of eight scattered corners.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lut_build_cells(const float* __restrict__ table, int n, float* __restrict__ cells) {
     const int nc = n - 1;
-    const int cell = blockIdx.x * 256 + threadIdx.x;
-    if (cell >= nc * nc * nc) return;
-    const int r0 = cell % nc, g0 = (cell / nc) % nc, b0 = cell / (nc * nc);
-    float rec[LUT_CELL_FLOATS];
-    lut_build_cell(table, n, b0, g0, r0, rec);
-    f32x4* dst = reinterpret_cast<f32x4*>(cells + (size_t)cell * LUT_CELL_FLOATS);
+    const int rec = blockIdx.x * 256 + threadIdx.x;
+    if (rec >= nc * nc * n) return;
+    const int r = rec % n, g0 = (rec / n) % nc, b0 = rec / (n * nc);
+    float v[LUT_REC_FLOATS];
+    lut_build_record(table, n, b0, g0, r, v);
+    f32x4* dst = reinterpret_cast<f32x4*>(cells + (size_t)rec * LUT_REC_FLOATS);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dst[i] = f32x4{rec[4 * i], rec[4 * i + 1], rec[4 * i + 2], rec[4 * i + 3]};
+    for (int i = 0; i < 3; ++i) dst[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
 }
 
 template <bool RGB_ONLY>
@@ -262,13 +262,13 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
 int64_t vrg_lut_cells_floats(int32_t lut_size) {
     if (lut_size < 2 || lut_size > 256) return 0;
     const int64_t nc = lut_size - 1;
-    return nc * nc * nc * LUT_CELL_FLOATS;
+    return nc * nc * lut_size * LUT_REC_FLOATS;
 }
 
 int vrg_lut_prepare_f32(const float* lut, int32_t lut_size, float* cells, void* stream) {
     if (!lut || !cells || lut_size < 2 || lut_size > 256) return VRG_ERR_BAD_ARG;
     const int64_t nc = lut_size - 1;
-    const uint32_t blocks = (uint32_t)((nc * nc * nc + 255) / 256);
+    const uint32_t blocks = (uint32_t)((nc * nc * lut_size + 255) / 256);
     hipLaunchKernelGGL(k_lut_build_cells, dim3(blocks), dim3(256), 0, (hipStream_t)stream, lut, lut_size, cells);
     VRG_CHECK_LAUNCH();
     return VRG_OK;

@@ -291,12 +291,15 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
 
 
 def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
-                ref_ms: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124), two passes over HBM."""
+                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
+    """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124).  Two passes over HBM:
+    statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain."""
     x = _check_frames(images, channels=3)
     if ref_ms is None:
-        ref = _check_frames(reference_image, "reference_image", channels=3).to(x.device)
+        ref = _check_frames(reference_image.to(x.device), "reference_image", channels=3)
         ref_ms = finalize_stats(lab_stats(ref))
+    if cache_lab:
+        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength)))
     img_ms = finalize_stats(lab_stats(x))
     return colormatch_apply(x, img_ms, ref_ms, match_strength)
 
@@ -350,12 +353,20 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
 
 
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
-                out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
+                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
     pass).  Bit-identical to applying the stand-alone operators in that order.
 
     `out` may supply the destination (bench: no allocation in the timed region); `kernel_events`, if a list,
-    receives (start, stop) HipEvent pairs bracketing each vrg_fused_chain_f32 launch on the current stream."""
+    receives (name, start, stop, frames) tuples -- HipEvent pairs on the current stream bracketing the
+    statistics pass ("stats") and the fused apply pass ("apply") of every segment.
+
+    Chains with a colour-match stage run as two passes: (1) grain -> LUT -> Lab, reduced to per-frame statistics
+    and (cache_lab=True) stored as a Lab image, (2) match -> Lab->RGB -> sharpen on that Lab image.  With
+    cache_lab=False pass 2 re-evaluates grain/LUT/Lab from the input instead (36 B/px instead of 48 B/px of HBM
+    traffic, but the gathers and powers twice); both forms give bit-identical results.  `lab_workspace` may
+    supply the fp32 buffer (same shape as images)."""
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
     if out is None:
@@ -388,8 +399,27 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
                 raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
             stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
             scratch = _stats_scratch(nf, x.device)
-            _hip.check(lib.vrg_chain_stats_f32(src, nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
-                       "vrg_chain_stats_f32")
+            if kernel_events is not None:
+                s0, s1 = HipEvent(), HipEvent()
+                s0.record()
+            if cache_lab:
+                if lab_workspace is not None:
+                    if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
+                        raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
+                    lab = lab_workspace[f0:f0 + nf]
+                else:
+                    lab = torch.empty((nf, H, W, 3), dtype=torch.float32, device=x.device)
+                keep.append(lab)
+                _hip.check(lib.vrg_chain_stats_lab_f32(src, _hip.ptr(lab), nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
+                           "vrg_chain_stats_lab_f32")
+                src = C.c_void_p(lab.data_ptr())
+                d.stages = (d.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+            else:
+                _hip.check(lib.vrg_chain_stats_f32(src, nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
+                           "vrg_chain_stats_f32")
+            if kernel_events is not None:
+                s1.record()
+                kernel_events.append(("stats", s0, s1, nf))
             img_ms = finalize_stats(stats)
             d.img_ms = img_ms.data_ptr()
             keep.append(img_ms)
@@ -399,7 +429,7 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         _hip.check(lib.vrg_fused_chain_f32(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_f32")
         if kernel_events is not None:
             e1.record()
-            kernel_events.append((e0, e1))
+            kernel_events.append(("apply", e0, e1, nf))
     return out
 
 

@@ -99,10 +99,10 @@ int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
  * the blend in apply_lut (VRGDG_IV_Adjustments.py:288-361), _apply_lut_tensor
  * (VRGDG_LUTVideoTools.py:172-185).
  * A LUT is prepared once: vrg_lut_prepare_f32 rewrites the parsed table `lut` (device fp32
- * [N][N][N][3] indexed [blue][green][red], as _parse_cube_file returns it) into the cell-major form
- * the kernels read -- (N-1)^3 records of 24 floats, one per interpolation cell, corner values copied
- * verbatim -- so that a pixel fetches one contiguous 96-byte record instead of eight scattered
- * corners.  `cells` must hold vrg_lut_cells_floats(N) floats, 16-byte aligned.  2 <= N <= 256.
+ * [N][N][N][3] indexed [blue][green][red], as _parse_cube_file returns it) into the gather-friendly
+ * form the kernels read -- (N-1)^2*N records of 12 floats, one per (b0, g0, red node), the four (g,b)
+ * corner values of each channel copied verbatim -- so that a pixel fetches one contiguous 96-byte
+ * run (red nodes r0, r0+1) instead of eight scattered corners.  `cells` must hold vrg_lut_cells_floats(N) floats, 16-byte aligned.  2 <= N <= 256.
  * `channels` >= 3; channels beyond RGB are copied through.  blend_mode: 1 = LUT only (blend>=1),
  * 2 = fl(fl(x*one_minus_blend) + fl(y*blend)).  (blend <= 0 is the caller's no-op.)
  * ------------------------------------------------------------------------------------------- */
@@ -147,10 +147,13 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
 #define VRG_STAGE_LUT        2
 #define VRG_STAGE_COLORMATCH 4
 #define VRG_STAGE_SHARPEN    8
+/* With VRG_STAGE_COLORMATCH: `in` already holds the Lab image of the colour-match input (written by
+ * vrg_chain_stats_lab_f32), so grain / LUT / rgb_to_lab are not re-evaluated in the apply pass. */
+#define VRG_STAGE_FROM_LAB   16
 
 typedef struct vrg_chain_desc {
     int32_t stages;               /* VRG_STAGE_* bits */
-    int32_t variant;              /* 0 = wave-march kernel (default); 1 = LDS-tile / point-wise kernels (A/B, cross-check) */
+    int32_t variant;              /* 0 = automatic; 1 = LDS-tile / point-wise kernels; 2 = register-resident wave-march kernel */
     /* grain */
     float intensity, sat, one_minus_sat;
     vrg_noise_desc noise;
@@ -171,6 +174,12 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
  * scratch as vrg_lab_stats_f32. */
 int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
                         const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
+/* Same pass, additionally storing the Lab image it reduces (`lab_out`, same shape as `in`): the apply pass
+ * then runs with VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB (| VRG_STAGE_SHARPEN) on `lab_out`.  Trades
+ * 12 B/px of extra HBM traffic for not evaluating grain, the LUT gathers and six powers twice -- the chain is
+ * ALU / L1-request bound, not HBM bound.  Results are bit-identical to the recomputing form. */
+int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int32_t height, int32_t width,
+                            const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Introspection
@@ -188,6 +197,9 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);
+/* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
+ * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 128-B record stride. */
+int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

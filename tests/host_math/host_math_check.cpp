@@ -71,11 +71,11 @@ void hm_grain(const float* x, const float* n, float* o, int64_t pixels, float I,
 void hm_lut(const float* x, float* o, int64_t pixels, const float* table, int n, const float* dmin, const float* dmax,
             int blend_mode, float blend, float one_minus_blend) {
     const int nc = n - 1;
-    float* cells = new float[(size_t)nc * nc * nc * LUT_CELL_FLOATS + 4];
+    float* cells = new float[(size_t)nc * nc * n * LUT_REC_FLOATS + 4];
     float* aligned = (float*)(((uintptr_t)cells + 15) & ~(uintptr_t)15);
     for (int b = 0; b < nc; ++b)
         for (int g = 0; g < nc; ++g)
-            for (int r = 0; r < nc; ++r) lut_build_cell(table, n, b, g, r, aligned + (size_t)((b * nc + g) * nc + r) * LUT_CELL_FLOATS);
+            for (int r = 0; r < n; ++r) lut_build_record(table, n, b, g, r, aligned + (size_t)((b * nc + g) * n + r) * LUT_REC_FLOATS);
     LutParams P;
     P.cells = aligned; P.n = n; P.top = (float)(n - 1); P.unit_domain = 1;
     for (int c = 0; c < 3; ++c) {

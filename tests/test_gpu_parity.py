@@ -329,6 +329,11 @@ def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
         assert err_ours[3] <= CM_ABS_TOL
     with pytest.raises(RuntimeError):
         node.match_color(x, ref4[:3], 1.0, 4)                # reference batch neither 1 nor the chunk size
+    from comfyui_vrgamedevgirl_amd import ops
+    xd = x.to(dev)
+    a = ops.color_match(xd, ref1.to(dev), 0.35)              # Lab cached between the passes (default)
+    b = ops.color_match(xd, ref1.to(dev), 0.35, cache_lab=False)
+    assert torch.equal(a, b)
 
 
 # ---------------------------------------------------------------------------------------- fused chain
@@ -353,7 +358,7 @@ CHAIN_SHAPES = [(5, 45, 70, 3), (4, 64, 128, 3), (2, 1, 1, 3), (1, 3, 1, 3), (1,
                 (1, 7, 123, 3), (1, 15, 17, 3), (1, 10, 33, 3), (4, 30, 200, 3)]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("case", CHAIN_CASES)
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)
 def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shape, variant):
@@ -392,7 +397,7 @@ def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shap
     assert_bit_equal(fused, o, "fused vs oracle")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("bs,shape", [(4, (3, 720, 1280, 3)), (0, (2, 600, 700, 3)), (1, (2, 540, 960, 3))])
 def test_fused_chain_across_several_philox_groups(ops, dev, variant, bs, shape):
     """Chunks larger than 4*G elements: several Philox call indices, ragged quarter rows, sibling strips that wrap
@@ -415,7 +420,7 @@ def test_fused_chain_across_several_philox_groups(ops, dev, variant, bs, shape):
     assert_bit_equal(fused, R.apply_lut_with_strength(o, data, 6.0), f"point-wise variant {variant}")
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_fused_chain_with_colour_match(ops, dev, variant):
     data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
     x = _rand((4, 48, 80, 3), 61)
@@ -431,6 +436,12 @@ def test_fused_chain_with_colour_match(ops, dev, variant):
     y = ops.color_match(y, None, 0.9, ref_ms=ref_ms)
     y = ops.stencil3x3(y, "unsharp", 0.5, False)
     assert_bit_equal(fused, y, "fused 4-stage vs sequential kernels")
+    torch.manual_seed(5)
+    recompute = ops.fused_chain(xd, spec, cache_lab=False)          # 36 B/px form: grain/LUT/Lab evaluated in both passes
+    assert_bit_equal(recompute, fused, "Lab-caching vs recomputing two-pass forms")
+    ws = torch.empty_like(xd)
+    torch.manual_seed(5)
+    assert_bit_equal(ops.fused_chain(xd, spec, lab_workspace=ws), fused, "caller-supplied Lab workspace")
     torch.manual_seed(5)
     o = R.fast_film_grain(x, 0.04, 0.5, 2, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
     o = R.apply_lut_with_strength(o, data, 10.0)
@@ -454,9 +465,11 @@ def test_full_size_4k_properties(ops, dev):
     y = ops.stencil3x3(ops.lut3d(ops.film_grain(x, 0.04, 0.5, chunk_frames=2), dlut, 10.0), "unsharp", 0.5, False)
     assert torch.equal(fused, y)
     torch.manual_seed(9)
-    tile = ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=1))
-    assert torch.equal(fused, tile)
-    del tile
+    for variant in (1, 2):
+        torch.manual_seed(9)
+        other = ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=variant))
+        assert torch.equal(fused, other), variant
+        del other
     # (2) the grain stream at full size is torch's
     torch.manual_seed(9)
     n = torch.cat([torch.randn((2, H, W, 3), device=dev) for _ in range(2)])

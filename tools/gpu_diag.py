@@ -134,7 +134,25 @@ def kernel_bench(ops, frames_4k, iters):
             ("v1 tile grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False), variant=1))),
             ("v1 tile 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=1))),
             ("fused grain+lut+sharpen smooth", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)), smooth)),
+            ("v2 march sharpen only", 24, chain(ops.ChainSpec(sharpen=("unsharp", 0.5, False), variant=2))),
+            ("v2 march lut+sharpen", 24, chain(ops.ChainSpec(lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False), variant=2))),
+            ("v2 march grain+lut", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), variant=2))),
+            ("v2 march grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False), variant=2))),
+            ("v2 march grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False), variant=2))),
+            ("v1 tile grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False), variant=1))),
+            ("v2 march 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=2))),
+            ("4-stage smooth", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)), smooth)),
         ]
+        if label == "4K":
+            import ctypes as C
+            from comfyui_vrgamedevgirl_amd import _hip
+            probe = torch.empty((px,), dtype=torch.float32, device=dev)
+            wide = torch.zeros(((lut33.size - 1) ** 2 * lut33.size * 16 + 16,), dtype=torch.float32, device=dev)   # 64-B records for mode 3
+            wide[:-16].view(-1, 16)[:, :12] = lut33.table.view(-1, 12)
+            for src_name, src in (("uniform", x), ("smooth", smooth)):
+                for mode, tab in ((0, lut33.table), (1, lut33.table), (2, lut33.table), (3, wide)):
+                    cases.append((f"probe lut fetch mode {mode} {src_name}", 16, (lambda m=mode, t=tab, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
+                        _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), lut33.size, m, _hip.current_stream()), "probe"))))
         for name, bpp, fn in cases:
             try:
                 med, best = time_it(fn, iters, ops)
