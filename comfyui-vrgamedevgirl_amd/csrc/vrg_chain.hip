@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t f = blockIdx.y;
-    const px3 v = in[f * ppf + p];
+    const px3 v = load_px_stream(in + f * ppf + p);
     const float x[3] = {v.r, v.g, v.b};
     float o[3];
     chain_pre<STAGES>(D, f, p, x, o, PT);
-    out[f * ppf + p] = px3{o[0], o[1], o[2]};
+    store_px_stream(out + f * ppf + p, px3{o[0], o[1], o[2]});
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
             y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
             x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
             const int32_t p = y * W + x;
-            const px3 v = fin[p];
+            const px3 v = load_px_stream(fin + p);
             const float xi[3] = {v.r, v.g, v.b};
             chain_pre<STAGES>(D, f, p, xi, o, PT);
         }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
                 for (int dx = 0; dx < 3; ++dx) p[dy][dx] = tile[c][ly + dy][lx + dx];
             o[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
         }
-        fout[y * W + x] = px3{o[0], o[1], o[2]};
+        store_px_stream(fout + (y * W + x), px3{o[0], o[1], o[2]});
     }
 }
 
@@ -130,12 +130,12 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
     const int32_t hi = lo + per < ppf ? lo + per : ppf;
     double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
     for (int32_t p = lo + threadIdx.x; p < hi; p += 256) {
-        const px3 v = fin[p];
+        const px3 v = load_px_stream(fin + p);
         const float x[3] = {v.r, v.g, v.b};
         float pre[3], lab[3];
         chain_pre<STAGES>(D, f, p, x, pre, PT);
         rgb_to_lab(pre, lab, PT);
-        if (lab_out) lab_out[f * ppf + p] = px3{lab[0], lab[1], lab[2]};
+        if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[0], lab[1], lab[2]});
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double d = (double)lab[c] - (double)pivot[c];

@@ -11,6 +11,24 @@ namespace vrg {
 // one RGB pixel; 4-byte aligned so that a load/store is a single global_*_dwordx3
 struct __attribute__((packed, aligned(4))) px3 { float r, g, b; };
 
+// Frame data is streamed once: loads/stores carry the non-temporal hint so that they do not displace the LUT
+// records (and the other read-mostly tables) from the per-XCD L2.  clang merges the three scalars into one
+// global_load/store_dwordx3 ... nt.
+__device__ __forceinline__ px3 load_px_stream(const px3* p) {
+    const float* f = reinterpret_cast<const float*>(p);
+    px3 v;
+    v.r = __builtin_nontemporal_load(f);
+    v.g = __builtin_nontemporal_load(f + 1);
+    v.b = __builtin_nontemporal_load(f + 2);
+    return v;
+}
+__device__ __forceinline__ void store_px_stream(px3* p, const px3& v) {
+    float* f = reinterpret_cast<float*>(p);
+    __builtin_nontemporal_store(v.r, f);
+    __builtin_nontemporal_store(v.g, f + 1);
+    __builtin_nontemporal_store(v.b, f + 2);
+}
+
 // Device copy of vrg_noise_desc plus the per-call geometry the noise mapping needs.
 struct NoiseK {
     uint64_t seed0, seed_stride, off0, off_stride;
@@ -64,10 +82,10 @@ inline LutParams make_lut(const float* cells, int n, const float dmin[3], const 
 
 // Stage the pow tables in LDS (2.5 KB) and return the views; every thread of the block must call it.
 #define VRG_STAGE_POW_TABLES(PT)                                                 \
-    __shared__ double vrg_pow_lds_[::vrg::POW_TABLE_DOUBLES];                     \
+    __shared__ __attribute__((aligned(16))) float vrg_pow_lds_[::vrg::POW_TABLE_WORDS]; \
     ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);      \
     __syncthreads();                                                             \
-    const ::vrg::PowTables PT{vrg_pow_lds_, vrg_pow_lds_ + 256}
+    const ::vrg::PowTables PT{vrg_pow_lds_, vrg_pow_lds_ + 512}
 
 #define VRG_CHECK_LAUNCH()                                   \
     do {                                                     \

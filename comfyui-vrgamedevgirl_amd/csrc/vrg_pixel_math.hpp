@@ -364,59 +364,57 @@ VRG_HD float stencil_value(int op, const float p[3][3], float strength, int zero
 }
 
 // ------------------------------------------------------------------------------------------
-// pow(x, y) for normal positive finite x and a constant exponent, evaluated in fp64 and rounded once to
-// fp32: |relative error| < 1e-12 before the final rounding, i.e. the correctly rounded fp32 power except in
-// ~1e-5 of cases where it is off by one ulp.  (torch's pow kernels are ocml powf on HIP and Sleef powf on
-// CPU, each "<= 1 ulp": this is at least as close to the true value as either.)
-//   x = 2^e * m, m in [1,2);  i = top 7 mantissa bits;  r = m*invc_i - 1 (|r| <= 2^-8, exact in fp64);
-//   log2 x = e + logc_i + r*(A1 + r*(A2 + r*(A3 + r*A4)));   E = y*log2 x = n/64 + f, |f| <= 2^-7;
-//   x^y = 2^(n>>6) * 2^((n&63)/64) * (1 + f*(B1 + f*(B2 + f*(B3 + f*B4)))).
-// ~21 fp64-rate ops + 2 table reads instead of ocml powf's ~180 instructions.
+// pow(x, y) for normal positive finite x and a constant exponent, in fp32 "double-word" arithmetic:
+//   x = 2^e * m, m in [1,2);  i = top 7 mantissa bits;  r = fma(m, invc_i, -1)        (|r| <= 2^-8, one rounding)
+//   log2 x = (e + logc_hi_i) + (logc_lo_i + r*(A0 + r*(A1 + r*A2)))                   = L_hi + L_lo, L_hi exact
+//   E = y*log2 x = E_hi + E_lo with E_hi = RN(y*L_hi), E_lo = fma(y, L_lo, fma(y, L_hi, -E_hi))
+//   n = rint(64*E_hi);  f = (E_hi - n/64) + E_lo  (|f| <= 2^-7);  q = 2^f - 1 by a degree-4 polynomial
+//   x^y = 2^(n>>6) * (T_hi[n&63] + fma(T_hi, q, T_lo))                                the last add is THE rounding
+// Error before that final rounding is < 0.06 ulp, so the result is within 0.56 ulp of the true power (ocml powf
+// and Sleef powf, what torch uses on HIP / CPU, are "<= 1 ulp").  ~33 fp32 issue slots + 2 LDS reads instead of
+// ocml powf's ~180 instructions; no fp64.
 // ------------------------------------------------------------------------------------------
 #include "vrg_pow_tables.inc"
 
-constexpr int POW_TABLE_DOUBLES = 256 + 64;
+constexpr int POW_TABLE_WORDS = 128 * 4 + 64 * 2;   // fp32 words
 
 struct PowTables {
-    const double* logt;  // [128][2] = {invc, logc}
-    const double* expt;  // [64]
+    const float* logt;  // [128][4] = {invc, logc_hi, logc_lo, pad}
+    const float* expt;  // [64][2]  = {hi, lo}
 };
 
-VRG_HD double f64_from_bits(unsigned long long b) {
-    union { unsigned long long u; double d; } c;
-    c.u = b;
-    return c.d;
-}
-
 // copy the constexpr tables into `dst` (LDS on the device, a static array in the host checker)
-VRG_HD void pow_tables_fill(double* dst, int first, int stride) {
-    for (int i = first; i < POW_TABLE_DOUBLES; i += stride)
-        dst[i] = f64_from_bits(i < 256 ? VRG_POW_LOGT[i >> 1][i & 1] : VRG_POW_EXPT[i - 256]);
+VRG_HD void pow_tables_fill(float* dst, int first, int stride) {
+    for (int i = first; i < POW_TABLE_WORDS; i += stride)
+        dst[i] = f32_from_bits(i < 512 ? VRG_POW_LOGT[i >> 2][i & 3] : VRG_POW_EXPT[(i - 512) >> 1][(i - 512) & 1]);
 }
 
-VRG_HD float pow_pos(float x, double y, const PowTables& T) {
+VRG_HD float pow_pos(float x, float y, const PowTables& T) {
     union { float f; uint32_t u; } cv;
     cv.f = x;
     const uint32_t b = cv.u;
-    const int e = (int)(b >> 23) - 127;
+    const float e = (float)((int)(b >> 23) - 127);
     const uint32_t i = (b >> 16) & 0x7fu;
-    const double m = (double)f32_from_bits((b & 0x007fffffu) | 0x3f800000u);
-    const double invc = T.logt[2 * i], logc = T.logt[2 * i + 1];
-    const double r = __builtin_fma(m, invc, -1.0);
-    double p = __builtin_fma(r, f64_from_bits(VRG_POW_A[3]), f64_from_bits(VRG_POW_A[2]));
-    p = __builtin_fma(r, p, f64_from_bits(VRG_POW_A[1]));
-    p = __builtin_fma(r, p, f64_from_bits(VRG_POW_A[0]));
-    const double L = __builtin_fma(r, p, (double)e + logc);
-    const double E = y * L;
-    const double nd = __builtin_rint(E * 64.0);
-    const double f = __builtin_fma(nd, -0.015625, E);
-    const int n = (int)nd;
-    double q = __builtin_fma(f, f64_from_bits(VRG_POW_B[3]), f64_from_bits(VRG_POW_B[2]));
-    q = __builtin_fma(f, q, f64_from_bits(VRG_POW_B[1]));
-    q = __builtin_fma(f, q, f64_from_bits(VRG_POW_B[0]));
-    q = __builtin_fma(f, q, 1.0);
-    const double v = __builtin_ldexp(T.expt[n & 63] * q, n >> 6);
-    return (x != x) ? x : (float)v;
+    const float m = f32_from_bits((b & 0x007fffffu) | 0x3f800000u);
+    const float invc = T.logt[4 * i], lhi = T.logt[4 * i + 1], llo = T.logt[4 * i + 2];
+    const float r = __builtin_fmaf(m, invc, -1.0f);
+    float p = __builtin_fmaf(r, f32_from_bits(VRG_POW_A[2]), f32_from_bits(VRG_POW_A[1]));
+    p = __builtin_fmaf(r, p, f32_from_bits(VRG_POW_A[0]));
+    const float L_hi = e + lhi;                               // exact: lhi is a multiple of 2^-16, |e| < 128
+    const float L_lo = __builtin_fmaf(r, p, llo);
+    const float E_hi = y * L_hi;
+    const float E_lo = __builtin_fmaf(y, L_lo, __builtin_fmaf(y, L_hi, -E_hi));
+    const float nf = __builtin_rintf(E_hi * 64.0f);
+    const float f = __builtin_fmaf(nf, -0.015625f, E_hi) + E_lo;
+    const int n = (int)nf;
+    float q = __builtin_fmaf(f, f32_from_bits(VRG_POW_B[3]), f32_from_bits(VRG_POW_B[2]));
+    q = __builtin_fmaf(f, q, f32_from_bits(VRG_POW_B[1]));
+    q = __builtin_fmaf(f, q, f32_from_bits(VRG_POW_B[0]));
+    q = f * q;
+    const float thi = T.expt[2 * (n & 63)], tlo = T.expt[2 * (n & 63) + 1];
+    const float v = thi + __builtin_fmaf(thi, q, tlo);
+    const float res = __builtin_ldexpf(v, n >> 6);
+    return (x != x) ? x : res;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -427,7 +425,7 @@ VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float t = v + 0.055f;
     const float q = VRG_DIVC(t, 1.055f);
     // the power is only selected for v > 0.04045 (q > 0.09): keep its argument in pow_pos's domain
-    const float hi = pow_pos(clamp_min(q, 0.0625f), (double)2.4f, T);
+    const float hi = pow_pos(clamp_min(q, 0.0625f), 2.4f, T);
     const float lo = VRG_DIVC(v, 12.92f);
     return v > 0.04045f ? hi : lo;
 }
@@ -435,7 +433,7 @@ VRG_HD float srgb_to_linear(float v, const PowTables& T) {
 VRG_HD float linear_to_srgb(float v, const PowTables& T) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
-    const float pw = pow_pos(base, (double)(float)(1.0 / 2.4), T);
+    const float pw = pow_pos(base, (float)(1.0 / 2.4), T);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
@@ -443,7 +441,7 @@ VRG_HD float linear_to_srgb(float v, const PowTables& T) {
 
 VRG_HD float lab_f(float t, const PowTables& T) {
     const float thr = 0.008856f;
-    const float pw = pow_pos(clamp_min(t, thr), (double)(float)(1.0 / 3.0), T);
+    const float pw = pow_pos(clamp_min(t, thr), (float)(1.0 / 3.0), T);
     const float sc = 7.787f * t + (float)(4.0 / 29.0);
     return t > thr ? pw : sc;
 }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, flo
     if (p >= pixels) return;
     float x[3], o[3];
     if (RGB_ONLY) {
-        const px3 v = reinterpret_cast<const px3*>(in)[p];
+        const px3 v = load_px_stream(reinterpret_cast<const px3*>(in) + p);
         x[0] = v.r; x[1] = v.g; x[2] = v.b;
     } else {
         const float* s = in + p * channels;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, flo
     }
     lut_pixel(P, x, o);
     if (RGB_ONLY) {
-        reinterpret_cast<px3*>(out)[p] = px3{o[0], o[1], o[2]};
+        store_px_stream(reinterpret_cast<px3*>(out) + p, px3{o[0], o[1], o[2]});
     } else {
         float* d = out + p * channels;
         d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
@@ -187,13 +187,13 @@ __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict_
     if (p >= pixels_per_frame) return;
     const int64_t f = blockIdx.y;
     const int64_t at = f * pixels_per_frame + p;
-    const px3 v = in[at];
+    const px3 v = load_px_stream(in + at);
     const float x[3] = {v.r, v.g, v.b};
     const float* ims = cm.img_ms + f * 6;
     const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
     float o[3];
     colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT);
-    out[at] = px3{o[0], o[1], o[2]};
+    store_px_stream(out + at, px3{o[0], o[1], o[2]});
 }
 
 }  // namespace vrg

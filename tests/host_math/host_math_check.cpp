@@ -16,8 +16,8 @@
 using namespace vrg;
 
 static const PowTables& host_tables() {
-    static double store[POW_TABLE_DOUBLES];
-    static PowTables T{store, store + 256};
+    static float store[POW_TABLE_WORDS];
+    static PowTables T{store, store + 512};
     static bool init = false;
     if (!init) { pow_tables_fill(store, 0, 1); init = true; }
     return T;
@@ -27,7 +27,7 @@ extern "C" {
 
 void hm_pow(const float* x, float* o, int64_t n, double y) {
     const PowTables& T = host_tables();
-    for (int64_t i = 0; i < n; ++i) o[i] = pow_pos(x[i], y, T);
+    for (int64_t i = 0; i < n; ++i) o[i] = pow_pos(x[i], (float)y, T);
 }
 
 // Markstein division vs IEEE: returns the number of bit mismatches among n inputs (NaN == NaN)

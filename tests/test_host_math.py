@@ -156,9 +156,10 @@ def test_lab_and_colormatch_close_to_oracle(hm):
     assert np.max(np.abs(out - want)) < 5e-6
 
 
-def test_pow_pos_is_essentially_correctly_rounded(hm):
-    """pow_pos (fp64 table + polynomial, one final rounding) against float64 pow rounded to fp32, on the three
-    (exponent, domain) pairs the Lab transforms use."""
+def test_pow_pos_is_faithful(hm):
+    """pow_pos (fp32 double-word log2/exp2, one final rounding) against float64 pow, on the three
+    (exponent, domain) pairs the Lab transforms use: never more than 1 ulp from the correctly rounded fp32 power,
+    within 0.56 ulp of the true value."""
     rng = np.random.default_rng(0)
     for y32, lo, hi in ((np.float32(2.4), 0.0625, 4.0), (np.float32(1.0 / 3.0), 0.008856, 4.0), (np.float32(1.0 / 2.4), 0.0031308, 64.0)):
         x = np.exp(rng.uniform(np.log(lo), np.log(hi), size=2_000_000)).astype(np.float32)
@@ -169,8 +170,9 @@ def test_pow_pos_is_essentially_correctly_rounded(hm):
         want = want64.astype(np.float32)
         ulp = np.abs(out.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
         assert ulp.max() <= 1
-        assert (ulp != 0).mean() < 1e-3          # only near-ties may round the other way
-        assert np.max(np.abs(out.astype(np.float64) - want64) / want64) < 6.1e-8
+        assert (ulp != 0).mean() < 0.06          # only values near a rounding boundary may round the other way
+        ulp_size = np.abs(np.spacing(want).astype(np.float64))
+        assert np.max(np.abs(out.astype(np.float64) - want64) / ulp_size) < 0.56
     bad = np.array([np.nan], dtype=np.float32)
     o = np.empty_like(bad)
     hm.hm_pow(bad, o, 1, 2.4)
