@@ -25,7 +25,12 @@ __host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
 // ----------------------------------------------------------------------------------------------
 template <int STAGES>
 __global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__ in, px3* __restrict__ out, int32_t ppf, ChainK D) {
-    VRG_STAGE_POW_TABLES(PT);
+    __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
+    if (STAGES & VRG_STAGE_COLORMATCH) {
+        pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
+        __syncthreads();
+    }
+    const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t f = blockIdx.y;
@@ -49,7 +54,12 @@ template <int STAGES>
 __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
                                                      int32_t tiles_x, ChainK D) {
     __shared__ float tile[3][HALO_H][LDS_PITCH];
-    VRG_STAGE_POW_TABLES(PT);
+    __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
+    if (STAGES & VRG_STAGE_COLORMATCH) {
+        pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
+        __syncthreads();
+    }
+    const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
     const int32_t ty0 = (blockIdx.x / tiles_x) * TILE_H;
     const int32_t tx0 = (blockIdx.x % tiles_x) * TILE_W;
     const int64_t f = blockIdx.y;
@@ -68,7 +78,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
             y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
             x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
             const int32_t p = y * W + x;
-            const px3 v = load_px_stream(fin + p);
+            const px3 v = fin[p];          // plain load: halo pixels are re-read by the neighbouring tiles (L2 hits)
             const float xi[3] = {v.r, v.g, v.b};
             chain_pre<STAGES>(D, f, p, xi, o, PT);
         }
@@ -110,7 +120,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int STAGES>
+template <int STAGES, int UNROLL = 1>
 __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                        double* __restrict__ partials, px3* __restrict__ lab_out) {
     __shared__ double red[4][6];
@@ -129,18 +139,31 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
     const int32_t lo = blockIdx.x * per;
     const int32_t hi = lo + per < ppf ? lo + per : ppf;
     double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
-    for (int32_t p = lo + threadIdx.x; p < hi; p += 256) {
-        const px3 v = load_px_stream(fin + p);
-        const float x[3] = {v.r, v.g, v.b};
-        float pre[3], lab[3];
-        chain_pre<STAGES>(D, f, p, x, pre, PT);
-        rgb_to_lab(pre, lab, PT);
-        if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[0], lab[1], lab[2]});
+    // UNROLL independent pixels per iteration: one pixel's LUT gather overlaps the other's Philox / pow work
+    for (int32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 256 * UNROLL) {
+        float lab[UNROLL][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double d = (double)lab[c] - (double)pivot[c];
-            s1[c] += d;
-            s2[c] += d * d;
+        for (int u = 0; u < UNROLL; ++u) {
+            const int32_t p = p0 + 256 * u;
+            const int32_t pc = p < hi ? p : hi - 1;
+            const px3 v = load_px_stream(fin + pc);
+            const float x[3] = {v.r, v.g, v.b};
+            float pre[3];
+            chain_pre<STAGES>(D, f, pc, x, pre, PT);
+            rgb_to_lab(pre, lab[u], PT);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int32_t p = p0 + 256 * u;
+            if (p < hi) {
+                if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[u][0], lab[u][1], lab[u][2]});
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double d = (double)lab[u][c] - (double)pivot[c];
+                    s1[c] += d;
+                    s2[c] += d * d;
+                }
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,7 +222,7 @@ __global__ void k_stats_finalize(const double* __restrict__ stats, float* __rest
 
 template <int STAGES>
 static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, const ChainK& D, double* stats, void* scratch,
-                        hipStream_t st, float* lab_out = nullptr) {
+                        hipStream_t st, float* lab_out = nullptr, int unroll = 1) {
     const int64_t ppf = (int64_t)H * W;
     const int bpf = stats_blocks_per_frame(ppf);
     double* partials = reinterpret_cast<double*>(scratch);
@@ -211,8 +234,12 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
             d.noise.chunk0 += f0 / D.noise.chunk_frames;
         }
         const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
-        hipLaunchKernelGGL(k_lab_partials<STAGES>, dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
-                           partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
+        if (unroll == 2)
+            hipLaunchKernelGGL((k_lab_partials<STAGES, 2>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
+                               partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
+        else
+            hipLaunchKernelGGL((k_lab_partials<STAGES, 1>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
+                               partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
         hipLaunchKernelGGL(k_lab_merge<STAGES>, dim3((uint32_t)nf), dim3(64), 0, st, src, (int32_t)ppf, bpf, d,
                            partials + f0 * bpf * 6, stats + f0 * 9);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
@@ -327,11 +354,12 @@ int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int
     ChainK D;
     const int rc = fill_chain(&pre, height, width, D);
     if (rc) return rc;
+    const int unroll = (desc->variant & 0x100) ? 2 : 1;     // A/B knob: pixels per loop iteration of the reduction
     switch (pre.stages & 3) {
-        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
-        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
-        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
-        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out);
+        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
+        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
+        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
+        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
     }
 }
 
@@ -343,7 +371,7 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
-    if (desc->variant < 0 || desc->variant > 2) return VRG_ERR_UNSUPPORTED;
+    if ((desc->variant & 0xff) > 2 || (desc->variant & ~0x1ff)) return VRG_ERR_UNSUPPORTED;
     ChainK D;
     const int rc = fill_chain(desc, height, width, D);
     if (rc) return rc;
@@ -352,7 +380,7 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     // variant 0 picks by measurement (profiles/): chains with a LUT or a colour-match stage are bound by the
     // L1/L2 gather path resp. fp64 issue, where the higher occupancy of the tile kernels wins; a chain whose
     // only pre-stage is grain is ALU bound and the march (Philox shared across four strips, no LDS) wins.
-    int variant = desc->variant;
+    int variant = desc->variant & 0xff;
     if (variant == 0) variant = ((desc->stages & VRG_STAGE_GRAIN) && !(desc->stages & (VRG_STAGE_LUT | VRG_STAGE_COLORMATCH))) ? 2 : 1;
     if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
     if (desc->stages & VRG_STAGE_FROM_LAB)

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
     for (int m = 0; m < 4; ++m) {
         int li = rowbase + offm[m];
         li = li < li_min ? li_min : (li > li_max ? li_max : li);
-        xin[m] = load_px_stream(reinterpret_cast<const px3*>(cin + li));
+        xin[m] = *reinterpret_cast<const px3*>(cin + li);
     }
 
     for (int rho = r_first; rho <= r_last; ++rho, rowbase += E) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
         for (int m = 0; m < 4; ++m) {
             int li = rowbase + E + offm[m];
             li = li < li_min ? li_min : (li > li_max ? li_max : li);
-            xnext[m] = load_px_stream(reinterpret_cast<const px3*>(cin + li));
+            xnext[m] = *reinterpret_cast<const px3*>(cin + li);
         }
         // ---------------- noise: three Philox calls per lane feed all four siblings
         float nz[3][4], nx[2][4];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                     if (lane_out && (uint32_t)li < px_limit) {
                         const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
                         if (a0 && a1 && a2) {
-                            store_px_stream(reinterpret_cast<px3*>(cout + li), px3{res[0], res[1], res[2]});
+                            *reinterpret_cast<px3*>(cout + li) = px3{res[0], res[1], res[2]};
                         } else {
                             if (a0) cout[li] = res[0];
                             if (a1) cout[li + 1] = res[1];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                 if (lane_out && (uint32_t)li < px_limit) {
                     const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
                     if (a0 && a1 && a2) {
-                        store_px_stream(reinterpret_cast<px3*>(cout + li), px3{Dn[m][0], Dn[m][1], Dn[m][2]});
+                        *reinterpret_cast<px3*>(cout + li) = px3{Dn[m][0], Dn[m][1], Dn[m][2]};
                     } else {
                         if (a0) cout[li] = Dn[m][0];
                         if (a1) cout[li + 1] = Dn[m][1];
