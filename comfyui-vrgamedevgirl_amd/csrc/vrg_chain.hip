@@ -50,9 +50,13 @@ constexpr int TILE_H = 32, TILE_W = 64;
 constexpr int HALO_H = TILE_H + 2, HALO_W = TILE_W + 2;
 constexpr int LDS_PITCH = HALO_W + 1;
 
+// XCD-aware work mapping: workgroup b is observed to run on XCD b % 8, each XCD has its own L2.  Work item
+// (frame, tile) = (b % 8) * ceil(total/8) + b / 8 gives every XCD one contiguous run of tiles, so that the halo
+// rows/columns a tile shares with its neighbours are re-read from the same L2 instead of from HBM (PMC: the
+// naive mapping fetched 16.9 B/px for 13.2 B/px of tile+halo reads).  Placement only affects speed.
 template <int STAGES>
 __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
-                                                     int32_t tiles_x, ChainK D) {
+                                                     int32_t tiles_x, int32_t tiles_per_frame, uint32_t total_work, ChainK D) {
     __shared__ float tile[3][HALO_H][LDS_PITCH];
     __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
     if (STAGES & VRG_STAGE_COLORMATCH) {
@@ -60,9 +64,13 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
         __syncthreads();
     }
     const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
-    const int32_t ty0 = (blockIdx.x / tiles_x) * TILE_H;
-    const int32_t tx0 = (blockIdx.x % tiles_x) * TILE_W;
-    const int64_t f = blockIdx.y;
+    const uint32_t per_xcd = (total_work + 7u) / 8u;
+    const uint32_t work = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || work >= total_work) return;      // uniform per workgroup (after the barrier above)
+    const uint32_t tile_id = work % (uint32_t)tiles_per_frame;
+    const int32_t ty0 = (int32_t)(tile_id / (uint32_t)tiles_x) * TILE_H;
+    const int32_t tx0 = (int32_t)(tile_id % (uint32_t)tiles_x) * TILE_W;
+    const int64_t f = work / (uint32_t)tiles_per_frame;
     const int32_t ppf = H * W;
     const px3* fin = in + f * ppf;
     const bool zero = D.zero_border != 0;
@@ -251,8 +259,24 @@ template <int STAGES>
 static int launch_chain(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, bool sharpen,
                         hipStream_t st) {
     const int64_t ppf = (int64_t)H * W;
-    for (int64_t f0 = 0; f0 < frames; f0 += 32768) {
-        const int64_t nf = frames - f0 < 32768 ? frames - f0 : 32768;
+    const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H;
+    const int64_t tpf = (int64_t)tx * ty;
+    // frames per launch: 2-D grid y limit for the point-wise kernel, 32-bit work-item count for the tile kernel
+    int64_t step = 32768;
+    if (sharpen) {
+        step = (1ll << 23) / tpf;
+        if (step < 1) return VRG_ERR_UNSUPPORTED;
+    }
+    if (STAGES & VRG_STAGE_GRAIN) {
+        if (step < D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
+        step -= step % D.noise.chunk_frames;
+    }
+    if ((STAGES & VRG_STAGE_COLORMATCH) && D.cm.ref_frames != 1) {
+        if (step < D.cm.ref_frames) return VRG_ERR_UNSUPPORTED;
+        step -= step % D.cm.ref_frames;     // (both alignments together are only needed when ref_frames divides chunk_frames)
+    }
+    for (int64_t f0 = 0; f0 < frames; f0 += step) {
+        const int64_t nf = frames - f0 < step ? frames - f0 : step;
         ChainK d = D;
         if (STAGES & VRG_STAGE_GRAIN) {
             if (f0 % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
@@ -265,8 +289,9 @@ static int launch_chain(const float* in, float* out, int64_t frames, int32_t H, 
         const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
         px3* dst = reinterpret_cast<px3*>(out) + f0 * ppf;
         if (sharpen) {
-            const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H;
-            hipLaunchKernelGGL(k_chain_tile<STAGES>, dim3((uint32_t)(tx * ty), (uint32_t)nf), dim3(256), 0, st, src, dst, H, W, tx, d);
+            const uint32_t total = (uint32_t)(tpf * nf);
+            const uint32_t blocks = ((total + 7u) / 8u) * 8u;
+            hipLaunchKernelGGL(k_chain_tile<STAGES>, dim3(blocks), dim3(256), 0, st, src, dst, H, W, tx, (int32_t)tpf, total, d);
         } else {
             hipLaunchKernelGGL(k_chain_pointwise<STAGES>, dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st, src,
                                dst, (int32_t)ppf, d);
@@ -377,11 +402,12 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (rc) return rc;
     const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
     // variant 2: register-resident wave march (vrg_march.hip); variant 1: LDS tile / point-wise kernels below.
-    // variant 0 picks by measurement (profiles/): chains with a LUT or a colour-match stage are bound by the
-    // L1/L2 gather path resp. fp64 issue, where the higher occupancy of the tile kernels wins; a chain whose
-    // only pre-stage is grain is ALU bound and the march (Philox shared across four strips, no LDS) wins.
+    // variant 0 picks by measurement (profiles/r01_diag_kernels.json): grain -> (LUT) -> sharpen chains are ALU
+    // bound and the march wins (Philox shared across four strips, no LDS); point-wise chains, chains without
+    // grain and the colour-match apply pass run faster on the higher-occupancy tile / point-wise kernels.
     int variant = desc->variant & 0xff;
-    if (variant == 0) variant = ((desc->stages & VRG_STAGE_GRAIN) && !(desc->stages & (VRG_STAGE_LUT | VRG_STAGE_COLORMATCH))) ? 2 : 1;
+    if (variant == 0)
+        variant = ((desc->stages & VRG_STAGE_GRAIN) && (desc->stages & VRG_STAGE_SHARPEN) && !(desc->stages & VRG_STAGE_COLORMATCH)) ? 2 : 1;
     if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
     if (desc->stages & VRG_STAGE_FROM_LAB)
         return launch_chain<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream);

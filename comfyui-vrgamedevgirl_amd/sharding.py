@@ -42,7 +42,7 @@ def allreduce_stats(local: torch.Tensor, group=None, mode: str = "allreduce") ->
     mode="allgather": all-gather the triples and merge them in rank order (bit-deterministic by construction).
     """
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local.clone()
     if local.dtype != torch.float64:
         raise ValueError("statistics must be float64 (n, mean, M2) triples")
@@ -84,7 +84,8 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torchrun (also with a single process)
+    if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -30,6 +30,17 @@ specs = {
     "grainsharp": ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)),
     "sharpen": ops.ChainSpec(sharpen=("unsharp", 0.5, False)),
 }
+if which == "traffic":
+    # known-byte kernels first (calibration), then the headline chain
+    ops.lab_stats(x)                         # k_lab_partials<0>: reads 12 B/px, writes ~nothing
+    ops.lut3d(x, lut, 10.0)                  # k_lut3d: reads 12 B/px (+LUT, cache resident), writes 12 B/px
+    ops.stencil3x3(x, "unsharp", 0.5, False) # k_chain_tile<0>: reads 12 B/px (+9.6% halo), writes 12 B/px
+    lab_ws = torch.empty_like(x)
+    ops.fused_chain(x, specs["chain4"], generator=gen, out=out, lab_workspace=lab_ws)
+    ops.fused_chain(x, specs["chain3"], generator=gen, out=out)
+    torch.cuda.synchronize()
+    print("done traffic")
+    sys.exit(0)
 for _ in range(3):
     if which == "lut":
         ops.lut3d(x, lut, 10.0)
