@@ -67,6 +67,7 @@ _SIGNATURES = {
                                            C.c_float, _P]),
     "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
+    "vrg_chain_stats_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc)]),
     "vrg_chain_stats_lab_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
 }
 

@@ -325,6 +325,10 @@ static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) 
 }
 
 int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st);
+bool produce_applicable(int stages, int64_t frame_elems);
+int64_t produce_scratch_bytes(const ChainK& D, int64_t frames, int64_t fe);
+int launch_produce(const float* in, float* lab_out, int64_t frames, int32_t H, int32_t W, const ChainK& D, int stages, double* stats,
+                   void* scratch, hipStream_t st);
 
 }  // namespace vrg
 
@@ -345,6 +349,20 @@ using namespace vrg;
 extern "C" {
 
 int64_t vrg_lab_stats_scratch_bytes(int64_t frames) { return frames < 0 ? 0 : frames * STATS_BPF_MAX * 6 * (int64_t)sizeof(double); }
+
+int64_t vrg_chain_stats_scratch_bytes(int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc) {
+    if (frames < 0 || height <= 0 || width <= 0 || !desc) return 0;
+    int64_t need = vrg_lab_stats_scratch_bytes(frames);
+    const int64_t fe = (int64_t)height * width * 3;
+    vrg_chain_desc pre = *desc;
+    pre.stages &= (VRG_STAGE_GRAIN | VRG_STAGE_LUT);
+    ChainK D;
+    if (produce_applicable(pre.stages, fe) && fill_chain(&pre, height, width, D) == VRG_OK && frames % D.noise.chunk_frames == 0) {
+        const int64_t p = produce_scratch_bytes(D, frames, fe);
+        if (p > need) need = p;
+    }
+    return need;
+}
 
 int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, double* stats, void* scratch, void* stream) {
     if (!in || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
@@ -380,6 +398,10 @@ int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int
     const int rc = fill_chain(&pre, height, width, D);
     if (rc) return rc;
     const int unroll = (desc->variant & 0x100) ? 2 : 1;     // A/B knob: pixels per loop iteration of the reduction
+    // chains that start with grain: shared-Philox pass (vrg_produce.hip) unless the A/B knob 0x200 asks for the
+    // general kernel; tiny frames always take the general kernel
+    if (!(desc->variant & 0x200) && produce_applicable(pre.stages, (int64_t)height * width * 3) && frames % D.noise.chunk_frames == 0)
+        return launch_produce(in, lab_out, frames, height, width, D, pre.stages, stats, scratch, (hipStream_t)stream);
     switch (pre.stages & 3) {
         case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
         case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
@@ -396,7 +418,7 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
-    if ((desc->variant & 0xff) > 2 || (desc->variant & ~0x1ff)) return VRG_ERR_UNSUPPORTED;
+    if ((desc->variant & 0xff) > 2 || (desc->variant & ~0x3ff)) return VRG_ERR_UNSUPPORTED;
     ChainK D;
     const int rc = fill_chain(desc, height, width, D);
     if (rc) return rc;

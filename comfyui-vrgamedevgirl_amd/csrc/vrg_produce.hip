@@ -1,0 +1,287 @@
+// vrg_produce.hip -- colour-match pass 1 for chains that start with grain: grain -> (LUT) -> Lab, with the Lab
+// image stored and the per-frame statistics reduced, and with the Philox work shared.  gfx950 only.
+//
+// The general statistics kernel (k_lab_partials, vrg_chain.hip) draws each pixel's three normals with three
+// Philox calls (one per element, one of four outputs used).  Here a block owns a run of Philox subsequences
+// of one call index k -- SUBS sub-ranges of 768 subsequences -- and therefore the four element ranges
+// {4Gk + G*m + idx}, m = 0..3, G apart: per sub-range every thread makes 3 Philox calls (12 normals) and
+// processes 4 pixels, one per sibling range (768 elements = 256 pixels per range).  G is not a multiple of 3,
+// so a sibling's pixels are shifted by 0..2 elements against the thread's subsequences: the normals go through
+// LDS, and the two elements past the end of a sub-range come from the general per-element routine.
+// A pixel belongs to the block that owns its channel-0 element, so every pixel is processed exactly once.
+//
+// Statistics: fp64 sums of (lab - pivot), (lab - pivot)^2 per sibling stay in registers across the SUBS
+// sub-ranges and are reduced once per block (wave shuffles -> LDS -> one record per (block, sibling)); a merge
+// kernel adds the records of each frame in a fixed order (deterministic, no atomics).  A sibling run that
+// crosses a frame boundary needs two accumulator sets; those few blocks are handled by the TWO_PART
+// instantiation in a second launch so that the common case keeps its registers.
+#include "vrg_chain_stages.hpp"
+
+namespace vrg {
+
+constexpr int PR_SUB = 768;      // subsequences per sub-range = 256 pixels per sibling
+constexpr int PR_SUBS = 8;       // sub-ranges per block
+constexpr int PR_RUN = PR_SUB * PR_SUBS;
+
+struct ProduceK {
+    int32_t numel;        // chunk elements
+    int32_t fe;           // frame elements (H*W*3)
+    int32_t chunk_frames;
+    uint32_t G, K, NB;    // subsequences, call indices per chunk, blocks per (chunk, k)
+    uint32_t chunks;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// does sibling m of block (k, ib) own pixels of two different frames?
+__device__ __forceinline__ bool run_crosses_frame(const ProduceK& P, int64_t A) {
+    if (A >= P.numel) return false;
+    int64_t last = A + PR_RUN - 1;
+    if (last > P.numel - 1) last = P.numel - 1;
+    return (A / P.fe) != (last / P.fe);
+}
+
+template <int STAGES, bool TWO_PART>
+__global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
+                                                      const float* __restrict__ pivots, double* __restrict__ rec,
+                                                      int32_t* __restrict__ rec_frame) {
+    __shared__ float sn[4][PR_SUB + 4];
+    __shared__ double red[4][12];
+    VRG_STAGE_POW_TABLES(PT);
+    const uint32_t per_chunk = P.K * P.NB;
+    const uint32_t chunk = blockIdx.x / per_chunk;
+    const uint32_t rem = blockIdx.x - chunk * per_chunk;
+    const uint32_t k = rem / P.NB;
+    const uint32_t ib = rem - k * P.NB;
+    const uint32_t G = P.G;
+    const int64_t q0 = (int64_t)4 * G * k;
+    const uint32_t run0 = ib * PR_RUN;                       // first subsequence of the block
+    // which launch handles this block?
+    bool crosses = false;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) crosses = crosses || run_crosses_frame(P, q0 + (int64_t)G * m + run0);
+    if (crosses != TWO_PART) return;
+
+    const float* cin = in + (int64_t)chunk * P.numel;
+    float* clab = lab_out ? lab_out + (int64_t)chunk * P.numel : nullptr;
+    const uint64_t seed = chunk_seed(D.noise, chunk);
+    const uint64_t off = chunk_offset(D.noise, chunk);
+    const uint64_t ctr = (off >> 2) + k;
+    const int tid = threadIdx.x;
+
+    // frames of the four sibling runs and their pivots
+    int fr[4];
+    int64_t fb[4];                 // first element of the next frame (TWO_PART split point)
+    float pv[4][2][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int64_t A = q0 + (int64_t)G * m + run0;
+        fr[m] = A < P.numel ? (int)(A / P.fe) : -1;
+        fb[m] = ((int64_t)fr[m] + 1) * P.fe;
+#pragma unroll
+        for (int part = 0; part < (TWO_PART ? 2 : 1); ++part) {
+            int f = fr[m] + part;
+            f = f < 0 ? 0 : (f > P.chunk_frames - 1 ? P.chunk_frames - 1 : f);
+            const float* pp = pivots + ((int64_t)chunk * P.chunk_frames + f) * 3;
+            pv[m][part][0] = pp[0]; pv[m][part][1] = pp[1]; pv[m][part][2] = pp[2];
+        }
+    }
+    double s1[4][TWO_PART ? 2 : 1][3], s2[4][TWO_PART ? 2 : 1][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int part = 0; part < (TWO_PART ? 2 : 1); ++part)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s1[m][part][c] = 0.0; s2[m][part][c] = 0.0; }
+
+    for (int sub = 0; sub < PR_SUBS; ++sub) {
+        const uint32_t I = run0 + (uint32_t)sub * PR_SUB;            // first subsequence of this sub-range
+        if (I >= G) break;                                           // uniform
+        const uint32_t valid_n = (G - I) < (uint32_t)PR_SUB ? (G - I) : (uint32_t)PR_SUB;
+        // ---- noise of the sub-range into LDS: 3 Philox calls per thread, 12 normals
+        {
+            float nz[3][4];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u32x4 r = philox_for(seed, I + 3u * tid + j, ctr);
+                const f32x2 a = box_muller(r.x, r.y);
+                const f32x2 b = box_muller(r.z, r.w);
+                nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = b.x; nz[j][3] = b.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (3u * tid + j < valid_n) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) sn[m][3 * tid + j] = nz[j][m];
+                }
+            if (tid < 8) {                                           // the two elements past the sub-range, per sibling
+                const int m = tid >> 1, h = tid & 1;
+                const int64_t li = q0 + (int64_t)G * m + I + valid_n + h;
+                sn[m][valid_n + h] = (li < P.numel) ? torch_randn_element(seed, off, G, (uint64_t)li) : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- one pixel per thread and sibling
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int64_t a = q0 + (int64_t)G * m + I;               // first element of the sibling's sub-range
+            const int shift = (int)((3 - a % 3) % 3);                // re-alignment to the pixel grid
+            const int p0 = shift + 3 * tid;                          // position of the pixel's channel 0 in the sub-range
+            const int64_t e0 = a + p0;
+            if (p0 < (int)valid_n && e0 + 2 < P.numel) {
+                const px3 v = load_px_stream(reinterpret_cast<const px3*>(cin + e0));
+                const float x[3] = {v.r, v.g, v.b};
+                const float n[3] = {sn[m][p0], sn[m][p0 + 1], sn[m][p0 + 2]};
+                float pre[3], lab[3];
+                chain_apply_stages<STAGES>(D, 0, x, n, pre, PT);
+                rgb_to_lab(pre, lab, PT);
+                if (clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
+                const int part = TWO_PART ? (e0 >= fb[m] ? 1 : 0) : 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (TWO_PART) {
+                        const double d0 = (double)lab[c] - (double)pv[m][0][c];
+                        const double d1 = (double)lab[c] - (double)pv[m][1][c];
+                        s1[m][0][c] += part == 0 ? d0 : 0.0;  s2[m][0][c] += part == 0 ? d0 * d0 : 0.0;
+                        s1[m][1][c] += part == 1 ? d1 : 0.0;  s2[m][1][c] += part == 1 ? d1 * d1 : 0.0;
+                    } else {
+                        const double d = (double)lab[c] - (double)pv[m][0][c];
+                        s1[m][0][c] += d;
+                        s2[m][0][c] += d * d;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- one record per (block, sibling, part)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int part = 0; part < (TWO_PART ? 2 : 1); ++part) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double a = wave_sum_f64(s1[m][part][c]);
+                const double b = wave_sum_f64(s2[m][part][c]);
+                if (lane == 0) { red[wave][part * 6 + c] = a; red[wave][part * 6 + 3 + c] = b; }
+            }
+        }
+        __syncthreads();
+        const int64_t base = ((int64_t)blockIdx.x * 4 + m) * 2;
+        if (tid < (TWO_PART ? 12 : 6)) {
+            const double t = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            rec[(base + tid / 6) * 6 + tid % 6] = t;
+        }
+        if (tid == 0) {
+            const int f0 = fr[m];
+            rec_frame[base] = f0 >= 0 ? (int32_t)(chunk * P.chunk_frames + f0) : -1;
+            rec_frame[base + 1] = (TWO_PART && f0 >= 0 && f0 + 1 < P.chunk_frames) ? (int32_t)(chunk * P.chunk_frames + f0 + 1) : -1;
+        }
+        __syncthreads();
+    }
+}
+
+// Lab of every frame's first pixel after the pre stages: the pivot of that frame's shifted sums
+template <int STAGES>
+__global__ __launch_bounds__(64) void k_frame_pivots(const px3* __restrict__ in, int32_t ppf, int64_t frames, ChainK D, float* __restrict__ pivots) {
+    VRG_STAGE_POW_TABLES(PT);
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= frames) return;
+    const px3 v0 = in[f * ppf];
+    const float x0[3] = {v0.r, v0.g, v0.b};
+    float pre[3], lab[3];
+    chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+    rgb_to_lab(pre, lab, PT);
+    pivots[f * 3] = lab[0]; pivots[f * 3 + 1] = lab[1]; pivots[f * 3 + 2] = lab[2];
+}
+
+// per frame: add the records tagged with this frame (they all live in the frame's chunk) in a fixed order
+__global__ __launch_bounds__(256) void k_produce_merge(const double* __restrict__ rec, const int32_t* __restrict__ rec_frame,
+                                                        const float* __restrict__ pivots, uint32_t recs_per_chunk, int32_t chunk_frames,
+                                                        int32_t ppf, double* __restrict__ stats) {
+    __shared__ double red[4][6];
+    const int32_t f = blockIdx.x;
+    const int64_t first = (int64_t)(f / chunk_frames) * recs_per_chunk;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (uint32_t r = threadIdx.x; r < recs_per_chunk; r += 256) {
+        if (rec_frame[first + r] == f) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[i] += rec[(first + r) * 6 + i];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double a = wave_sum_f64(acc[i]);
+        if (lane == 0) red[wave][i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        const double s1 = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        const double s2 = ((red[0][3 + c] + red[1][3 + c]) + red[2][3 + c]) + red[3][3 + c];
+        const double n = (double)ppf;
+        const double dm = s1 / n;
+        double m2 = s2 - s1 * dm;
+        if (m2 < 0.0) m2 = 0.0;
+        stats[((int64_t)f * 3 + c) * 3 + 0] = n;
+        stats[((int64_t)f * 3 + c) * 3 + 1] = (double)pivots[(int64_t)f * 3 + c] + dm;
+        stats[((int64_t)f * 3 + c) * 3 + 2] = m2;
+    }
+}
+
+// Can the shared-Philox pass 1 be used?  (grain stage present; a block's run crosses at most one frame boundary)
+bool produce_applicable(int stages, int64_t frame_elems) {
+    return (stages & VRG_STAGE_GRAIN) && !(stages & VRG_STAGE_COLORMATCH) && frame_elems >= PR_RUN + 3;
+}
+
+static void produce_geometry(const ChainK& D, int64_t frames, int64_t fe, ProduceK& P) {
+    P.fe = (int32_t)fe;
+    P.chunk_frames = D.noise.chunk_frames;
+    P.numel = (int32_t)(fe * D.noise.chunk_frames);
+    P.G = D.noise.G;
+    P.K = (uint32_t)((P.numel + 4ll * P.G - 1) / (4ll * P.G));
+    P.NB = (P.G + PR_RUN - 1) / PR_RUN;
+    P.chunks = (uint32_t)(frames / D.noise.chunk_frames);
+}
+
+int64_t produce_scratch_bytes(const ChainK& D, int64_t frames, int64_t fe) {
+    ProduceK P;
+    produce_geometry(D, frames, fe, P);
+    const int64_t blocks = (int64_t)P.chunks * P.K * P.NB;
+    return blocks * 8 * (6 * 8 + 4) + frames * 3 * 4 + 256;
+}
+
+template <int STAGES>
+static int launch_produce_t(const float* in, float* lab_out, int64_t frames, int32_t H, int32_t W, const ChainK& D, double* stats,
+                            void* scratch, hipStream_t st) {
+    const int64_t fe = (int64_t)H * W * 3;
+    ProduceK P;
+    produce_geometry(D, frames, fe, P);
+    const int64_t blocks = (int64_t)P.chunks * P.K * P.NB;
+    if (blocks >= (1ll << 24) || frames % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
+    char* base = reinterpret_cast<char*>(scratch);
+    double* rec = reinterpret_cast<double*>(base);
+    int32_t* rec_frame = reinterpret_cast<int32_t*>(base + blocks * 8 * 6 * 8);
+    float* pivots = reinterpret_cast<float*>(base + blocks * 8 * (6 * 8 + 4));
+    const px3* src = reinterpret_cast<const px3*>(in);
+    hipLaunchKernelGGL(k_frame_pivots<STAGES>, dim3((uint32_t)((frames + 63) / 64)), dim3(64), 0, st, src, (int32_t)(H * W), frames, D, pivots);
+    hipLaunchKernelGGL((k_produce_lab<STAGES, false>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, pivots, rec, rec_frame);
+    hipLaunchKernelGGL((k_produce_lab<STAGES, true>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, pivots, rec, rec_frame);
+    hipLaunchKernelGGL(k_produce_merge, dim3((uint32_t)frames), dim3(256), 0, st, rec, rec_frame, pivots, P.K * P.NB * 8u,
+                       P.chunk_frames, (int32_t)(H * W), stats);
+    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+}
+
+int launch_produce(const float* in, float* lab_out, int64_t frames, int32_t H, int32_t W, const ChainK& D, int stages, double* stats,
+                   void* scratch, hipStream_t st) {
+    if ((stages & 3) == 3) return launch_produce_t<3>(in, lab_out, frames, H, W, D, stats, scratch, st);
+    return launch_produce_t<1>(in, lab_out, frames, H, W, D, stats, scratch, st);
+}
+
+}  // namespace vrg

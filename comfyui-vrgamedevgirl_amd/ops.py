@@ -352,6 +352,35 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
     return d
 
 
+def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
+                lab_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Colour-match pass 1 on its own: fp64 (n, mean, M2) of Lab(grain -> LUT (images)) per frame, optionally
+    storing that Lab image.  (Test / analysis entry; fused_chain runs the same kernels.)"""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    fe = H * W * 3
+    segments = [(0, F, None)]
+    if spec.grain is not None:
+        main, tail, n_full = plans if plans is not None else plan_noise(F, fe, spec.grain[2], x.device, generator)
+        segments = []
+        if main is not None:
+            segments.append((0, n_full * main.chunk_frames, main))
+        if tail is not None:
+            segments.append((F - tail.chunk_frames, tail.chunk_frames, tail))
+    stats = torch.empty((F, 3, 3), dtype=torch.float64, device=x.device)
+    lib = _hip.lib()
+    for f0, nf, plan in segments:
+        keep = []
+        d = _chain_desc(ChainSpec(grain=spec.grain, lut=spec.lut, variant=spec.variant), plan, keep)
+        nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
+        scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
+        src = C.c_void_p(x.data_ptr() + f0 * fe * 4)
+        dst = C.c_void_p(lab_out.data_ptr() + f0 * fe * 4) if lab_out is not None else C.c_void_p(0)
+        _hip.check(lib.vrg_chain_stats_lab_f32(src, dst, nf, H, W, C.byref(d), C.c_void_p(stats.data_ptr() + f0 * 72),
+                                              _hip.ptr(scratch), _hip.current_stream()), "vrg_chain_stats_lab_f32")
+    return stats
+
+
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
                 lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
@@ -398,7 +427,8 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             if d.ref_frames != 1 and (nf % d.ref_frames or f0 % d.ref_frames):
                 raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
             stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
-            scratch = _stats_scratch(nf, x.device)
+            nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
+            scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
             if kernel_events is not None:
                 s0, s1 = HipEvent(), HipEvent()
                 s0.record()

@@ -171,9 +171,12 @@ typedef struct vrg_chain_desc {
 int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
                         const vrg_chain_desc* desc, void* stream);
 /* Lab statistics of the grain->LUT output (the input of the colour-match stage), same layout and
- * scratch as vrg_lab_stats_f32. */
+ * as vrg_lab_stats_f32; `scratch` must hold vrg_chain_stats_scratch_bytes(...) bytes. */
 int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
                         const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
+/* Scratch size for vrg_chain_stats_f32 / vrg_chain_stats_lab_f32 with this descriptor (chains that start with
+ * grain use a pass that shares the Philox work and keeps one partial record per (workgroup, strip)). */
+int64_t vrg_chain_stats_scratch_bytes(int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc);
 /* Same pass, additionally storing the Lab image it reduces (`lab_out`, same shape as `in`): the apply pass
  * then runs with VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB (| VRG_STAGE_SHARPEN) on `lab_out`.  Trades
  * 12 B/px of extra HBM traffic for not evaluating grain, the LUT gathers and six powers twice -- the chain is

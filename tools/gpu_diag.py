@@ -141,7 +141,8 @@ def kernel_bench(ops, frames_4k, iters):
             ("v2 march grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False), variant=2))),
             ("v1 tile grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False), variant=1))),
             ("v2 march 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=2))),
-            ("4-stage stats-unroll2", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=0x100))),
+            ("4-stage general-stats-kernel", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=0x200))),
+            ("4-stage stats-unroll2", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=0x300))),
             ("4-stage smooth", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)), smooth)),
         ]
         if label == "4K":
