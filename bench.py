@@ -166,7 +166,7 @@ def main():
         passes.setdefault(name, []).append(a.elapsed_ms(b))
     pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (segments of a step added up)
     algo_bpp = {"stats": 12, "apply": 24}
-    kern_names = {"stats": "k_lab_partials (grain->LUT->Lab statistics pass, stores Lab)",
+    kern_names = {"stats": "k_produce_lab (grain->LUT->Lab pass 1: shared Philox, stores Lab, per-frame statistics)",
                   "apply": "k_chain_march (fused apply pass)"}
     dom = max(pass_ms, key=pass_ms.get)
     kern_avg_ms = pass_ms[dom]

@@ -53,18 +53,38 @@ __global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ i
     __shared__ double red[4][12];
     VRG_STAGE_POW_TABLES(PT);
     const uint32_t per_chunk = P.K * P.NB;
-    const uint32_t chunk = blockIdx.x / per_chunk;
-    const uint32_t rem = blockIdx.x - chunk * per_chunk;
-    const uint32_t k = rem / P.NB;
-    const uint32_t ib = rem - k * P.NB;
     const uint32_t G = P.G;
+    uint32_t chunk, k, ib;
+    if (!TWO_PART) {
+        // one workgroup per (chunk, k, run); runs that cross a frame boundary are left to the TWO_PART launch
+        chunk = blockIdx.x / per_chunk;
+        const uint32_t rem = blockIdx.x - chunk * per_chunk;
+        k = rem / P.NB;
+        ib = rem - k * P.NB;
+    } else {
+        // one workgroup per (chunk, frame boundary b, sibling m): the run whose sibling m contains element b*fe;
+        // a run crossed by several siblings is taken by the lowest such sibling only
+        const uint32_t per = (uint32_t)(P.chunk_frames - 1) * 4u;
+        chunk = blockIdx.x / per;
+        const uint32_t j = blockIdx.x - chunk * per;
+        const int64_t edge = (int64_t)(j / 4u + 1u) * P.fe;           // first element of frame b
+        const uint32_t m_here = j & 3u;
+        const int64_t q = (edge - 1) / G;                            // quarter of the last element of frame b-1
+        if ((uint32_t)(q & 3) != m_here) return;
+        k = (uint32_t)(q >> 2);
+        ib = (uint32_t)(((edge - 1) - q * (int64_t)G) / PR_RUN);
+    }
     const int64_t q0 = (int64_t)4 * G * k;
     const uint32_t run0 = ib * PR_RUN;                       // first subsequence of the block
-    // which launch handles this block?
     bool crosses = false;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) crosses = crosses || run_crosses_frame(P, q0 + (int64_t)G * m + run0);
+    for (int m = 0; m < 4; ++m) {
+        const bool c = run_crosses_frame(P, q0 + (int64_t)G * m + run0);
+        if (TWO_PART && c && !crosses && (uint32_t)m != (blockIdx.x & 3u)) return;    // a lower sibling owns this run
+        crosses = crosses || c;
+    }
     if (crosses != TWO_PART) return;
+    const uint32_t block_lin = chunk * per_chunk + k * P.NB + ib;    // record slot of the run
 
     const float* cin = in + (int64_t)chunk * P.numel;
     float* clab = lab_out ? lab_out + (int64_t)chunk * P.numel : nullptr;
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ i
             }
         }
         __syncthreads();
-        const int64_t base = ((int64_t)blockIdx.x * 4 + m) * 2;
+        const int64_t base = ((int64_t)block_lin * 4 + m) * 2;
         if (tid < (TWO_PART ? 12 : 6)) {
             const double t = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
             rec[(base + tid / 6) * 6 + tid % 6] = t;
@@ -272,7 +292,9 @@ static int launch_produce_t(const float* in, float* lab_out, int64_t frames, int
     const px3* src = reinterpret_cast<const px3*>(in);
     hipLaunchKernelGGL(k_frame_pivots<STAGES>, dim3((uint32_t)((frames + 63) / 64)), dim3(64), 0, st, src, (int32_t)(H * W), frames, D, pivots);
     hipLaunchKernelGGL((k_produce_lab<STAGES, false>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, pivots, rec, rec_frame);
-    hipLaunchKernelGGL((k_produce_lab<STAGES, true>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, pivots, rec, rec_frame);
+    if (P.chunk_frames > 1)
+        hipLaunchKernelGGL((k_produce_lab<STAGES, true>), dim3(P.chunks * (uint32_t)(P.chunk_frames - 1) * 4u), dim3(256), 0, st, in, lab_out, P,
+                           D, pivots, rec, rec_frame);
     hipLaunchKernelGGL(k_produce_merge, dim3((uint32_t)frames), dim3(256), 0, st, rec, rec_frame, pivots, P.K * P.NB * 8u,
                        P.chunk_frames, (int32_t)(H * W), stats);
     return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
