@@ -173,6 +173,19 @@ def main():
     algo_bytes = algo_bpp[dom] * px_rank
     achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
     bytes_per_px_chain = 36 if "colormatch" in stages else 24
+    # HBM traffic of the dominant pass from the PMC run committed under profiles/ (rocprofv3 cannot run inside this
+    # process): bytes per pixel measured there x the pixels of one launch here
+    traffic, traffic_note = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_fetch_write.json")) as fh:
+            summ = json.load(fh).get("summary", {})
+        key = dom if "colormatch" in stages else "chain3_apply"
+        if summ.get(key, {}).get("total"):
+            traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
+            traffic_note = (f"GB per launch = {summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
+                            "FETCH_SIZE / WRITE_SIZE, separate passes, 16x4K frames, FETCH_SIZE x2 per the gfx950 calibration) x pixels")
+    except Exception:
+        pass
 
     if rank == 0:
         line = {
@@ -188,7 +201,7 @@ def main():
             "chain_hbm_frac": round(value / world * bytes_per_px_chain * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kern_names[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}},
         }
