@@ -32,3 +32,34 @@ def _apply_film_grain_tensor(image_tensor, grain_intensity=0.04, saturation_mix=
         gen = torch.Generator(device=src.device)
         gen.manual_seed(int(seed))
     return ops.film_grain(src, intensity, saturation, chunk_frames=0, generator=gen)
+
+
+# bounds of the 13 sliders (VRGDG_LUTVideoTools.py:282-297 of the reference)
+_ADJUST_BOUNDS = {
+    "temperature": (-100.0, 100.0), "tint": (-100.0, 100.0), "saturation": (-100.0, 100.0),
+    "exposure": (-100.0, 100.0), "contrast": (-100.0, 100.0), "highlights": (-100.0, 100.0),
+    "shadows": (-100.0, 100.0), "whites": (-100.0, 100.0), "blacks": (-100.0, 100.0),
+    "sharpen": (0.0, 100.0), "clarity": (-100.0, 100.0), "vignette": (0.0, 100.0), "fade": (0.0, 100.0),
+}
+
+
+def _normalize_adjust_settings(settings=None):
+    """Same contract as the reference (:280-304): non-dict -> defaults, unparsable -> 0, values clamped to the
+    slider range, ``enabled`` true unless it is literally ``False``."""
+    settings = settings if isinstance(settings, dict) else {}
+    normalized = {"enabled": settings.get("enabled", True) is not False}
+    for key, (lo, hi) in _ADJUST_BOUNDS.items():
+        try:
+            value = float(settings.get(key, 0.0))
+        except Exception:
+            value = 0.0
+        normalized[key] = max(lo, min(hi, value))
+    return normalized
+
+
+def _apply_adjust_tensor(image_tensor, settings=None, device="cpu"):
+    """13-slider Adjust for one decoded batch (:307-391 of the reference): one or two HIP passes
+    (csrc/vrg_adjust.hip); result stays on the GPU."""
+    adjust = _normalize_adjust_settings(settings)
+    src = _on_gpu(image_tensor).to(torch.float32)
+    return ops.adjust(src, ops.adjust_terms(adjust))

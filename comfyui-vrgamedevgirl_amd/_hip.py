@@ -37,6 +37,17 @@ class ChainDesc(C.Structure):
                 ("stencil_op", C.c_int32), ("border", C.c_int32), ("strength", C.c_float)]
 
 
+class AdjustDesc(C.Structure):
+    """vrg_adjust_desc"""
+    _fields_ = [("enabled", C.c_int32), ("shift", C.c_float * 3), ("exposure", C.c_float),
+                ("contrast", C.c_float), ("saturation", C.c_float),
+                ("highlights", C.c_float), ("shadows", C.c_float), ("whites", C.c_float), ("blacks", C.c_float),
+                ("has_clarity", C.c_int32), ("clarity", C.c_float),
+                ("has_sharpen", C.c_int32), ("sharpen", C.c_float),
+                ("has_fade", C.c_int32), ("fade_mul", C.c_float), ("fade_add", C.c_float),
+                ("has_vignette", C.c_int32), ("vignette", C.c_float)]
+
+
 _F3 = C.c_float * 3
 _P = C.c_void_p
 _SIGNATURES = {
@@ -60,6 +71,7 @@ _SIGNATURES = {
                                 C.c_float, _P]),
     "vrg_stencil3x3_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_float, _P]),
+    "vrg_adjust_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(AdjustDesc), _P]),
     "vrg_lab_stats_scratch_bytes": (C.c_int64, [C.c_int64]),
     "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),

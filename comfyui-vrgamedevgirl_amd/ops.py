@@ -229,6 +229,63 @@ def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool
 
 
 # ------------------------------------------------------------------------------------------------
+# 13-slider Adjust (video routes)
+# ------------------------------------------------------------------------------------------------
+
+def adjust_terms(adjust: dict) -> "_hip.AdjustDesc":
+    """Slider arithmetic of _apply_adjust_tensor (VRGDG_LUTVideoTools.py:309-315 ff.) in Python doubles, rounded
+    once to fp32 -- what torch does with a Python scalar operand.  `adjust` is a normalized settings dict."""
+    d = _hip.AdjustDesc()
+    d.enabled = 1 if adjust["enabled"] else 0
+    t, ti = adjust["temperature"], adjust["tint"]
+    d.shift[0] = _f32(t / 400.0 - ti / 900.0)
+    d.shift[1] = _f32(ti / 450.0)
+    d.shift[2] = _f32(-t / 400.0 - ti / 900.0)
+    d.exposure = _f32(2.0 ** (adjust["exposure"] / 100.0))
+    d.contrast = _f32(1.0 + (adjust["contrast"] / 100.0))
+    d.saturation = _f32(1.0 + (adjust["saturation"] / 100.0))
+    d.highlights = _f32(adjust["highlights"] / 220.0)
+    d.shadows = _f32(adjust["shadows"] / 220.0)
+    d.whites = _f32(adjust["whites"] / 240.0)
+    d.blacks = _f32(adjust["blacks"] / 240.0)
+    clarity = adjust["clarity"] / 100.0
+    sharpen = adjust["sharpen"] / 100.0
+    d.has_clarity = 1 if abs(clarity) > 0.001 else 0
+    d.clarity = _f32(clarity)
+    d.has_sharpen = 1 if sharpen > 0.001 else 0
+    d.sharpen = _f32(sharpen)
+    fade = adjust["fade"] / 100.0
+    d.has_fade = 1 if fade > 0.0 else 0
+    d.fade_mul = _f32(1.0 - fade * 0.35)
+    d.fade_add = _f32(fade * 0.18)
+    vignette = adjust["vignette"] / 100.0
+    d.has_vignette = 1 if vignette > 0.0 else 0
+    d.vignette = _f32(vignette)
+    return d
+
+
+def adjust(images: torch.Tensor, terms: "_hip.AdjustDesc", out: torch.Tensor | None = None,
+           workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """Run the Adjust kernels on ``[F,H,W,3]`` fp32 frames.  `workspace` (same shape) is used only when clarity
+    and sharpen are both active; it is allocated when not supplied."""
+    x = _check_frames(images)
+    if x.shape[-1] != 3:
+        raise ValueError("adjust expects 3-channel frames")
+    out = torch.empty_like(x) if out is None else out
+    F, H, W, _ = x.shape
+    if x.numel() == 0:
+        return out
+    tmp = None
+    if terms.enabled and terms.has_clarity and terms.has_sharpen:
+        tmp = workspace if workspace is not None else torch.empty_like(x)
+        if tmp.shape != x.shape or tmp.dtype != torch.float32 or not tmp.is_contiguous() or tmp.device != x.device:
+            raise ValueError("adjust workspace must match the frames")
+    _hip.check(_hip.lib().vrg_adjust_f32(_hip.ptr(x), _hip.ptr(out), _hip.ptr(tmp) if tmp is not None else None,
+                                        F, H, W, C.byref(terms), _hip.current_stream()), "vrg_adjust_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # colour match
 # ------------------------------------------------------------------------------------------------
 

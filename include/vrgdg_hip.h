@@ -185,6 +185,31 @@ int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int
                             const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 13-slider Adjust of the video routes.
+ * Replaces _apply_adjust_tensor, VRGDG_LUTVideoTools.py:307-391: clamp, white balance (temperature / tint),
+ * exposure, contrast, saturation, highlights / shadows / whites / blacks masks, clarity (k x k reflect box,
+ * k = min(9, odd(H), odd(W))), sharpen (3x3 replicate box), fade, vignette, clamp.  The host rounds the
+ * slider arithmetic (Python doubles, :309-315) once to fp32 and passes the terms below; the kernels keep the
+ * reference's fp32 rounding order, including avg_pool2d's raster-order running sums.
+ * `tmp` (same shape as `in`) is needed only when clarity and sharpen are both active; it may be NULL otherwise.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vrg_adjust_desc {
+    int32_t enabled;                 /* 0: output = clamp(in, 0, 1) (:308) */
+    float shift[3];                  /* temp/400 - tint/900, tint/450, -temp/400 - tint/900 (:319-326) */
+    float exposure;                  /* 2 ** (exposure/100) (:327) */
+    float contrast, saturation;      /* 1 + slider/100 (:328,330) */
+    float highlights, shadows;       /* slider/220 (:336-337) */
+    float whites, blacks;            /* slider/240 (:338-339) */
+    int32_t has_clarity; float clarity;      /* slider != 0; slider/100 (:342-356) */
+    int32_t has_sharpen; float sharpen;      /* slider > 0;  slider/100 (:358-372) */
+    int32_t has_fade; float fade_mul, fade_add;   /* 1 - fade*0.35, fade*0.18 (:374-375) */
+    int32_t has_vignette; float vignette;    /* slider > 0; slider/100 (:377-389) */
+} vrg_adjust_desc;
+
+int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int32_t height, int32_t width,
+                   const vrg_adjust_desc* desc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Introspection
  * ------------------------------------------------------------------------------------------- */
 int vrg_abi_version(void);

@@ -398,6 +398,94 @@ def color_match(images, reference_image, match_strength, batch_size):
 
 
 # --------------------------------------------------------------------------------------
+# 13-slider "Adjust" 
+# --------------------------------------------------------------------------------------
+
+ADJUST_FIELDS = {
+    "temperature": (-100.0, 100.0), "tint": (-100.0, 100.0), "saturation": (-100.0, 100.0), "exposure": (-100.0, 100.0),
+    "contrast": (-100.0, 100.0), "highlights": (-100.0, 100.0), "shadows": (-100.0, 100.0), "whites": (-100.0, 100.0),
+    "blacks": (-100.0, 100.0), "sharpen": (0.0, 100.0), "clarity": (-100.0, 100.0), "vignette": (0.0, 100.0), "fade": (0.0, 100.0),
+}
+
+
+def normalize_adjust_settings(settings=None) -> dict:
+    """_normalize_adjust_settings (VRGDG_LUTVideoTools.py:280-304): clamp every slider, bad values -> 0."""
+    settings = settings if isinstance(settings, dict) else {}
+    out = {"enabled": settings.get("enabled", True) is not False}
+    for key, (lo, hi) in ADJUST_FIELDS.items():
+        try:
+            v = float(settings.get(key, 0.0))
+        except Exception:
+            v = 0.0
+        out[key] = max(lo, min(hi, v))
+    return out
+
+
+def _luma(t, dim):
+    r, g, b = t.narrow(dim, 0, 1), t.narrow(dim, 1, 1), t.narrow(dim, 2, 1)
+    return (r * 0.2126) + (g * 0.7152) + (b * 0.0722)
+
+
+def adjust_box_kernel(target: int, height: int, width: int) -> int:
+    """kernel = min(target, largest odd <= H, largest odd <= W); < 3 disables the blur (:349-353)."""
+    return min(int(target), height if height % 2 else height - 1, width if width % 2 else width - 1)
+
+
+def adjust_tensor(image: torch.Tensor, settings=None, ieee_sqrt: bool = False) -> torch.Tensor:
+    """_apply_adjust_tensor (VRGDG_LUTVideoTools.py:307-391), op for op: white balance shift, exposure, contrast,
+    saturation, highlights / shadows / whites / blacks masks on the post-saturation luma, clarity (9x9 reflect box
+    blur detail, mid-tone weighted), sharpen (3x3 replicate box blur detail x5), fade, vignette, clamp.
+
+    ``ieee_sqrt``: this torch build's CPU ``torch.sqrt`` is not correctly rounded (it disagrees with the IEEE
+    square root on ~0.55 % of fp32 inputs, by 1 ulp), while the device sqrt the reference gets on a GPU is.  With
+    ``ieee_sqrt=True`` the vignette distance uses numpy's correctly rounded sqrt -- the only op that changes --
+    which is what the HIP kernels are held to bit for bit; the default reproduces the reference on CPU exactly."""
+    adj = normalize_adjust_settings(settings)
+    source = image.clamp(0.0, 1.0)
+    if not adj["enabled"]:
+        return source
+    out = source + torch.tensor(
+        [adj["temperature"] / 400.0 - adj["tint"] / 900.0, adj["tint"] / 450.0, -adj["temperature"] / 400.0 - adj["tint"] / 900.0],
+        dtype=source.dtype).view(1, 1, 1, 3)
+    out = out * (2.0 ** (adj["exposure"] / 100.0))
+    out = (out - 0.5) * (1.0 + adj["contrast"] / 100.0) + 0.5
+    gray = _luma(out, 3).repeat(1, 1, 1, 3)
+    out = gray + (out - gray) * (1.0 + adj["saturation"] / 100.0)
+    luma = _luma(out, 3)
+    out = out + torch.clamp((luma - 0.55) / 0.45, 0.0, 1.0) * (adj["highlights"] / 220.0)
+    out = out + torch.clamp((0.45 - luma) / 0.45, 0.0, 1.0) * (adj["shadows"] / 220.0)
+    out = out + torch.clamp((luma - 0.75) / 0.25, 0.0, 1.0) * (adj["whites"] / 240.0)
+    out = out + torch.clamp((0.25 - luma) / 0.25, 0.0, 1.0) * (adj["blacks"] / 240.0)
+    clarity = adj["clarity"] / 100.0
+    sharpen = adj["sharpen"] / 100.0
+    if abs(clarity) > 0.001 or sharpen > 0.001:
+        x = out.permute(0, 3, 1, 2)
+        H, W = int(x.shape[2]), int(x.shape[3])
+        if abs(clarity) > 0.001:
+            k = adjust_box_kernel(9, H, W)
+            blur = x if k < 3 else F.avg_pool2d(F.pad(x, (k // 2,) * 4, mode="reflect"), kernel_size=k, stride=1)
+            detail = x - blur
+            mid = 1.0 - torch.clamp(torch.abs(_luma(x, 1) - 0.5) / 0.5, 0.0, 1.0)
+            x = x + detail * clarity * 1.55 * (0.35 + mid * 0.65)
+        if sharpen > 0.001:
+            fine = F.avg_pool2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), kernel_size=3, stride=1)
+            x = x + (x - fine) * sharpen * 5.0
+        out = x.permute(0, 2, 3, 1)
+    fade = adj["fade"] / 100.0
+    if fade > 0.0:
+        out = out * (1.0 - fade * 0.35) + fade * 0.18
+    vig = adj["vignette"] / 100.0
+    if vig > 0.0:
+        H, W = out.shape[1], out.shape[2]
+        yy = torch.linspace(-1.0, 1.0, H, dtype=out.dtype).view(1, H, 1, 1)
+        xx = torch.linspace(-1.0, 1.0, W, dtype=out.dtype).view(1, 1, W, 1)
+        d2 = (xx * xx) + (yy * yy)
+        dist = torch.from_numpy(np.sqrt(d2.numpy())) if ieee_sqrt else torch.sqrt(d2)
+        out = out * (1.0 - torch.clamp((dist - 0.35) / 1.05, 0.0, 1.0) * vig * 0.75)
+    return out.clamp(0.0, 1.0)
+
+
+# --------------------------------------------------------------------------------------
 # Sequential composition used by the fused-chain parity tests
 # --------------------------------------------------------------------------------------
 

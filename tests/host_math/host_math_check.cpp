@@ -12,6 +12,7 @@
 #define VRG_HW_SIN_REV(x) sinf((x) * 6.28318530717958647692f)
 #define VRG_HW_COS_REV(x) cosf((x) * 6.28318530717958647692f)
 #include "vrg_pixel_math.hpp"
+#include "vrg_adjust_math.hpp"
 
 using namespace vrg;
 
@@ -119,6 +120,83 @@ void hm_lab_to_rgb(const float* x, float* o, int64_t pixels) {
 // ms arrays: [3][2] = {mean, std+1e-5}
 void hm_colormatch(const float* x, float* o, int64_t pixels, const float* img_ms, const float* ref_ms, float K, float T) {
     for (int64_t p = 0; p < pixels; ++p) colormatch_pixel(x + 3 * p, img_ms, ref_ms, K, T, o + 3 * p, host_tables());
+}
+
+// Adjust, frame by frame with plain loops: point stage -> (clarity: k x k reflect box, raster-order sum) ->
+// (sharpen: 3x3 replicate box) -> tail.  t = the 20 descriptor terms in vrg_adjust_desc order.
+void hm_adjust(const float* in, float* out, int F, int H, int W, const float* t) {
+    AdjustK A{};
+    A.enabled = (int)t[0];
+    A.shift[0] = t[1]; A.shift[1] = t[2]; A.shift[2] = t[3];
+    A.exposure = t[4]; A.contrast = t[5]; A.saturation = t[6];
+    A.highlights = t[7]; A.shadows = t[8]; A.whites = t[9]; A.blacks = t[10];
+    A.has_clarity = (int)t[11]; A.clarity = t[12]; A.has_sharpen = (int)t[13]; A.sharpen = t[14];
+    A.has_fade = (int)t[15]; A.fade_mul = t[16]; A.fade_add = t[17]; A.has_vignette = (int)t[18]; A.vignette = t[19];
+    A.box = adjust_box_size(H, W);
+    const int64_t n = (int64_t)H * W * 3;
+    float* a = new float[n];
+    float* b = new float[n];
+    for (int f = 0; f < F; ++f) {
+        const float* src = in + f * n;
+        float* dst = out + f * n;
+        if (!A.enabled) {
+            for (int64_t i = 0; i < n; ++i) dst[i] = clamp01(src[i]);
+            continue;
+        }
+        for (int64_t p = 0; p < (int64_t)H * W; ++p) adjust_point(A, src + 3 * p, a + 3 * p);
+        if (A.has_clarity && A.box >= 3) {
+            const int r = A.box / 2;
+            const float kk = (float)(A.box * A.box);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float blur[3];
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.0f;
+                        for (int dy = -r; dy <= r; ++dy)
+                            for (int dx = -r; dx <= r; ++dx) {
+                                int yy = y + dy, xx = x + dx;
+                                if (yy < 0) yy = -yy;
+                                if (yy > H - 1) yy = 2 * (H - 1) - yy;
+                                if (xx < 0) xx = -xx;
+                                if (xx > W - 1) xx = 2 * (W - 1) - xx;
+                                acc = acc + a[((int64_t)yy * W + xx) * 3 + c];
+                            }
+                        blur[c] = acc / kk;
+                    }
+                    adjust_clarity_mix(A, a + ((int64_t)y * W + x) * 3, blur, b + ((int64_t)y * W + x) * 3);
+                }
+            memcpy(a, b, n * sizeof(float));
+        }
+        if (A.has_sharpen) {
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float blur[3];
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.0f;
+                        for (int dy = -1; dy <= 1; ++dy)
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                int yy = y + dy, xx = x + dx;
+                                yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+                                xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                                acc = acc + a[((int64_t)yy * W + xx) * 3 + c];
+                            }
+                        blur[c] = div9(acc);
+                    }
+                    adjust_sharpen_mix(A, a + ((int64_t)y * W + x) * 3, blur, b + ((int64_t)y * W + x) * 3);
+                }
+            memcpy(a, b, n * sizeof(float));
+        }
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float* v = a + ((int64_t)y * W + x) * 3;
+                adjust_tail(A, y, x, H, W, v);
+                dst[((int64_t)y * W + x) * 3 + 0] = v[0];
+                dst[((int64_t)y * W + x) * 3 + 1] = v[1];
+                dst[((int64_t)y * W + x) * 3 + 2] = v[2];
+            }
+    }
+    delete[] a;
+    delete[] b;
 }
 
 }  // extern "C"

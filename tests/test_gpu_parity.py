@@ -520,3 +520,80 @@ def test_full_size_4k_properties(ops, dev):
     cpu = x[0:1, 0:3].cpu()
     o = R.unsharp(R.apply_lut_with_strength(cpu, data, 10.0), 0.5, False)
     assert torch.equal(whole[0, 0:2].cpu(), o[0, 0:2])
+
+
+# ---------------------------------------------------------------------------------------- 13-slider Adjust (8f-2)
+def _adjust_meta():
+    import json
+    with open(os.path.join(GOLDEN, "adjust_cases.json")) as fh:
+        return json.load(fh)
+
+
+def _adjust_want(x, settings, fixture=None):
+    """Bit-exact target: the reference's CPU result, except that the vignette distance uses the correctly rounded
+    sqrt the device has (torch's CPU sqrt is 1 ulp off on ~0.5 % of inputs; oracle/restated.py adjust_tensor)."""
+    norm = R.normalize_adjust_settings(settings)
+    if norm["enabled"] and norm["vignette"] > 0.0:
+        return R.adjust_tensor(x, settings, ieee_sqrt=True).contiguous()
+    return _t(fixture) if fixture is not None else R.adjust_tensor(x, settings).contiguous()
+
+
+def test_adjust_route_matches_reference_fixtures(pkg, dev):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    z = _npz("adjust.npz")
+    meta = _adjust_meta()
+    for tag in meta["shapes"]:
+        x = _t(z[f"{tag}.x"])
+        for name, settings in meta["cases"].items():
+            got = LVT._apply_adjust_tensor(x, settings, "cpu")
+            assert got.is_cuda and got.dtype == torch.float32
+            ref = _t(z[f"{tag}.{name}"])
+            assert (got.cpu() - ref).abs().max().item() <= 1.2e-7, (tag, name)      # reference on CPU, as committed
+            assert_bit_equal(got, _adjust_want(x, settings, z[f"{tag}.{name}"]), f"adjust {tag}.{name}")
+
+
+ADJUST_BIG = [
+    ((2, 97, 150, 3), {"clarity": 55, "sharpen": 25, "vignette": 80, "fade": 30, "exposure": 20}),
+    ((1, 33, 64, 3), {"clarity": -40, "temperature": 60, "blacks": 50}),
+    ((3, 64, 129, 3), {"sharpen": 100, "whites": -35, "tint": 44}),
+    ((1, 32, 65, 3), {"saturation": -100, "contrast": 100, "vignette": 100}),
+    ((2, 270, 480, 3), {"temperature": -12.5, "tint": 8, "saturation": 14, "exposure": -9, "contrast": 11, "highlights": -22,
+                         "shadows": 17, "whites": 6, "blacks": -4, "sharpen": 33, "clarity": 21, "vignette": 28, "fade": 9}),
+    ((1, 8, 300, 3), {"clarity": 100}),          # box shrinks to 7
+    ((1, 300, 6, 3), {"clarity": 100, "sharpen": 50}),   # box shrinks to 5
+]
+
+
+@pytest.mark.parametrize("shape,settings", ADJUST_BIG)
+def test_adjust_kernels_vs_oracle_across_tiles(ops, pkg, dev, shape, settings):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    x = _rand(shape, seed=sum(shape) + len(settings), lo=-0.1, hi=1.1)
+    terms = ops.adjust_terms(LVT._normalize_adjust_settings(settings))
+    xd = x.to(dev)
+    got = ops.adjust(xd, terms)
+    assert_bit_equal(got, _adjust_want(x, settings), f"adjust {shape} {settings}")
+    # caller-provided output / workspace, and input left untouched
+    out = torch.full_like(xd, -7.0)
+    ws = torch.empty_like(xd)
+    got2 = ops.adjust(xd, terms, out=out, workspace=ws)
+    assert got2 is out and torch.equal(out, got) and torch.equal(xd.cpu(), x)
+
+
+def test_adjust_1080p_all_sliders(ops, pkg, dev):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    settings = ADJUST_BIG[4][1]
+    x = _rand((1, 1080, 1920, 3), seed=77, lo=-0.05, hi=1.05)
+    got = ops.adjust(x.to(dev), ops.adjust_terms(LVT._normalize_adjust_settings(settings)))
+    assert_bit_equal(got, _adjust_want(x, settings), "adjust 1080p")
+
+
+def test_adjust_argument_errors(ops, pkg, dev):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    terms = ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 10, "sharpen": 10}))
+    with pytest.raises(ValueError):
+        ops.adjust(torch.zeros(1, 4, 4, 4, device=dev), terms)
+    with pytest.raises(ValueError):
+        ops.adjust(torch.zeros(1, 4, 4, 3, device=dev), terms, workspace=torch.zeros(1, 4, 5, 3, device=dev))
+    with pytest.raises(RuntimeError):
+        ops.adjust(torch.zeros(1, 4, 4, 3), terms)
+    assert ops.adjust(torch.zeros(0, 4, 4, 3, device=dev), terms).shape == (0, 4, 4, 3)

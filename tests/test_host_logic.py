@@ -161,3 +161,27 @@ def test_merge_stats_is_chan(pkg):
     assert merged[0].item() == allv.size
     assert abs(merged[1].item() - allv.mean()) < 1e-10
     assert abs(merged[2].item() - ((allv - allv.mean()) ** 2).sum()) < 1e-6
+
+
+def test_adjust_normalization_and_terms(pkg):
+    """Host mirror of _normalize_adjust_settings (reference fixture) and the descriptor terms the kernels get."""
+    import json
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT, ops
+    with open(os.path.join(GOLDEN, "adjust_normalized.json")) as fh:
+        want = json.load(fh)
+    with open(os.path.join(GOLDEN, "adjust_cases.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for name, settings in cases.items():
+        assert LVT._normalize_adjust_settings(settings) == want[name], name
+    assert LVT._normalize_adjust_settings("nope") == want["not_a_dict"]
+    d = ops.adjust_terms(LVT._normalize_adjust_settings(cases["all"]))
+    f32 = lambda v: float(np.float32(v))
+    assert d.enabled == 1 and d.has_clarity == 1 and d.has_sharpen == 1 and d.has_fade == 1 and d.has_vignette == 1
+    assert d.shift[0] == f32(-12.5 / 400.0 - 8.0 / 900.0) and d.shift[1] == f32(8.0 / 450.0)
+    assert d.shift[2] == f32(12.5 / 400.0 - 8.0 / 900.0)
+    assert d.exposure == f32(2.0 ** (-9.0 / 100.0)) and d.fade_mul == f32(1.0 - 0.09 * 0.35) and d.fade_add == f32(0.09 * 0.18)
+    t = ops.adjust_terms(LVT._normalize_adjust_settings(cases["thresholds"]))   # the reference's > 0.001 / > 0 gates
+    assert t.has_clarity == (1 if abs(0.1 / 100.0) > 0.001 else 0) and t.has_sharpen == (1 if 0.1 / 100.0 > 0.001 else 0)
+    assert t.has_fade == 1 and t.has_vignette == 1
+    off = ops.adjust_terms(LVT._normalize_adjust_settings(cases["disabled"]))
+    assert off.enabled == 0

@@ -190,3 +190,48 @@ def test_constant_division_by_fma_is_ieee_division(hm):
         assert hm.hm_divc_mismatches(mid, mid.size, which) == 0, which
     allx = np.ascontiguousarray(x)
     assert hm.hm_divc_mismatches(allx, allx.size, 8) == 0          # /9 (unsharp): every input incl. denormals, Inf
+
+
+def _adjust_terms_array(pkg_ops, lvt, settings):
+    d = pkg_ops.adjust_terms(lvt._normalize_adjust_settings(settings))
+    return np.array([d.enabled, d.shift[0], d.shift[1], d.shift[2], d.exposure, d.contrast, d.saturation, d.highlights,
+                     d.shadows, d.whites, d.blacks, d.has_clarity, d.clarity, d.has_sharpen, d.sharpen, d.has_fade,
+                     d.fade_mul, d.fade_add, d.has_vignette, d.vignette], dtype=np.float32)
+
+
+def test_adjust_bit_exact(hm, pkg):
+    """Adjust arithmetic (csrc/vrg_adjust_math.hpp) on the host == the reference's fixtures, bit for bit:
+    rounding order of the point stage, raster-order box sums, torch.linspace's two-sided evaluation."""
+    import json
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT, ops
+    hm.hm_adjust.argtypes = [F32P, F32P, C.c_int, C.c_int, C.c_int, F32P]
+    z = np.load(os.path.join(GOLDEN, "adjust.npz"))
+    with open(os.path.join(GOLDEN, "adjust_cases.json")) as fh:
+        meta = json.load(fh)
+    for tag in meta["shapes"]:
+        x = np.ascontiguousarray(z[f"{tag}.x"])
+        F, H, W, _ = x.shape
+        for name, settings in meta["cases"].items():
+            o = np.empty_like(x)
+            hm.hm_adjust(x, o, F, H, W, _adjust_terms_array(ops, LVT, settings))
+            want = z[f"{tag}.{name}"]
+            if LVT._normalize_adjust_settings(settings)["vignette"] > 0.0 and settings.get("enabled", True) is not False:
+                # torch's CPU sqrt is not correctly rounded (oracle/restated.py adjust_tensor): 1 ulp on a few pixels
+                assert np.max(np.abs(o - want)) <= 1.2e-7, (tag, name)
+                assert np.mean(o != want) < 0.03, (tag, name)
+                want = R.adjust_tensor(torch.from_numpy(x), settings, ieee_sqrt=True).contiguous().numpy()
+            assert np.array_equal(o, want), (tag, name, float(np.max(np.abs(o - want))))
+
+
+@pytest.mark.parametrize("shape", [(1, 33, 70, 3), (2, 64, 9, 3), (1, 7, 130, 3)])
+def test_adjust_vs_oracle_larger_frames(hm, pkg, shape):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT, ops
+    hm.hm_adjust.argtypes = [F32P, F32P, C.c_int, C.c_int, C.c_int, F32P]
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(*shape, generator=g) * 1.2 - 0.1
+    for settings in ({"clarity": 55, "sharpen": 25, "vignette": 80, "fade": 30, "exposure": 20},
+                     {"clarity": -40, "temperature": 60, "blacks": 50, "vignette": 100}):
+        want = R.adjust_tensor(x, settings, ieee_sqrt=True).contiguous().numpy()
+        o = np.empty_like(want)
+        hm.hm_adjust(np.ascontiguousarray(x.numpy()), o, shape[0], shape[1], shape[2], _adjust_terms_array(ops, LVT, settings))
+        assert np.array_equal(o, want), float(np.max(np.abs(o - want)))

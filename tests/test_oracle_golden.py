@@ -151,3 +151,28 @@ def test_restatement_against_live_reference_random_shapes():
             assert torch.equal(R.unsharp(x, s, gpu).contiguous(), nodes.FastUnsharpSharpen().apply_unsharp(x, s, gpu)[0].contiguous())
             assert torch.equal(R.laplacian(x, s, gpu).contiguous(), nodes.FastLaplacianSharpen().apply_laplacian(x, s, gpu)[0].contiguous())
             assert torch.equal(R.sobel(x, s, gpu).contiguous(), nodes.FastSobelSharpen().apply_sobel(x, s, gpu)[0].contiguous())
+
+
+# ------------------------------------------------------------------ 13-slider Adjust (section 8f rank 2)
+
+def _adjust_cases():
+    with open(os.path.join(GOLDEN, "adjust_cases.json")) as fh:
+        return json.load(fh)
+
+
+def test_adjust_restatement_against_reference_fixtures():
+    z = _npz("adjust.npz")
+    meta = _adjust_cases()
+    for tag in meta["shapes"]:
+        x = _t(z[f"{tag}.x"])
+        for name, settings in meta["cases"].items():
+            got = R.adjust_tensor(x, settings).contiguous().numpy()
+            assert np.array_equal(got, z[f"{tag}.{name}"]), (tag, name)
+
+
+def test_adjust_normalization_against_reference_fixture():
+    with open(os.path.join(GOLDEN, "adjust_normalized.json")) as fh:
+        want = json.load(fh)
+    for name, settings in _adjust_cases()["cases"].items():
+        assert R.normalize_adjust_settings(settings) == want[name], name
+    assert R.normalize_adjust_settings("nope") == want["not_a_dict"]

@@ -86,7 +86,7 @@ def time_it(fn, iters, ops):
 
 
 @section("kernels")
-def kernel_bench(ops, frames_4k, iters):
+def kernel_bench(ops, frames_4k, iters, match=""):
     from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
     from comfyui_vrgamedevgirl_amd import cube
     dev = torch.device("cuda", 0)
@@ -145,6 +145,20 @@ def kernel_bench(ops, frames_4k, iters):
             ("4-stage stats-unroll2", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), variant=0x300))),
             ("4-stage smooth", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)), smooth)),
         ]
+        from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+        adj_ws = torch.empty_like(x)
+
+        def adj(settings):
+            terms = ops.adjust_terms(LVT._normalize_adjust_settings(settings))
+            return lambda: ops.adjust(x, terms, out=out, workspace=adj_ws)
+
+        cases += [
+            ("adjust point+tail", 24, adj({"temperature": 20, "exposure": 10, "contrast": 12, "saturation": 8, "highlights": -20,
+                                            "shadows": 15, "fade": 10, "vignette": 30})),
+            ("adjust clarity", 24, adj({"clarity": 40, "contrast": 12})),
+            ("adjust sharpen", 24, adj({"sharpen": 40, "contrast": 12})),
+            ("adjust clarity+sharpen", 48, adj({"clarity": 40, "sharpen": 30, "contrast": 12, "vignette": 30})),
+        ]
         if label == "4K":
             import ctypes as C
             from comfyui_vrgamedevgirl_amd import _hip
@@ -156,6 +170,8 @@ def kernel_bench(ops, frames_4k, iters):
                     cases.append((f"probe lut fetch mode {mode} {src_name}", 16, (lambda m=mode, t=tab, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
                         _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), lut33.size, m, _hip.current_stream()), "probe"))))
         for name, bpp, fn in cases:
+            if match and match not in name:
+                continue
             try:
                 med, best = time_it(fn, iters, ops)
                 row = {"size": label, "frames": F, "kernel": name, "ms": round(med, 4), "best_ms": round(best, 4),
@@ -174,6 +190,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=16, help="4K frames per timing batch (1080p uses 4x)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--match", default="", help="only time kernels whose label contains this")
     ap.add_argument("--out", default=os.path.join(OUT_DIR, "diag.json"))
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -181,7 +198,7 @@ def main():
     from comfyui_vrgamedevgirl_amd import ops
     device_info()
     noise_check(ops)
-    kernel_bench(ops, args.frames, args.iters)
+    kernel_bench(ops, args.frames, args.iters, args.match)
     with open(args.out, "w") as fh:
         json.dump(RESULT, fh, indent=1)
     print("[diag] written", args.out)
