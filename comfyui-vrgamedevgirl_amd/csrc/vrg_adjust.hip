@@ -9,10 +9,11 @@
 //
 // Bit-exactness needs the reference's summation order: avg_pool2d adds the k*k taps in raster order, one
 // rounding per add, then divides by k*k.  The stencil kernels therefore keep one sequential chain per output
-// (no separable / sliding sums); each thread produces 4 horizontally adjacent pixels so that one row of 12
-// (resp. 6) LDS values feeds 4 chains.  The point stage is recomputed for the halo instead of being stored.
-// With clarity AND sharpen the second box needs the first one's result in a 1-pixel ring: two passes through a
-// caller-supplied temporary (48 B/px); every other combination is a single 24 B/px pass.
+// (no separable / sliding sums) and spend their effort on issue slots instead (k_adjust_box below).  The point
+// stage is recomputed for the halo instead of being stored.  With clarity AND sharpen the second box needs the
+// first one's result in a 1-pixel ring: two passes through a caller-supplied temporary (48 B/px); every other
+// combination is a single 24 B/px pass.  All kernels are instruction-issue bound (81 dependent adds per pixel and
+// channel for clarity), not HBM bound; DESIGN.md section 8 has the measured table.
 #include "vrg_common.hpp"
 #include "vrg_adjust_math.hpp"
 
@@ -39,93 +40,159 @@ __global__ __launch_bounds__(256) void k_adjust_point(const px3* __restrict__ in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// box-detail stencils.  Tile 32 x 64 output pixels, 256 threads, 4 adjacent pixels per thread, two rows of
-// work per thread.  RADIUS 4 = clarity (reflect border, k x k box with k <= 9), RADIUS 1 = sharpen (replicate).
-// PRE: the tile's input is the frame itself and the point stage is applied while filling LDS; otherwise the
-// input already is the (clarity) intermediate.  TAIL: apply fade / vignette / clamp before storing.
+// box-detail stencils, K = 9 (clarity, reflect border) and K = 3 (sharpen, replicate border).
+//
+// Tile 32 x 64 output pixels, 256 threads, each thread 4 adjacent columns x 2 adjacent rows.  The running sums
+// cannot be re-associated, so the work is 81 (9) dependent adds per pixel and channel; what can be saved is issue
+// slots and LDS traffic:
+//   * the tile (+ halo) is kept in LDS as VERTICAL PAIRS  V[r][c] = (T[r][c], T[r+1][c])  for every r, so the two
+//     rows a thread owns advance together through v_pk_add_f32 (one issue slot, two adds), with every operand an
+//     aligned register pair straight out of ds_read_b128 -- whatever the tap offset;
+//   * one row of 4 + K - 1 pairs feeds the 4 x 2 chains of a thread (K adds each).
+// PRE: the input is the frame and the point stage is applied while filling LDS (recomputed for the halo instead of
+// stored); otherwise the input already is the clarity result.  TAIL: fade / vignette / clamp before storing.
 // ---------------------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int AT_H = 32, AT_W = 64;
 
-template <int RADIUS, bool PRE, bool TAIL>
+template <int K, bool PRE, bool TAIL>
 __global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
                                                      int32_t tiles_x, AdjustK A) {
-    constexpr int LH = AT_H + 2 * RADIUS, LW = AT_W + 2 * RADIUS, PITCH = LW + 4 - (LW % 4 ? LW % 4 : 4) + 4;
-    __shared__ __attribute__((aligned(16))) float tile[3][LH][PITCH];
+    constexpr int R = K / 2, LR = AT_H + 2 * R, LC = AT_W + 2 * R, VR = LR - 1, PITCH = LC + 2;   // LC even => PITCH even
+    constexpr int NCOL = 4 + K - 1;                                                                // pairs per row and thread
+    static_assert(PITCH % 2 == 0 && NCOL % 2 == 0, "b128 alignment");
+    __shared__ __attribute__((aligned(16))) f2 V[3][VR][PITCH];
     const int32_t ty0 = (blockIdx.x / tiles_x) * AT_H;
     const int32_t tx0 = (blockIdx.x % tiles_x) * AT_W;
     const int64_t fbase = (int64_t)blockIdx.y * H * W;
     const px3* fin = in + fbase;
-    const int rad = RADIUS == 1 ? 1 : A.box / 2;          // actual halo used by the box (<= RADIUS)
 
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int hy = i / LW, hx = i - hy * LW;
-        int y = ty0 + hy - RADIUS, x = tx0 + hx - RADIUS;
-        if (RADIUS == 1) {                                // F.pad(mode="replicate")
-            y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-            x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-        } else {                                          // F.pad(mode="reflect"), valid for |offset| <= rad < dim
+    // fill: all global loads of the thread first (one memory latency per tile instead of one per element -- only two
+    // workgroups fit a CU next to 68 KB of LDS), then point stage and the two LDS copies of every element
+    constexpr int NIT = (LR * LC + 255) / 256;
+    px3 pre[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        const int hy = i / LC, hx = i - hy * LC;
+        int y = ty0 + hy - R, x = tx0 + hx - R;
+        if (K != 3) {                                     // F.pad(mode="reflect"); |offset| <= R < dim for real taps
             if (y < 0) y = -y;
             if (y > H - 1) y = 2 * (H - 1) - y;
             if (x < 0) x = -x;
             if (x > W - 1) x = 2 * (W - 1) - x;
-            y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);      // positions further out than `rad` are never read
-            x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
         }
-        const px3 s = fin[y * W + x];
-        float v[3] = {s.r, s.g, s.b};
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);          // replicate (K == 3); otherwise only positions no valid
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);          // output reads (past the frame in a partial tile)
+        pre[it] = fin[y * W + x];                         // i >= LR*LC maps to some valid pixel as well: harmless
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + 256 * it;
+        if (i >= LR * LC) break;
+        const int hy = i / LC, hx = i - hy * LC;
+        float v[3] = {pre[it].r, pre[it].g, pre[it].b};
         if (PRE) {
             float o[3];
             adjust_point(A, v, o);
             v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
         }
-        tile[0][hy][hx] = v[0];
-        tile[1][hy][hx] = v[1];
-        tile[2][hy][hx] = v[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (hy < VR) V[c][hy][hx].x = v[c];
+            if (hy > 0) V[c][hy - 1][hx].y = v[c];
+        }
     }
     __syncthreads();
 
-    const int k = 2 * rad + 1;
-    const float kk = (float)(k * k);
-    px3* fout = out + fbase;
-    for (int it = 0; it < 2; ++it) {
-        const int q = threadIdx.x + 256 * it;             // 512 groups of 4 pixels
-        const int ly = q / (AT_W / 4), lx = (q % (AT_W / 4)) * 4;
-        const int y = ty0 + ly, x0 = tx0 + lx;
-        if (y >= H) continue;
-        float res[4][3];
+    const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * 2;
+    f2 blur[3][4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            // raster order over the k x k window: for each row, taps left to right (avg_pool2d's running sum)
-            for (int dy = -rad; dy <= rad; ++dy) {
-                const float* row = &tile[c][ly + RADIUS + dy][lx + RADIUS - rad];
-                float r[4 + 2 * RADIUS];
+    for (int c = 0; c < 3; ++c) {
+        f2 acc[4];
 #pragma unroll
-                for (int j = 0; j < 4 + 2 * RADIUS; ++j) r[j] = (j < 4 + 2 * rad) ? row[j] : 0.0f;
+        for (int o = 0; o < 4; ++o) acc[o] = f2{0.0f, 0.0f};
+        // raster order over the window: rows top to bottom, taps left to right (avg_pool2d's running sum)
 #pragma unroll
-                for (int dx = 0; dx < 2 * RADIUS + 1; ++dx) {
-                    if (dx < k) {
+        for (int dy = 0; dy < K; ++dy) {
+            const f2* row = &V[c][ly + dy][lx];
+            f2 r[NCOL];
 #pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[o] = acc[o] + r[o + dx];
-                    }
-                }
+            for (int j = 0; j < NCOL; j += 2) {
+                const f4 t = *reinterpret_cast<const f4*>(row + j);
+                r[j] = f2{t.x, t.y};
+                r[j + 1] = f2{t.z, t.w};
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o) res[o][c] = RADIUS == 1 ? div9(acc[o]) : acc[o] / kk;
+            for (int dx = 0; dx < K; ++dx) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = acc[o] + r[o + dx];
+            }
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int x = x0 + o;
-            if (x >= W) continue;
-            const float ctr[3] = {tile[0][ly + RADIUS][lx + RADIUS + o], tile[1][ly + RADIUS][lx + RADIUS + o],
-                                  tile[2][ly + RADIUS][lx + RADIUS + o]};
-            float v[3];
-            if (RADIUS == 1) adjust_sharpen_mix(A, ctr, res[o], v);
-            else adjust_clarity_mix(A, ctr, res[o], v);
-            if (TAIL) adjust_tail(A, y, x, H, W, v);
-            store_px_stream(fout + (y * W + x), px3{v[0], v[1], v[2]});
+            if (K == 3) blur[c][o] = f2{div9(acc[o].x), div9(acc[o].y)};
+            else blur[c][o] = f2{VRG_ADJ_DIV(acc[o].x, (float)(K * K)), VRG_ADJ_DIV(acc[o].y, (float)(K * K))};
         }
     }
+    px3* fout = out + fbase;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = ty0 + ly + rr;
+        if (y >= H) continue;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int x = tx0 + lx + o;
+            if (x >= W) continue;
+            float ctr[3], bl[3], v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f2 cc = V[c][ly + R][lx + R + o];
+                ctr[c] = rr ? cc.y : cc.x;
+                bl[c] = rr ? blur[c][o].y : blur[c][o].x;
+            }
+            if (K == 3) adjust_sharpen_mix(A, ctr, bl, v);
+            else adjust_clarity_mix(A, ctr, bl, v);
+            if (TAIL) adjust_tail(A, y, x, H, W, v);
+            fout[y * W + x] = px3{v[0], v[1], v[2]};      // plain store: a lane's 4 pixels are 4 instructions, L2 merges the lines
+        }
+    }
+}
+
+// Frames smaller than 9 pixels in a dimension: the clarity box shrinks to 7, 5 or 3 (:349-352).  One pixel per
+// thread straight from global memory, point stage per tap -- thumbnails only, not a performance path.
+template <bool TAIL>
+__global__ __launch_bounds__(256) void k_adjust_box_small(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
+                                                           AdjustK A) {
+    const int32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int64_t fbase = (int64_t)blockIdx.y * H * W;
+    const px3* fin = in + fbase;
+    const int y = p / W, x = p % W, r = A.box / 2;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int dy = -r; dy <= r; ++dy)
+        for (int dx = -r; dx <= r; ++dx) {
+            int yy = y + dy, xx = x + dx;
+            if (yy < 0) yy = -yy;
+            if (yy > H - 1) yy = 2 * (H - 1) - yy;
+            if (xx < 0) xx = -xx;
+            if (xx > W - 1) xx = 2 * (W - 1) - xx;
+            const px3 s = fin[yy * W + xx];
+            const float t[3] = {s.r, s.g, s.b};
+            float o[3];
+            adjust_point(A, t, o);
+            acc[0] = acc[0] + o[0]; acc[1] = acc[1] + o[1]; acc[2] = acc[2] + o[2];
+        }
+    const float kk = (float)(A.box * A.box);
+    const px3 s = fin[p];
+    const float t[3] = {s.r, s.g, s.b};
+    float ctr[3], v[3];
+    adjust_point(A, t, ctr);
+    const float bl[3] = {acc[0] / kk, acc[1] / kk, acc[2] / kk};
+    adjust_clarity_mix(A, ctr, bl, v);
+    if (TAIL) adjust_tail(A, y, x, H, W, v);
+    out[fbase + p] = px3{v[0], v[1], v[2]};
 }
 
 }  // namespace vrg
@@ -148,6 +215,8 @@ extern "C" int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t f
     A.has_fade = d->has_fade; A.has_vignette = d->has_vignette;
     const int box = adjust_box_size(height, width);
     A.box = box;
+    A.step_y = linspace_step(height);
+    A.step_x = linspace_step(width);
     A.has_clarity = d->enabled && d->has_clarity && box >= 3;      // kernel < 3: blur == source, detail == 0, x + 0*... == x
     A.has_sharpen = d->enabled && d->has_sharpen;
     hipStream_t st = (hipStream_t)stream;
@@ -159,17 +228,22 @@ extern "C" int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t f
         const px3* s = src + f0 * ppf;
         px3* o = dst + f0 * ppf;
         const dim3 tg((uint32_t)(tx * ty), nf);
-        if (!A.has_clarity && !A.has_sharpen) {
-            hipLaunchKernelGGL(k_adjust_point, dim3((uint32_t)((ppf + 255) / 256), nf), dim3(256), 0, st, s, o, height, width, A);
-        } else if (A.has_clarity && !A.has_sharpen) {
-            hipLaunchKernelGGL((k_adjust_box<4, true, true>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
-        } else if (!A.has_clarity) {
-            hipLaunchKernelGGL((k_adjust_box<1, true, true>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
-        } else {
-            if (!tmp) return VRG_ERR_BAD_ARG;
-            px3* t = reinterpret_cast<px3*>(tmp) + f0 * ppf;
-            hipLaunchKernelGGL((k_adjust_box<4, true, false>), tg, dim3(256), 0, st, s, t, height, width, tx, A);
-            hipLaunchKernelGGL((k_adjust_box<1, false, true>), tg, dim3(256), 0, st, t, o, height, width, tx, A);
+        const dim3 pg((uint32_t)((ppf + 255) / 256), nf);
+        px3* mid = A.has_sharpen ? (tmp ? reinterpret_cast<px3*>(tmp) + f0 * ppf : nullptr) : o;   // clarity result
+        if (A.has_clarity && A.has_sharpen && !mid) return VRG_ERR_BAD_ARG;
+        if (!A.has_clarity && !A.has_sharpen) hipLaunchKernelGGL(k_adjust_point, pg, dim3(256), 0, st, s, o, height, width, A);
+        if (A.has_clarity) {
+            if (box == 9) {
+                if (A.has_sharpen) hipLaunchKernelGGL((k_adjust_box<9, true, false>), tg, dim3(256), 0, st, s, mid, height, width, tx, A);
+                else hipLaunchKernelGGL((k_adjust_box<9, true, true>), tg, dim3(256), 0, st, s, mid, height, width, tx, A);
+            } else {
+                if (A.has_sharpen) hipLaunchKernelGGL(k_adjust_box_small<false>, pg, dim3(256), 0, st, s, mid, height, width, A);
+                else hipLaunchKernelGGL(k_adjust_box_small<true>, pg, dim3(256), 0, st, s, mid, height, width, A);
+            }
+        }
+        if (A.has_sharpen) {
+            if (A.has_clarity) hipLaunchKernelGGL((k_adjust_box<3, false, true>), tg, dim3(256), 0, st, mid, o, height, width, tx, A);
+            else hipLaunchKernelGGL((k_adjust_box<3, true, true>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
         }
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
     }

@@ -133,6 +133,7 @@ void hm_adjust(const float* in, float* out, int F, int H, int W, const float* t)
     A.has_clarity = (int)t[11]; A.clarity = t[12]; A.has_sharpen = (int)t[13]; A.sharpen = t[14];
     A.has_fade = (int)t[15]; A.fade_mul = t[16]; A.fade_add = t[17]; A.has_vignette = (int)t[18]; A.vignette = t[19];
     A.box = adjust_box_size(H, W);
+    A.step_y = linspace_step(H); A.step_x = linspace_step(W);
     const int64_t n = (int64_t)H * W * 3;
     float* a = new float[n];
     float* b = new float[n];
@@ -161,7 +162,7 @@ void hm_adjust(const float* in, float* out, int F, int H, int W, const float* t)
                                 if (xx > W - 1) xx = 2 * (W - 1) - xx;
                                 acc = acc + a[((int64_t)yy * W + xx) * 3 + c];
                             }
-                        blur[c] = acc / kk;
+                        blur[c] = A.box == 9 ? VRG_ADJ_DIV(acc, 81.0f) : acc / kk;
                     }
                     adjust_clarity_mix(A, a + ((int64_t)y * W + x) * 3, blur, b + ((int64_t)y * W + x) * 3);
                 }
