@@ -46,6 +46,9 @@ int64_t hm_divc_mismatches(const float* x, int64_t n, int which) {
             case 5: got = VRG_DIVC(v, 500.0f); want = v / 500.0f; break;
             case 6: got = VRG_DIVC(v, 200.0f); want = v / 200.0f; break;
             case 7: got = VRG_DIVC(v, 7.787f); want = v / 7.787f; break;
+            case 9: got = VRG_ADJ_DIV(v, 0.45f); want = v / 0.45f; break;
+            case 10: got = VRG_ADJ_DIV(v, 1.05f); want = v / 1.05f; break;
+            case 11: got = VRG_ADJ_DIV(v, 81.0f); want = v / 81.0f; break;
             default: got = div9(v); want = v / 9.0f; break;
         }
         uint32_t a, b;

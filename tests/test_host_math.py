@@ -190,6 +190,8 @@ def test_constant_division_by_fma_is_ieee_division(hm):
         assert hm.hm_divc_mismatches(mid, mid.size, which) == 0, which
     allx = np.ascontiguousarray(x)
     assert hm.hm_divc_mismatches(allx, allx.size, 8) == 0          # /9 (unsharp): every input incl. denormals, Inf
+    for which in (9, 10, 11):                                       # Adjust: guarded form, every input
+        assert hm.hm_divc_mismatches(allx, allx.size, which) == 0, which
 
 
 def _adjust_terms_array(pkg_ops, lvt, settings):
