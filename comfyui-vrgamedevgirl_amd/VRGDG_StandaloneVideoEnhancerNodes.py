@@ -48,3 +48,16 @@ def _process_with_retry(images, settings, frame_start):
         left, ls = _process_with_retry(images[:mid], settings, frame_start)
         right, rs = _process_with_retry(images[mid:], settings, frame_start + mid)
         return torch.cat((left, right), dim=0), min(ls, rs)
+
+
+def _frames_to_tensor(frames):
+    """BGR uint8 frames -> fp32 RGB in [0,1] (:311-316 of the reference); 3 B/px cross PCIe, the conversion runs
+    on the GPU and the tensor stays there for _process_with_retry."""
+    from .VRGDG_LUTVideoTools import _frames_to_tensor as impl
+    return impl(frames)
+
+
+def _tensor_to_frames(tensor):
+    """fp32 RGB -> list of BGR uint8 frames (:319-324 of the reference)."""
+    from .VRGDG_LUTVideoTools import _tensor_to_frames as impl
+    return impl(tensor)

@@ -22,12 +22,14 @@ namespace vrg {
 // ---------------------------------------------------------------------------------------------------------
 // no stencil: point stage + tail, one pixel per thread.  enabled == 0: clamp only.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_adjust_point(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W, AdjustK A) {
+template <class IO>
+__global__ __launch_bounds__(256) void k_adjust_point(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
+                                                       int32_t H, int32_t W, AdjustK A) {
     const int32_t ppf = H * W;
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t at = (int64_t)blockIdx.y * ppf + p;
-    const px3 s = load_px_stream(in + at);
+    const px3 s = IO::load_stream(in + at);
     const float x[3] = {s.r, s.g, s.b};
     float v[3];
     if (!A.enabled) {
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void k_adjust_point(const px3* __restrict__ in
         adjust_point(A, x, v);
         adjust_tail(A, p / W, p % W, H, W, v);
     }
-    store_px_stream(out + at, px3{v[0], v[1], v[2]});
+    IO::store_stream(out + at, px3{v[0], v[1], v[2]});
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -56,9 +58,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int AT_H = 32, AT_W = 64;
 
-template <int K, bool PRE, bool TAIL>
-__global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
-                                                     int32_t tiles_x, AdjustK A) {
+template <int K, bool PRE, bool TAIL, class IN = IoF32, class OUT = IoF32>
+__global__ __launch_bounds__(256) void k_adjust_box(const typename IN::elem* __restrict__ in, typename OUT::elem* __restrict__ out,
+                                                     int32_t H, int32_t W, int32_t tiles_x, AdjustK A) {
     constexpr int R = K / 2, LR = AT_H + 2 * R, LC = AT_W + 2 * R, VR = LR - 1, PITCH = LC + 2;   // LC even => PITCH even
     constexpr int NCOL = 4 + K - 1;                                                                // pairs per row and thread
     static_assert(PITCH % 2 == 0 && NCOL % 2 == 0, "b128 alignment");
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, 
     const int32_t ty0 = (blockIdx.x / tiles_x) * AT_H;
     const int32_t tx0 = (blockIdx.x % tiles_x) * AT_W;
     const int64_t fbase = (int64_t)blockIdx.y * H * W;
-    const px3* fin = in + fbase;
+    const typename IN::elem* fin = in + fbase;
 
     // fill: all global loads of the thread first (one memory latency per tile instead of one per element -- only two
     // workgroups fit a CU next to 68 KB of LDS), then point stage and the two LDS copies of every element
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, 
         }
         y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);          // replicate (K == 3); otherwise only positions no valid
         x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);          // output reads (past the frame in a partial tile)
-        pre[it] = fin[y * W + x];                         // i >= LR*LC maps to some valid pixel as well: harmless
+        pre[it] = IN::load(fin + (y * W + x));            // i >= LR*LC maps to some valid pixel as well: harmless
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, 
             else blur[c][o] = f2{VRG_ADJ_DIV(acc[o].x, (float)(K * K)), VRG_ADJ_DIV(acc[o].y, (float)(K * K))};
         }
     }
-    px3* fout = out + fbase;
+    typename OUT::elem* fout = out + fbase;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = ty0 + ly + rr;
@@ -155,20 +157,20 @@ __global__ __launch_bounds__(256) void k_adjust_box(const px3* __restrict__ in, 
             if (K == 3) adjust_sharpen_mix(A, ctr, bl, v);
             else adjust_clarity_mix(A, ctr, bl, v);
             if (TAIL) adjust_tail(A, y, x, H, W, v);
-            fout[y * W + x] = px3{v[0], v[1], v[2]};      // plain store: a lane's 4 pixels are 4 instructions, L2 merges the lines
+            OUT::store(fout + (y * W + x), px3{v[0], v[1], v[2]});   // plain store: a lane's 4 pixels are 4 instructions, L2 merges the lines
         }
     }
 }
 
 // Frames smaller than 9 pixels in a dimension: the clarity box shrinks to 7, 5 or 3 (:349-352).  One pixel per
 // thread straight from global memory, point stage per tap -- thumbnails only, not a performance path.
-template <bool TAIL>
-__global__ __launch_bounds__(256) void k_adjust_box_small(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
-                                                           AdjustK A) {
+template <bool TAIL, class IN = IoF32, class OUT = IoF32>
+__global__ __launch_bounds__(256) void k_adjust_box_small(const typename IN::elem* __restrict__ in, typename OUT::elem* __restrict__ out,
+                                                           int32_t H, int32_t W, AdjustK A) {
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= H * W) return;
     const int64_t fbase = (int64_t)blockIdx.y * H * W;
-    const px3* fin = in + fbase;
+    const typename IN::elem* fin = in + fbase;
     const int y = p / W, x = p % W, r = A.box / 2;
     float acc[3] = {0.0f, 0.0f, 0.0f};
     for (int dy = -r; dy <= r; ++dy)
@@ -178,29 +180,27 @@ __global__ __launch_bounds__(256) void k_adjust_box_small(const px3* __restrict_
             if (yy > H - 1) yy = 2 * (H - 1) - yy;
             if (xx < 0) xx = -xx;
             if (xx > W - 1) xx = 2 * (W - 1) - xx;
-            const px3 s = fin[yy * W + xx];
+            const px3 s = IN::load(fin + (yy * W + xx));
             const float t[3] = {s.r, s.g, s.b};
             float o[3];
             adjust_point(A, t, o);
             acc[0] = acc[0] + o[0]; acc[1] = acc[1] + o[1]; acc[2] = acc[2] + o[2];
         }
     const float kk = (float)(A.box * A.box);
-    const px3 s = fin[p];
+    const px3 s = IN::load(fin + p);
     const float t[3] = {s.r, s.g, s.b};
     float ctr[3], v[3];
     adjust_point(A, t, ctr);
     const float bl[3] = {acc[0] / kk, acc[1] / kk, acc[2] / kk};
     adjust_clarity_mix(A, ctr, bl, v);
     if (TAIL) adjust_tail(A, y, x, H, W, v);
-    out[fbase + p] = px3{v[0], v[1], v[2]};
+    OUT::store(out + fbase + p, px3{v[0], v[1], v[2]});
 }
 
-}  // namespace vrg
-
-using namespace vrg;
-
-extern "C" int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int32_t height, int32_t width,
-                              const vrg_adjust_desc* d, void* stream) {
+template <class IO>
+static int launch_adjust(const void* in, void* out, float* tmp, int64_t frames, int32_t height, int32_t width, const vrg_adjust_desc* d,
+                         hipStream_t st) {
+    typedef typename IO::elem elem;
     if (!in || !out || !d || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     const int64_t ppf = (int64_t)height * width;
@@ -219,33 +219,79 @@ extern "C" int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t f
     A.step_x = linspace_step(width);
     A.has_clarity = d->enabled && d->has_clarity && box >= 3;      // kernel < 3: blur == source, detail == 0, x + 0*... == x
     A.has_sharpen = d->enabled && d->has_sharpen;
-    hipStream_t st = (hipStream_t)stream;
-    const px3* src = reinterpret_cast<const px3*>(in);
-    px3* dst = reinterpret_cast<px3*>(out);
+    const bool both = A.has_clarity && A.has_sharpen;
+    if (both && !tmp) return VRG_ERR_BAD_ARG;
+    const elem* src = reinterpret_cast<const elem*>(in);
+    elem* dst = reinterpret_cast<elem*>(out);
     const int tx = (width + AT_W - 1) / AT_W, ty = (height + AT_H - 1) / AT_H;
     for (int64_t f0 = 0; f0 < frames; f0 += 32768) {
         const uint32_t nf = (uint32_t)(frames - f0 < 32768 ? frames - f0 : 32768);
-        const px3* s = src + f0 * ppf;
-        px3* o = dst + f0 * ppf;
+        const elem* s = src + f0 * ppf;
+        elem* o = dst + f0 * ppf;
+        px3* mid = both ? reinterpret_cast<px3*>(tmp) + f0 * ppf : nullptr;     // fp32 ring between the two boxes
         const dim3 tg((uint32_t)(tx * ty), nf);
         const dim3 pg((uint32_t)((ppf + 255) / 256), nf);
-        px3* mid = A.has_sharpen ? (tmp ? reinterpret_cast<px3*>(tmp) + f0 * ppf : nullptr) : o;   // clarity result
-        if (A.has_clarity && A.has_sharpen && !mid) return VRG_ERR_BAD_ARG;
-        if (!A.has_clarity && !A.has_sharpen) hipLaunchKernelGGL(k_adjust_point, pg, dim3(256), 0, st, s, o, height, width, A);
+        if (!A.has_clarity && !A.has_sharpen) hipLaunchKernelGGL(k_adjust_point<IO>, pg, dim3(256), 0, st, s, o, height, width, A);
         if (A.has_clarity) {
             if (box == 9) {
-                if (A.has_sharpen) hipLaunchKernelGGL((k_adjust_box<9, true, false>), tg, dim3(256), 0, st, s, mid, height, width, tx, A);
-                else hipLaunchKernelGGL((k_adjust_box<9, true, true>), tg, dim3(256), 0, st, s, mid, height, width, tx, A);
+                if (both) hipLaunchKernelGGL((k_adjust_box<9, true, false, IO, IoF32>), tg, dim3(256), 0, st, s, mid, height, width, tx, A);
+                else hipLaunchKernelGGL((k_adjust_box<9, true, true, IO, IO>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
             } else {
-                if (A.has_sharpen) hipLaunchKernelGGL(k_adjust_box_small<false>, pg, dim3(256), 0, st, s, mid, height, width, A);
-                else hipLaunchKernelGGL(k_adjust_box_small<true>, pg, dim3(256), 0, st, s, mid, height, width, A);
+                if (both) hipLaunchKernelGGL((k_adjust_box_small<false, IO, IoF32>), pg, dim3(256), 0, st, s, mid, height, width, A);
+                else hipLaunchKernelGGL((k_adjust_box_small<true, IO, IO>), pg, dim3(256), 0, st, s, o, height, width, A);
             }
         }
         if (A.has_sharpen) {
-            if (A.has_clarity) hipLaunchKernelGGL((k_adjust_box<3, false, true>), tg, dim3(256), 0, st, mid, o, height, width, tx, A);
-            else hipLaunchKernelGGL((k_adjust_box<3, true, true>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
+            if (both) hipLaunchKernelGGL((k_adjust_box<3, false, true, IoF32, IO>), tg, dim3(256), 0, st, (const px3*)mid, o, height, width, tx, A);
+            else hipLaunchKernelGGL((k_adjust_box<3, true, true, IO, IO>), tg, dim3(256), 0, st, s, o, height, width, tx, A);
         }
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
     }
     return VRG_OK;
 }
+
+// stand-alone conversions (the enhancer's sharpen -> per-frame-seeded grain order runs on fp32 tensors)
+__global__ __launch_bounds__(256) void k_u8_to_f32(const bgr8* __restrict__ in, px3* __restrict__ out, int64_t pixels) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < pixels) store_px_stream(out + p, IoU8::load(in + p));
+}
+__global__ __launch_bounds__(256) void k_f32_to_u8(const px3* __restrict__ in, bgr8* __restrict__ out, int64_t pixels) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < pixels) IoU8::store(out + p, load_px_stream(in + p));
+}
+
+}  // namespace vrg
+
+using namespace vrg;
+
+extern "C" {
+
+int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int32_t height, int32_t width, const vrg_adjust_desc* d,
+                   void* stream) {
+    return launch_adjust<IoF32>(in, out, tmp, frames, height, width, d, (hipStream_t)stream);
+}
+
+int vrg_adjust_u8(const uint8_t* in, uint8_t* out, float* tmp, int64_t frames, int32_t height, int32_t width, const vrg_adjust_desc* d,
+                  void* stream) {
+    return launch_adjust<IoU8>(in, out, tmp, frames, height, width, d, (hipStream_t)stream);
+}
+
+int vrg_u8bgr_to_f32rgb(const uint8_t* in, float* out, int64_t pixels, void* stream) {
+    if (!in || !out || pixels < 0) return VRG_ERR_BAD_ARG;
+    if (pixels == 0) return VRG_OK;
+    if (pixels > (int64_t)0x7fffffff * 256) return VRG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_u8_to_f32, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const bgr8*>(in), reinterpret_cast<px3*>(out), pixels);
+    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+}
+
+int vrg_f32rgb_to_u8bgr(const float* in, uint8_t* out, int64_t pixels, void* stream) {
+    if (!in || !out || pixels < 0) return VRG_ERR_BAD_ARG;
+    if (pixels == 0) return VRG_OK;
+    if (pixels > (int64_t)0x7fffffff * 256) return VRG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_f32_to_u8, dim3((uint32_t)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const px3*>(in), reinterpret_cast<bgr8*>(out), pixels);
+    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -23,8 +23,9 @@ __host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
 // ----------------------------------------------------------------------------------------------
 // Point-wise chain (no sharpen): one pixel per thread.
 // ----------------------------------------------------------------------------------------------
-template <int STAGES>
-__global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__ in, px3* __restrict__ out, int32_t ppf, ChainK D) {
+template <int STAGES, class IO>
+__global__ __launch_bounds__(256) void k_chain_pointwise(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
+                                                          int32_t ppf, ChainK D) {
     __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
     if (STAGES & VRG_STAGE_COLORMATCH) {
         pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
@@ -34,11 +35,11 @@ __global__ __launch_bounds__(256) void k_chain_pointwise(const px3* __restrict__
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t f = blockIdx.y;
-    const px3 v = load_px_stream(in + f * ppf + p);
+    const px3 v = IO::load_stream(in + f * ppf + p);
     const float x[3] = {v.r, v.g, v.b};
     float o[3];
     chain_pre<STAGES>(D, f, p, x, o, PT);
-    store_px_stream(out + f * ppf + p, px3{o[0], o[1], o[2]});
+    IO::store_stream(out + f * ppf + p, px3{o[0], o[1], o[2]});
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -54,9 +55,10 @@ constexpr int LDS_PITCH = HALO_W + 1;
 // (frame, tile) = (b % 8) * ceil(total/8) + b / 8 gives every XCD one contiguous run of tiles, so that the halo
 // rows/columns a tile shares with its neighbours are re-read from the same L2 instead of from HBM (PMC: the
 // naive mapping fetched 16.9 B/px for 13.2 B/px of tile+halo reads).  Placement only affects speed.
-template <int STAGES>
-__global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
-                                                     int32_t tiles_x, int32_t tiles_per_frame, uint32_t total_work, ChainK D) {
+template <int STAGES, class IO>
+__global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
+                                                     int32_t H, int32_t W, int32_t tiles_x, int32_t tiles_per_frame, uint32_t total_work,
+                                                     ChainK D) {
     __shared__ float tile[3][HALO_H][LDS_PITCH];
     __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
     if (STAGES & VRG_STAGE_COLORMATCH) {
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
     const int32_t tx0 = (int32_t)(tile_id % (uint32_t)tiles_x) * TILE_W;
     const int64_t f = work / (uint32_t)tiles_per_frame;
     const int32_t ppf = H * W;
-    const px3* fin = in + f * ppf;
+    const typename IO::elem* fin = in + f * ppf;
     const bool zero = D.zero_border != 0;
 
     for (int i = threadIdx.x; i < HALO_H * HALO_W; i += 256) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
             y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
             x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
             const int32_t p = y * W + x;
-            const px3 v = fin[p];          // plain load: halo pixels are re-read by the neighbouring tiles (L2 hits)
+            const px3 v = IO::load(fin + p);   // plain load: halo pixels are re-read by the neighbouring tiles (L2 hits)
             const float xi[3] = {v.r, v.g, v.b};
             chain_pre<STAGES>(D, f, p, xi, o, PT);
         }
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
         tile[2][hy][hx] = o[2];
     }
     __syncthreads();
-    px3* fout = out + f * ppf;
+    typename IO::elem* fout = out + f * ppf;
     for (int i = threadIdx.x; i < TILE_H * TILE_W; i += 256) {
         const int ly = i / TILE_W, lx = i - ly * TILE_W;
         const int y = ty0 + ly, x = tx0 + lx;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const px3* __restrict__ in, 
                 for (int dx = 0; dx < 3; ++dx) p[dy][dx] = tile[c][ly + dy][lx + dx];
             o[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
         }
-        store_px_stream(fout + (y * W + x), px3{o[0], o[1], o[2]});
+        IO::store_stream(fout + (y * W + x), px3{o[0], o[1], o[2]});
     }
 }
 
@@ -255,8 +257,8 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
     return VRG_OK;
 }
 
-template <int STAGES>
-static int launch_chain(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, bool sharpen,
+template <int STAGES, class IO = IoF32>
+static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, bool sharpen,
                         hipStream_t st) {
     const int64_t ppf = (int64_t)H * W;
     const int tx = (W + TILE_W - 1) / TILE_W, ty = (H + TILE_H - 1) / TILE_H;
@@ -286,15 +288,15 @@ static int launch_chain(const float* in, float* out, int64_t frames, int32_t H, 
             if (D.cm.ref_frames != 1 && (f0 % D.cm.ref_frames)) return VRG_ERR_UNSUPPORTED;
             d.cm.img_ms += f0 * 6;
         }
-        const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
-        px3* dst = reinterpret_cast<px3*>(out) + f0 * ppf;
+        const typename IO::elem* src = reinterpret_cast<const typename IO::elem*>(in) + f0 * ppf;
+        typename IO::elem* dst = reinterpret_cast<typename IO::elem*>(out) + f0 * ppf;
         if (sharpen) {
             const uint32_t total = (uint32_t)(tpf * nf);
             const uint32_t blocks = ((total + 7u) / 8u) * 8u;
-            hipLaunchKernelGGL(k_chain_tile<STAGES>, dim3(blocks), dim3(256), 0, st, src, dst, H, W, tx, (int32_t)tpf, total, d);
+            hipLaunchKernelGGL((k_chain_tile<STAGES, IO>), dim3(blocks), dim3(256), 0, st, src, dst, H, W, tx, (int32_t)tpf, total, d);
         } else {
-            hipLaunchKernelGGL(k_chain_pointwise<STAGES>, dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st, src,
-                               dst, (int32_t)ppf, d);
+            hipLaunchKernelGGL((k_chain_pointwise<STAGES, IO>), dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st,
+                               src, dst, (int32_t)ppf, d);
         }
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
     }
@@ -436,6 +438,27 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
     VRG_DISPATCH_PRE(desc->stages, CALL)
 #undef CALL
+}
+
+// uint8 BGR frames in and out (video routes): grain / LUT / 3x3 sharpen in any combination, no colour match (the
+// routes have none; its statistics pass would need the fp32 image anyway).  LDS-tile and point-wise kernels only.
+int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc,
+                       void* stream) {
+    if (!in || !out || !desc || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (desc->stages == 0 || (desc->stages & ~(VRG_STAGE_GRAIN | VRG_STAGE_LUT | VRG_STAGE_SHARPEN))) return VRG_ERR_UNSUPPORTED;
+    if (frames == 0) return VRG_OK;
+    if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
+    ChainK D;
+    const int rc = fill_chain(desc, height, width, D);
+    if (rc) return rc;
+    const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (desc->stages & 3) {
+        case 0: return launch_chain<0, IoU8>(in, out, frames, height, width, D, sharpen, st);
+        case 1: return launch_chain<1, IoU8>(in, out, frames, height, width, D, sharpen, st);
+        case 2: return launch_chain<2, IoU8>(in, out, frames, height, width, D, sharpen, st);
+        default: return launch_chain<3, IoU8>(in, out, frames, height, width, D, sharpen, st);
+    }
 }
 
 }  // extern "C"

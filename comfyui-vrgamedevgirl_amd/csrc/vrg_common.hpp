@@ -31,6 +31,35 @@ __device__ __forceinline__ void store_px_stream(px3* p, const px3& v) {
     __builtin_nontemporal_store(v.b, f + 2);
 }
 
+// Frame element types at the kernel boundary.  IoF32: the reference's fp32 RGB tensors (12 B/px).  IoU8: decoded video
+// frames as cv2 hands them over, uint8 BGR (3 B/px) -- the /255, the *255-clip-truncate and the channel swap of
+// _frames_to_tensor / _tensor_to_frames happen in the load / store of the kernel that does the work, so a route batch
+// moves 3 + 3 B/px through HBM (and over PCIe) instead of 12 + 12.
+struct __attribute__((packed)) bgr8 { uint8_t b, g, r; };
+
+struct IoF32 {
+    typedef px3 elem;
+    static __device__ __forceinline__ px3 load_stream(const elem* p) { return load_px_stream(p); }
+    static __device__ __forceinline__ px3 load(const elem* p) { return *p; }
+    static __device__ __forceinline__ void store_stream(elem* p, const px3& v) { store_px_stream(p, v); }
+    static __device__ __forceinline__ void store(elem* p, const px3& v) { *p = v; }
+};
+struct IoU8 {
+    typedef bgr8 elem;
+    static __device__ __forceinline__ px3 load(const elem* p) {
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(p);
+        return px3{unit_from_u8(q[2]), unit_from_u8(q[1]), unit_from_u8(q[0])};
+    }
+    static __device__ __forceinline__ px3 load_stream(const elem* p) { return load(p); }
+    static __device__ __forceinline__ void store(elem* p, const px3& v) {
+        uint8_t* q = reinterpret_cast<uint8_t*>(p);
+        q[0] = u8_from_unit(v.b);
+        q[1] = u8_from_unit(v.g);
+        q[2] = u8_from_unit(v.r);
+    }
+    static __device__ __forceinline__ void store_stream(elem* p, const px3& v) { store(p, v); }
+};
+
 // Device copy of vrg_noise_desc plus the per-call geometry the noise mapping needs.
 struct NoiseK {
     uint64_t seed0, seed_stride, off0, off_stride;

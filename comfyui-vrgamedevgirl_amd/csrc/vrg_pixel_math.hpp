@@ -75,6 +75,20 @@ VRG_HD float div9(float x) {
 
 
 // ------------------------------------------------------------------------------------------
+// uint8 <-> unit-range fp32 at the video I/O edge:
+// _frames_to_tensor: astype(float32) / 255.0      (VRGDG_LUTVideoTools.py:736-743, StandaloneVideoEnhancer:311-316)
+// _tensor_to_frames: clip(x * 255.0, 0, 255).astype(uint8) -- truncation (LUTVideoTools.py:746-752, Enhancer:319-324)
+// The FMA-form quotient equals v / 255.0f for all 256 inputs (tests/test_host_math.py).  NaN quantises to 0
+// (what the x86 cast in numpy's astype yields).
+// ------------------------------------------------------------------------------------------
+VRG_HD float unit_from_u8(uint8_t v) { return VRG_DIVC((float)v, 255.0f); }
+VRG_HD uint8_t u8_from_unit(float x) {
+    const float y = x * 255.0f;
+    const float c = __builtin_fminf(__builtin_fmaxf(y, 0.0f), 255.0f);     // fmax(NaN, 0) = 0
+    return (uint8_t)(int)c;
+}
+
+// ------------------------------------------------------------------------------------------
 // Philox4x32-10 (rocrand_philox4x32_10.h:270-303)
 // ------------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };

@@ -27,11 +27,11 @@ def _f32(v: float) -> float:
     return float(np.float32(v))
 
 
-def _check_frames(t: torch.Tensor, name="images", channels: Optional[int] = None):
+def _check_frames(t: torch.Tensor, name="images", channels: Optional[int] = None, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or t.ndim != 4:
         raise ValueError(f"{name} must be a [frames, height, width, channels] tensor")
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name} must be float32")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {str(dtype).replace('torch.', '')}")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (ops.* are device-resident; nodes.* move data for you)")
     if channels is not None and t.shape[-1] != channels:
@@ -266,22 +266,52 @@ def adjust_terms(adjust: dict) -> "_hip.AdjustDesc":
 
 def adjust(images: torch.Tensor, terms: "_hip.AdjustDesc", out: torch.Tensor | None = None,
            workspace: torch.Tensor | None = None) -> torch.Tensor:
-    """Run the Adjust kernels on ``[F,H,W,3]`` fp32 frames.  `workspace` (same shape) is used only when clarity
-    and sharpen are both active; it is allocated when not supplied."""
-    x = _check_frames(images)
+    """Run the Adjust kernels on ``[F,H,W,3]`` frames: fp32 R,G,B tensors, or uint8 B,G,R decoded frames (then the
+    result is uint8 B,G,R as well, equal to convert -> adjust -> convert).  `workspace` (fp32, same shape) is used
+    only when clarity and sharpen are both active; it is allocated when not supplied."""
+    u8 = isinstance(images, torch.Tensor) and images.dtype == torch.uint8       # decoded BGR frames (video routes)
+    x = _check_frames(images, dtype=torch.uint8 if u8 else torch.float32)
     if x.shape[-1] != 3:
         raise ValueError("adjust expects 3-channel frames")
-    out = torch.empty_like(x) if out is None else out
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous tensor shaped and typed like the frames on the same device")
     F, H, W, _ = x.shape
     if x.numel() == 0:
         return out
     tmp = None
     if terms.enabled and terms.has_clarity and terms.has_sharpen:
-        tmp = workspace if workspace is not None else torch.empty_like(x)
+        tmp = workspace if workspace is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
         if tmp.shape != x.shape or tmp.dtype != torch.float32 or not tmp.is_contiguous() or tmp.device != x.device:
-            raise ValueError("adjust workspace must match the frames")
-    _hip.check(_hip.lib().vrg_adjust_f32(_hip.ptr(x), _hip.ptr(out), _hip.ptr(tmp) if tmp is not None else None,
-                                        F, H, W, C.byref(terms), _hip.current_stream()), "vrg_adjust_f32")
+            raise ValueError("adjust workspace must be a contiguous float32 tensor shaped like the frames")
+    fn, name = (_hip.lib().vrg_adjust_u8, "vrg_adjust_u8") if u8 else (_hip.lib().vrg_adjust_f32, "vrg_adjust_f32")
+    _hip.check(fn(_hip.ptr(x), _hip.ptr(out), _hip.ptr(tmp) if tmp is not None else None, F, H, W, C.byref(terms),
+                  _hip.current_stream()), name)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# uint8 BGR frames <-> fp32 RGB tensors (video I/O edge)
+# ------------------------------------------------------------------------------------------------
+
+def frames_u8_to_f32(frames_bgr: torch.Tensor) -> torch.Tensor:
+    """``[F,H,W,3]`` uint8 B,G,R on the GPU -> fp32 R,G,B in [0,1] (``/ 255.0``)."""
+    x = _check_frames(frames_bgr, "frames", channels=3, dtype=torch.uint8)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if x.numel():
+        _hip.check(_hip.lib().vrg_u8bgr_to_f32rgb(_hip.ptr(x), _hip.ptr(out), x.numel() // 3, _hip.current_stream()),
+                   "vrg_u8bgr_to_f32rgb")
+    return out
+
+
+def f32_to_frames_u8(images: torch.Tensor) -> torch.Tensor:
+    """fp32 R,G,B -> ``clip(x * 255, 0, 255)`` truncated to uint8, B,G,R order."""
+    x = _check_frames(images, channels=3)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    if x.numel():
+        _hip.check(_hip.lib().vrg_f32rgb_to_u8bgr(_hip.ptr(x), _hip.ptr(out), x.numel() // 3, _hip.current_stream()),
+                   "vrg_f32rgb_to_u8bgr")
     return out
 
 
@@ -453,12 +483,16 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     cache_lab=False pass 2 re-evaluates grain/LUT/Lab from the input instead (36 B/px instead of 48 B/px of HBM
     traffic, but the gathers and powers twice); both forms give bit-identical results.  `lab_workspace` may
     supply the fp32 buffer (same shape as images)."""
-    x = _check_frames(images, channels=3)
+    u8 = isinstance(images, torch.Tensor) and images.dtype == torch.uint8       # decoded BGR frames (video routes)
+    x = _check_frames(images, channels=3, dtype=torch.uint8 if u8 else torch.float32)
+    if u8 and spec.colormatch is not None:
+        raise ValueError("uint8 frames: colour match is not part of the video routes (convert to fp32 first)")
+    esize = 1 if u8 else 4
     F, H, W, _ = x.shape
     if out is None:
         out = torch.empty_like(x)
-    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
-        raise ValueError("out must be a contiguous float32 tensor shaped like images on the same device")
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous tensor shaped and typed like images on the same device")
     if F == 0:
         return out
     fe = H * W * 3
@@ -478,8 +512,8 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         if d.stages == 0:
             out[f0:f0 + nf] = x[f0:f0 + nf]
             continue
-        src = C.c_void_p(x.data_ptr() + f0 * fe * 4)
-        dst = C.c_void_p(out.data_ptr() + f0 * fe * 4)
+        src = C.c_void_p(x.data_ptr() + f0 * fe * esize)
+        dst = C.c_void_p(out.data_ptr() + f0 * fe * esize)
         if d.stages & _hip.STAGE_COLORMATCH:
             if d.ref_frames != 1 and (nf % d.ref_frames or f0 % d.ref_frames):
                 raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
@@ -513,7 +547,10 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         if kernel_events is not None:
             e0, e1 = HipEvent(), HipEvent()
             e0.record()
-        _hip.check(lib.vrg_fused_chain_f32(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_f32")
+        if u8:
+            _hip.check(lib.vrg_fused_chain_u8(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_u8")
+        else:
+            _hip.check(lib.vrg_fused_chain_f32(src, dst, nf, H, W, C.byref(d), st), "vrg_fused_chain_f32")
         if kernel_events is not None:
             e1.record()
             kernel_events.append(("apply", e0, e1, nf))

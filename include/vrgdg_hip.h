@@ -210,6 +210,24 @@ int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int3
                    const vrg_adjust_desc* desc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * uint8 BGR frames at the video I/O edge.
+ * Replaces _frames_to_tensor / _tensor_to_frames (VRGDG_LUTVideoTools.py:736-752,
+ * VRGDG_StandaloneVideoEnhancerNodes.py:311-324): `astype(float32) / 255.0` after the BGR->RGB swap on the way
+ * in, `clip(x * 255.0, 0, 255).astype(uint8)` (truncation) and RGB->BGR on the way out.  In the *_u8 entry points
+ * both conversions happen inside the kernel that does the work, so a route batch (_process_video_batch,
+ * _process_film_grain_batch, _process_adjust_batch, :1365-1386) moves 3 + 3 B/px instead of 12 + 12; results are
+ * identical to convert -> fp32 entry point -> convert.  Frames are [frames][height][width][3] uint8, B,G,R order.
+ * ------------------------------------------------------------------------------------------- */
+int vrg_u8bgr_to_f32rgb(const uint8_t* in, float* out, int64_t pixels, void* stream);
+int vrg_f32rgb_to_u8bgr(const float* in, uint8_t* out, int64_t pixels, void* stream);
+/* grain / LUT / 3x3 sharpen in any combination (no colour match: VRG_ERR_UNSUPPORTED); desc as for vrg_fused_chain_f32 */
+int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width,
+                       const vrg_chain_desc* desc, void* stream);
+/* `tmp`: fp32, frames*height*width*3 floats, needed only when clarity and sharpen are both active */
+int vrg_adjust_u8(const uint8_t* in, uint8_t* out, float* tmp, int64_t frames, int32_t height, int32_t width,
+                  const vrg_adjust_desc* desc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Introspection
  * ------------------------------------------------------------------------------------------- */
 int vrg_abi_version(void);

@@ -111,6 +111,29 @@ def load_iv_adjustments():
     return _CACHE["iv"]
 
 
+class cv2_stub:
+    """``with cv2_stub():`` -- the reference's frame converters import cv2 (absent here) for exactly one thing,
+    ``cv2.cvtColor(frame, COLOR_BGR2RGB / COLOR_RGB2BGR)``, which for 3-channel uint8 frames is the channel
+    reversal by definition.  Everything numeric in them (``astype(float32) / 255.0``, ``clip(x * 255, 0, 255)
+    .astype(uint8)``) is numpy and runs as written."""
+
+    def __enter__(self):
+        import numpy as np
+        self._saved = sys.modules.get("cv2")
+        mod = types.ModuleType("cv2")
+        mod.COLOR_BGR2RGB, mod.COLOR_RGB2BGR = 4, 4
+        mod.cvtColor = lambda frame, code: np.ascontiguousarray(np.asarray(frame)[..., ::-1])
+        sys.modules["cv2"] = mod
+        return mod
+
+    def __exit__(self, *exc):
+        if self._saved is None:
+            sys.modules.pop("cv2", None)
+        else:
+            sys.modules["cv2"] = self._saved
+        return False
+
+
 def _ast_extract(filename: str, names, namespace):
     """Same AST-exec pattern the reference's own tests use
     (tests/test_standalone_video_enhancer.py:20-36)."""
@@ -131,10 +154,12 @@ def load_lut_video_tools():
         _ast_extract(
             "VRGDG_LUTVideoTools.py",
             {"_apply_film_grain_tensor", "_apply_lut_tensor", "_normalize_adjust_settings",
-             "_apply_adjust_tensor"},
+             "_apply_adjust_tensor", "_frames_to_tensor", "_tensor_to_frames", "_process_video_batch",
+             "_process_film_grain_batch", "_process_adjust_batch"},
             ns,
         )
-        _CACHE["lvt"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith("_apply") or k.startswith("_normalize")})
+        _CACHE["lvt"] = types.SimpleNamespace(**{k: v for k, v in ns.items()
+                                                 if k.startswith(("_apply", "_normalize", "_frames", "_tensor", "_process"))})
     return _CACHE["lvt"]
 
 
@@ -148,8 +173,8 @@ def load_standalone_enhancer():
         _ast_extract(
             "VRGDG_StandaloneVideoEnhancerNodes.py",
             {"_auto_batch_size", "_apply_unsharp", "_apply_seeded_grain", "_apply_effects_batch",
-             "_process_with_retry"},
+             "_process_with_retry", "_frames_to_tensor", "_tensor_to_frames"},
             ns,
         )
-        _CACHE["sve"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith("_a") or k.startswith("_p")})
+        _CACHE["sve"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith(("_a", "_p", "_f", "_t"))})
     return _CACHE["sve"]

@@ -486,6 +486,24 @@ def adjust_tensor(image: torch.Tensor, settings=None, ieee_sqrt: bool = False) -
 
 
 # --------------------------------------------------------------------------------------
+# uint8 BGR frames at the codec edge
+# --------------------------------------------------------------------------------------
+
+def frames_to_tensor(frames) -> torch.Tensor:
+    """_frames_to_tensor (VRGDG_LUTVideoTools.py:736-743 == VRGDG_StandaloneVideoEnhancerNodes.py:311-316):
+    BGR->RGB channel reversal (cv2.COLOR_BGR2RGB), stack, ``astype(float32) / 255.0``."""
+    rgb = [np.ascontiguousarray(np.asarray(f)[..., ::-1]) for f in frames]
+    return torch.from_numpy(np.stack(rgb, axis=0).astype(np.float32) / 255.0)
+
+
+def tensor_to_frames(tensor: torch.Tensor):
+    """_tensor_to_frames (:746-752 / :319-324): ``clip(x * 255.0, 0, 255).astype(uint8)`` (C truncation), then
+    RGB->BGR per frame."""
+    array = np.clip(tensor.detach().cpu().numpy() * 255.0, 0, 255).astype(np.uint8)
+    return [np.ascontiguousarray(frame[..., ::-1]) for frame in array]
+
+
+# --------------------------------------------------------------------------------------
 # Sequential composition used by the fused-chain parity tests
 # --------------------------------------------------------------------------------------
 

@@ -203,4 +203,8 @@ void hm_adjust(const float* in, float* out, int F, int H, int W, const float* t)
     delete[] b;
 }
 
+// uint8 codec edge
+void hm_u8_to_unit(const uint8_t* in, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = unit_from_u8(in[i]); }
+void hm_unit_to_u8(const float* in, uint8_t* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = u8_from_unit(in[i]); }
+
 }  // extern "C"

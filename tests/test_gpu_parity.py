@@ -597,3 +597,126 @@ def test_adjust_argument_errors(ops, pkg, dev):
     with pytest.raises(RuntimeError):
         ops.adjust(torch.zeros(1, 4, 4, 3), terms)
     assert ops.adjust(torch.zeros(0, 4, 4, 3, device=dev), terms).shape == (0, 4, 4, 3)
+
+
+# ---------------------------------------------------------------------------------------- uint8 codec edge (8f-3)
+def _frames_eq(got, want, what):
+    got = np.stack([np.asarray(f) for f in got], axis=0) if isinstance(got, list) else np.asarray(got)
+    want = np.stack(want, axis=0) if isinstance(want, list) else np.asarray(want)
+    assert got.dtype == np.uint8 and got.shape == want.shape, (what, got.dtype, got.shape, want.shape)
+    if not np.array_equal(got, want):
+        bad = np.nonzero(got != want)
+        pytest.fail(f"{what}: {bad[0].size}/{got.size} bytes differ, first at {tuple(int(b[0]) for b in bad)}: "
+                    f"got {got[bad][0]} want {want[bad][0]}")
+
+
+class _ListWriter:
+    def __init__(self):
+        self.frames = []
+
+    def write(self, frame):
+        self.frames.append(np.array(frame, copy=True))
+
+
+def test_u8_converters_match_reference_fixtures(pkg, ops, dev):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT, VRGDG_StandaloneVideoEnhancerNodes as SVE
+    z = _npz("io_u8.npz")
+    for mod in (LVT, SVE):
+        for tag in ("rand", "ramp"):
+            t = mod._frames_to_tensor(list(z[f"{tag}.frames"]))
+            assert t.is_cuda and t.dtype == torch.float32
+            assert_bit_equal(t, _t(z[f"{tag}.tensor"]), f"frames_to_tensor {tag}")
+        for tag in ("tens", "edge"):
+            _frames_eq(mod._tensor_to_frames(_t(z[f"{tag}.tensor"])), z[f"{tag}.frames"], f"tensor_to_frames {tag}")
+    # NaN quantises to 0 (numpy's x86 cast), +-Inf saturate; CPU tensors are accepted like GPU ones
+    odd = torch.tensor([float("nan"), float("inf"), -float("inf"), 0.5, 1.0, 2.0]).reshape(1, 1, 2, 3)
+    got = ops.f32_to_frames_u8(odd.to(dev)).cpu().numpy().reshape(-1)
+    assert got.tolist() == [0, 255, 0, 255, 255, 127]          # B,G,R order within each pixel
+    with pytest.raises(ValueError):
+        ops.frames_u8_to_f32(torch.zeros(1, 2, 2, 3, device=dev))
+    with pytest.raises(ValueError):
+        LVT._stack_frames([np.zeros((2, 2, 3), dtype=np.float32)])
+
+
+def test_u8_route_batches_match_reference_fixtures(pkg, dev, monkeypatch):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT, VRGDG_IV_Adjustments as iv
+    z = _npz("io_u8.npz")
+    frames = list(z["rand.frames"])
+    monkeypatch.setattr(iv, "LUTS_DIR", GOLDEN)
+    monkeypatch.setattr(iv.VRGDG_LUTS, "_LUT_CACHE", {})
+    for s in (10.0, 4.5):
+        w = _ListWriter()
+        assert LVT._process_video_batch(frames, w, "synthetic_17.cube", s, "cuda") == 3
+        _frames_eq(w.frames, z[f"batch.lut.s{s}"], f"_process_video_batch {s}")
+    cases = _adjust_meta()["cases"]
+    for name in ("all", "both", "fade_vig", "tone"):
+        w = _ListWriter()
+        assert LVT._process_adjust_batch(frames, w, cases[name], "cuda") == 3
+        want = R.tensor_to_frames(_adjust_want(R.frames_to_tensor(frames), cases[name]))
+        _frames_eq(w.frames, want, f"_process_adjust_batch {name}")
+        diff = np.abs(np.stack(w.frames).astype(np.int16) - z[f"batch.adjust.{name}"].astype(np.int16))
+        assert diff.max() <= 1 and (diff != 0).mean() < 0.01, name       # reference on CPU: torch.sqrt's last ulp
+    # grain: one randn draw for the batch from a generator seeded per call, clamped sliders
+    w = _ListWriter()
+    LVT._process_film_grain_batch(frames, w, 0.2, 0.7, "cuda", seed=123)
+    g = torch.Generator(device=dev).manual_seed(123)
+    x = R.frames_to_tensor(frames)
+    noise = torch.randn(x.shape, generator=g, device=dev).cpu()
+    _frames_eq(w.frames, R.tensor_to_frames(R.grain_apply(x, noise, 0.2, 0.7)), "_process_film_grain_batch")
+
+
+U8_CHAINS = [
+    dict(grain=(0.06, 0.5, 2), lut=10.0, sharpen=("unsharp", 0.8, False)),
+    dict(grain=None, lut=7.5, sharpen=("unsharp", 1.5, True)),
+    dict(grain=(0.1, 1.0, 0), lut=None, sharpen=None),
+    dict(grain=None, lut=10.0, sharpen=None),
+    dict(grain=None, lut=None, sharpen=("laplacian", 0.4, False)),
+    dict(grain=(0.05, 0.3, 1), lut=3.0, sharpen=None),
+    dict(grain=None, lut=0.0, sharpen=None),                 # nothing to do: uint8 copy == convert -> convert
+]
+
+
+@pytest.mark.parametrize("shape", [(4, 45, 70, 3), (2, 64, 129, 3), (3, 1, 5, 3), (2, 270, 480, 3)])
+@pytest.mark.parametrize("case", U8_CHAINS)
+def test_fused_chain_u8_equals_convert_chain_convert(ops, dev, case, shape):
+    data, dlut = _lut_pair(ops, dev)
+    g = torch.Generator().manual_seed(sum(shape))
+    frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    spec = ops.ChainSpec(grain=case["grain"], lut=(dlut, case["lut"]) if case["lut"] is not None else None, sharpen=case["sharpen"],
+                         variant=1)
+    torch.manual_seed(5)
+    got = ops.fused_chain(frames.to(dev), spec)
+    assert got.dtype == torch.uint8 and got.shape == frames.shape
+    torch.manual_seed(5)
+    via_f32 = ops.f32_to_frames_u8(ops.fused_chain(ops.frames_u8_to_f32(frames.to(dev)), spec))
+    _frames_eq(got.cpu().numpy(), via_f32.cpu().numpy(), "u8 chain vs convert -> fp32 chain -> convert")
+    # and against the CPU oracle from the bytes up
+    torch.manual_seed(5)
+    o = R.frames_to_tensor(list(frames.numpy()))
+    if case["grain"]:
+        I, s, bs = case["grain"]
+        o = R.fast_film_grain(o, I, s, bs, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    if case["lut"] is not None:
+        o = R.apply_lut_with_strength(o, data, case["lut"])
+    if case["sharpen"]:
+        name, s, zero = case["sharpen"]
+        o = R.unsharp(o, s, zero).contiguous() if name == "unsharp" else R.laplacian(o, s, False)
+    _frames_eq(got.cpu().numpy(), R.tensor_to_frames(o), "u8 chain vs oracle")
+
+
+@pytest.mark.parametrize("shape,settings", ADJUST_BIG[:5] + ADJUST_BIG[6:])
+def test_adjust_u8_equals_convert_adjust_convert(ops, pkg, dev, shape, settings):
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    terms = ops.adjust_terms(LVT._normalize_adjust_settings(settings))
+    got = ops.adjust(frames.to(dev), terms)
+    assert got.dtype == torch.uint8
+    want = R.tensor_to_frames(_adjust_want(R.frames_to_tensor(list(frames.numpy())), settings))
+    _frames_eq(got.cpu().numpy(), want, f"adjust u8 {shape}")
+
+
+def test_u8_entry_points_reject_colour_match(ops, dev):
+    ref_ms = torch.ones(1, 3, 2, device=dev)
+    with pytest.raises(ValueError):
+        ops.fused_chain(torch.zeros(1, 4, 4, 3, dtype=torch.uint8, device=dev), ops.ChainSpec(colormatch=(ref_ms, 1.0)))

@@ -237,3 +237,25 @@ def test_adjust_vs_oracle_larger_frames(hm, pkg, shape):
         o = np.empty_like(want)
         hm.hm_adjust(np.ascontiguousarray(x.numpy()), o, shape[0], shape[1], shape[2], _adjust_terms_array(ops, LVT, settings))
         assert np.array_equal(o, want), float(np.max(np.abs(o - want)))
+
+
+def test_u8_codec_edge_conversions(hm):
+    """unit_from_u8 == astype(float32) / 255.0 for all 256 codes; u8_from_unit == clip(x * 255, 0, 255).astype(uint8)
+    on the fixture's grid values / neighbours and on 4M random floats; the round trip is the identity."""
+    U8P = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    hm.hm_u8_to_unit.argtypes = [U8P, F32P, C.c_int64]
+    hm.hm_unit_to_u8.argtypes = [F32P, U8P, C.c_int64]
+    codes = np.arange(256, dtype=np.uint8)
+    unit = np.empty(256, dtype=np.float32)
+    hm.hm_u8_to_unit(codes, unit, 256)
+    assert np.array_equal(unit, codes.astype(np.float32) / 255.0)
+    back = np.empty(256, dtype=np.uint8)
+    hm.hm_unit_to_u8(unit, back, 256)
+    assert np.array_equal(back, codes)
+    z = np.load(os.path.join(GOLDEN, "io_u8.npz"))
+    rng = np.random.default_rng(5)
+    for x in (np.ascontiguousarray(z["edge.tensor"]).ravel(), np.ascontiguousarray(z["tens.tensor"]).ravel(),
+              (rng.random(1 << 22, dtype=np.float32) * 1.5 - 0.25), np.array([-0.0, 0.0, 1.0, 2.0, -3.0, 1e-45, 0.99999994], dtype=np.float32)):
+        got = np.empty(x.size, dtype=np.uint8)
+        hm.hm_unit_to_u8(x, got, x.size)
+        assert np.array_equal(got, np.clip(x * np.float32(255.0), 0, 255).astype(np.uint8))

@@ -176,3 +176,22 @@ def test_adjust_normalization_against_reference_fixture():
     for name, settings in _adjust_cases()["cases"].items():
         assert R.normalize_adjust_settings(settings) == want[name], name
     assert R.normalize_adjust_settings("nope") == want["not_a_dict"]
+
+
+# ------------------------------------------------------------------ uint8 codec edge (section 8f rank 3)
+
+def test_u8_codec_edge_restatement_against_reference_fixtures():
+    z = _npz("io_u8.npz")
+    for tag in ("rand", "ramp"):
+        assert np.array_equal(R.frames_to_tensor(list(z[f"{tag}.frames"])).numpy(), z[f"{tag}.tensor"]), tag
+    for tag in ("tens", "edge"):
+        assert np.array_equal(np.stack(R.tensor_to_frames(_t(z[f"{tag}.tensor"])), axis=0), z[f"{tag}.frames"]), tag
+    frames = list(z["rand.frames"])
+    lut = R.parse_cube_file(os.path.join(GOLDEN, "synthetic_17.cube"))
+    for s in (10.0, 4.5):
+        out = R.apply_lut_with_strength(R.frames_to_tensor(frames), lut, s)
+        assert np.array_equal(np.stack(R.tensor_to_frames(out), axis=0), z[f"batch.lut.s{s}"]), s
+    cases = _adjust_cases()["cases"]
+    for name in ("all", "both", "fade_vig", "tone"):
+        out = R.adjust_tensor(R.frames_to_tensor(frames), cases[name])
+        assert np.array_equal(np.stack(R.tensor_to_frames(out), axis=0), z[f"batch.adjust.{name}"]), name

@@ -159,6 +159,20 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             ("adjust sharpen", 24, adj({"sharpen": 40, "contrast": 12})),
             ("adjust clarity+sharpen", 48, adj({"clarity": 40, "sharpen": 30, "contrast": 12, "vignette": 30})),
         ]
+        xu8 = torch.randint(0, 256, x.shape, dtype=torch.uint8, device=dev)
+        outu8 = torch.empty_like(xu8)
+        adj_pt = ops.adjust_terms(LVT._normalize_adjust_settings({"temperature": 20, "exposure": 10, "contrast": 12, "saturation": 8,
+                                                                   "highlights": -20, "shadows": 15, "fade": 10, "vignette": 30}))
+        cases += [
+            ("u8 -> f32 convert", 15, lambda: ops.frames_u8_to_f32(xu8)),
+            ("f32 -> u8 convert", 15, lambda: ops.f32_to_frames_u8(x)),
+            ("u8 lut33", 6, lambda: ops.fused_chain(xu8, ops.ChainSpec(lut=(lut33, 10.0)), out=outu8)),
+            ("u8 grain", 6, lambda: ops.fused_chain(xu8, ops.ChainSpec(grain=(0.04, 0.5, 4)), generator=gen, out=outu8)),
+            ("u8 grain+lut+sharpen", 6, lambda: ops.fused_chain(xu8, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0),
+                                                                 sharpen=("unsharp", 0.5, False)), generator=gen, out=outu8)),
+            ("u8 unsharp", 6, lambda: ops.fused_chain(xu8, ops.ChainSpec(sharpen=("unsharp", 0.5, False)), out=outu8)),
+            ("u8 adjust point+tail", 6, lambda: ops.adjust(xu8, adj_pt, out=outu8)),
+        ]
         if label == "4K":
             import ctypes as C
             from comfyui_vrgamedevgirl_amd import _hip
