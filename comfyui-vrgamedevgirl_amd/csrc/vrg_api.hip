@@ -78,7 +78,84 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ i
 
 }  // namespace vrg
 
+namespace vrg {
+
+// Issue-rate probe: every lane runs `iters` passes over 64 independent-enough instructions of one kind (8 chains x 8),
+// nothing else in the loop but the counter.  The measured lane-instructions per second are the VALU roofline the fused
+// chains are priced against in DESIGN.md (they are issue bound, not HBM bound).
+#define VRG_REP8(X) X X X X X X X X
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, int32_t iters) {
+    float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f,
+          a7 = a0 + 7.0f;
+    const float b = 0.999f, c = 1e-3f;
+    uint32_t u0 = threadIdx.x + 1, u1 = u0 * 3, u2 = u0 * 5, u3 = u0 * 7, u4 = u0 * 11, u5 = u0 * 13, u6 = u0 * 17, u7 = u0 * 19;
+    uint64_t w0 = u0, w1 = u1, w2 = u2, w3 = u3, w4 = u4, w5 = u5, w6 = u6, w7 = u7;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const f2 pb = {b, b}, pc = {c, c};
+    const uint32_t k = 0xD2511F53u;
+    for (int32_t i = 0; i < iters; ++i) {
+        if (MODE == 0) {
+            VRG_REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                                  "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (MODE == 1) {
+            VRG_REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %10, %1\n v_mad_u64_u32 %2, vcc, %8, %11, %2\n"
+                                  "v_mad_u64_u32 %3, vcc, %8, %12, %3\n v_mad_u64_u32 %4, vcc, %8, %13, %4\n v_mad_u64_u32 %5, vcc, %8, %14, %5\n"
+                                  "v_mad_u64_u32 %6, vcc, %8, %15, %6\n v_mad_u64_u32 %7, vcc, %8, %16, %7"
+                                  : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(w4), "+v"(w5), "+v"(w6), "+v"(w7)
+                                  : "v"(k), "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(u4), "v"(u5), "v"(u6), "v"(u7) : "vcc");)
+        } else if (MODE == 2) {
+            VRG_REP8(asm volatile("v_log_f32 %0, %0\n v_log_f32 %1, %1\n v_log_f32 %2, %2\n v_log_f32 %3, %3\n"
+                                  "v_log_f32 %4, %4\n v_log_f32 %5, %5\n v_log_f32 %6, %6\n v_log_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 3) {
+            VRG_REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                                  "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 4) {
+            VRG_REP8(asm volatile("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+                                  "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k));)
+        } else if (MODE == 5) {
+            VRG_REP8(asm volatile("v_sqrt_f32 %0, %0\n v_sin_f32 %1, %1\n v_cos_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                                  "v_sqrt_f32 %4, %4\n v_sin_f32 %5, %5\n v_cos_f32 %6, %6\n v_rcp_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 6) {
+            VRG_REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n"
+                                  "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
+        } else {
+            VRG_REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                                  "v_fma_f64 %0, %0, %4, %0\n v_fma_f64 %1, %1, %4, %1\n v_fma_f64 %2, %2, %4, %2\n v_fma_f64 %3, %3, %4, %3"
+                                  : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(w4));)
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) +
+                                          (float)(w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7) + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
+}
+
+}  // namespace vrg
+
 extern "C" {
+
+int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream) {
+    if (!out || blocks <= 0 || iters <= 0 || mode < 0 || mode > 7) return VRG_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 1: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 2: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 3: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 4: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 5: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<5>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        case 6: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<6>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        default: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<7>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    }
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
     if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 3) return VRG_ERR_BAD_ARG;

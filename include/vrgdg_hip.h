@@ -246,6 +246,10 @@ int vrg_selftest_lanes(float* out128, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 128-B record stride. */
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
+/* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
+ * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,
+ * 6 v_cmp+v_cndmask pairs, 7 v_mul_f64/v_fma_f64); `out` = blocks*256 floats.  Measures the VALU roofline. */
+int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

@@ -85,6 +85,29 @@ def time_it(fn, iters, ops):
     return ts[len(ts) // 2], ts[0]
 
 
+@section("valu_rate")
+def valu_rate(ops):
+    """Issue-rate probe: lane-instructions per second for a few instruction kinds (the VALU roofline)."""
+    from comfyui_vrgamedevgirl_amd import _hip
+    dev = torch.device("cuda", 0)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    names = ["v_fma_f32", "v_mad_u64_u32", "v_log_f32", "v_pk_fma_f32", "v_xor_b32", "sqrt/sin/cos/rcp", "v_cmp+v_cndmask", "v_mul/fma_f64"]
+    rows = []
+    for waves_per_simd in (8, 2):
+        blocks = cus * waves_per_simd           # 4 waves per block -> waves_per_simd waves on each of the 4 SIMDs of every CU
+        out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+        iters = 4096 // waves_per_simd
+        for mode, name in enumerate(names):
+            fn = lambda m=mode: _hip.check(_hip.lib().vrg_debug_valu_rate(_hip.ptr(out), blocks, iters, m, _hip.current_stream()), "valu")
+            med, best = time_it(fn, 3, ops)
+            lane_instr = blocks * 256 * iters * 64
+            row = {"instr": name, "waves_per_simd": waves_per_simd, "ms": round(best, 4), "tera_lane_instr_s": round(lane_instr / best / 1e9, 2),
+                   "cycles_per_wave_instr_at_2p4GHz": round(best * 1e-3 * 2.4e9 / (iters * 64 * waves_per_simd), 2)}
+            rows.append(row)
+            print("[diag]", row, flush=True)
+    return rows
+
+
 @section("kernels")
 def kernel_bench(ops, frames_4k, iters, match=""):
     from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
@@ -204,6 +227,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=16, help="4K frames per timing batch (1080p uses 4x)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--valu", action="store_true", help="also run the VALU issue-rate probe")
     ap.add_argument("--match", default="", help="only time kernels whose label contains this")
     ap.add_argument("--out", default=os.path.join(OUT_DIR, "diag.json"))
     args = ap.parse_args()
@@ -212,6 +236,8 @@ def main():
     from comfyui_vrgamedevgirl_amd import ops
     device_info()
     noise_check(ops)
+    if args.valu:
+        valu_rate(ops)
     kernel_bench(ops, args.frames, args.iters, args.match)
     with open(args.out, "w") as fh:
         json.dump(RESULT, fh, indent=1)

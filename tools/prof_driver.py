@@ -41,6 +41,25 @@ if which == "traffic":
     torch.cuda.synchronize()
     print("done traffic")
     sys.exit(0)
+if which == "issue":
+    # calibration (known instruction count) + the kernels whose VALU instruction counts DESIGN.md quotes
+    from comfyui_vrgamedevgirl_amd import _hip, VRGDG_LUTVideoTools as LVT
+    probe = torch.empty(2048 * 256, dtype=torch.float32, device=dev)
+    _hip.check(_hip.lib().vrg_debug_valu_rate(_hip.ptr(probe), 2048, 512, 0, _hip.current_stream()), "valu")   # 2048*4 waves * 512*64 v_fma
+    lab_ws = torch.empty_like(x)
+    ops.fused_chain(x, specs["chain4"], generator=gen, out=out, lab_workspace=lab_ws)
+    ops.fused_chain(x, specs["chain3"], generator=gen, out=out)
+    ops.fused_chain(x, specs["grainsharp"], generator=gen, out=out)
+    ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen)
+    ops.lut3d(x, lut, 10.0)
+    ops.stencil3x3(x, "unsharp", 0.5, False)
+    ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 40, "contrast": 12})), out=out)
+    ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"sharpen": 40, "contrast": 12})), out=out)
+    ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"temperature": 20, "exposure": 10, "contrast": 12, "saturation": 8,
+                                                                   "highlights": -20, "shadows": 15, "fade": 10, "vignette": 30})), out=out)
+    torch.cuda.synchronize()
+    print("done issue")
+    sys.exit(0)
 for _ in range(3):
     if which == "lut":
         ops.lut3d(x, lut, 10.0)
