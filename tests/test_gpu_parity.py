@@ -720,3 +720,42 @@ def test_u8_entry_points_reject_colour_match(ops, dev):
     ref_ms = torch.ones(1, 3, 2, device=dev)
     with pytest.raises(ValueError):
         ops.fused_chain(torch.zeros(1, 4, 4, 3, dtype=torch.uint8, device=dev), ops.ChainSpec(colormatch=(ref_ms, 1.0)))
+
+
+def test_full_size_4k_properties_adjust_and_u8(ops, pkg, dev):
+    """Size-independent properties of the widened rows at 4K (the CPU oracle needs minutes per frame here)."""
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    data, dlut = _lut_pair(ops, dev)
+    H, W = 2160, 3840
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.rand((2, H, W, 3), generator=g, device=dev) * 1.1 - 0.05
+    # (1) point stage + vignette commute with flips: torch.linspace is evaluated symmetrically from both ends
+    t_pt = ops.adjust_terms(LVT._normalize_adjust_settings({"temperature": 15, "exposure": -20, "contrast": 30, "saturation": 12,
+                                                              "highlights": 25, "blacks": -18, "fade": 12, "vignette": 70}))
+    a = ops.adjust(x, t_pt)
+    assert torch.equal(ops.adjust(x.flip(1).contiguous(), t_pt), a.flip(1))
+    assert torch.equal(ops.adjust(x.flip(2).contiguous(), t_pt), a.flip(2))
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    # (2) disabled == clamp; frames are independent units
+    off = ops.adjust_terms(LVT._normalize_adjust_settings({"enabled": False, "clarity": 50}))
+    assert torch.equal(ops.adjust(x, off), x.clamp(0, 1))
+    t_all = ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 45, "sharpen": 30, "vignette": 20, "contrast": 10}))
+    both = ops.adjust(x, t_all)
+    assert torch.equal(ops.adjust(x[1:2], t_all), both[1:2])
+    # (3) a slab of the 4K frame against the CPU oracle: clarity + sharpen need 5 rows of context, vignette the frame size
+    #     -> oracle on the top 24 rows with the kernels' own geometry is not separable; check the no-vignette form instead
+    t_cs = ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 45, "sharpen": 30, "contrast": 10}))
+    got = ops.adjust(x[:1], t_cs)
+    slab = x[:1, :40].cpu()
+    want = R.adjust_tensor(slab, {"clarity": 45, "sharpen": 30, "contrast": 10})
+    assert torch.equal(got[0, :30].cpu(), want[0, :30])            # rows whose 9x9 + 3x3 windows lie inside the slab
+    # (4) uint8 edge at full size: round trip is the identity, fused uint8 chain == convert -> fp32 chain -> convert
+    u8 = torch.randint(0, 256, (2, H, W, 3), dtype=torch.uint8, device=dev)
+    assert torch.equal(ops.f32_to_frames_u8(ops.frames_u8_to_f32(u8)), u8)
+    spec = ops.ChainSpec(grain=(0.05, 0.5, 1), lut=(dlut, 8.0), sharpen=("unsharp", 0.6, False), variant=1)
+    torch.manual_seed(3)
+    direct = ops.fused_chain(u8, spec)
+    torch.manual_seed(3)
+    via = ops.f32_to_frames_u8(ops.fused_chain(ops.frames_u8_to_f32(u8), spec))
+    assert torch.equal(direct, via)
+    assert torch.equal(ops.adjust(u8, t_all), ops.f32_to_frames_u8(ops.adjust(ops.frames_u8_to_f32(u8), t_all)))
