@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import cube, ops
-from ._devices import compute_device
+from ._devices import compute_device, stream_frames
 
 LUTS_DIR = os.path.join(os.path.dirname(__file__), "LUTS")
 SUPPORTED_LUT_EXTENSIONS = cube.SUPPORTED_LUT_EXTENSIONS
@@ -32,8 +32,11 @@ def _strength_widget():
 def _graded(image, lut_data, requested_device, strength):
     """Shared tail of both nodes: resolve device, run the kernel, hand the result back on image.device."""
     target = VRGDG_LUTS._resolve_device(requested_device, image)
-    working = image.to(device=target)
     dev_lut = ops.upload_lut(lut_data, target)
+    if image.device.type == "cpu" and image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0:
+        # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames)
+        return stream_frames(image, lambda frames, _first: ops.lut3d(frames, dev_lut, strength))
+    working = image.to(device=target)
     return ops.lut3d(working, dev_lut, strength).to(device=image.device)
 
 

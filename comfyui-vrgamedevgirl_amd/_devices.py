@@ -4,8 +4,13 @@ from __future__ import annotations
 
 import torch
 
-#: upper bound of one host->device staging transfer (bytes of fp32 frames)
+import threading
+
+#: upper bound of one host->device staging transfer (bytes of fp32 frames) -- sequential fallback path
 STAGE_BYTES = 1 << 30
+#: target size of one pipelined piece (bytes of frames) and the number of pieces in flight
+PIPE_BYTES = 256 << 20
+PIPE_DEPTH = 3
 
 
 def compute_device() -> torch.device:
@@ -42,3 +47,113 @@ def frame_groups(n_frames: int, frame_bytes: int, multiple_of: int = 1):
     per = max(multiple_of, (per // multiple_of) * multiple_of)
     for s in range(0, n_frames, per):
         yield s, min(n_frames, s + per)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Host-fed batches (what ComfyUI hands a node: CPU tensors in, CPU tensors out).  The kernels need ~0.1 ms per 4K
+# frame; a PCIe crossing of that frame needs ~2 ms each way at the 56 GB/s measured on the bench box.  Measured
+# (tools/gpu_diag.py --host): the DMA itself is not the problem -- a plain ``.to("cpu")`` spends 8x the DMA time
+# page-faulting the fresh pageable result tensor.  So:
+#   * the result is allocated page-locked (torch's caching host allocator: ~0.07 s per GiB the first time, free on
+#     reuse) and the device->host DMA writes straight into it;
+#   * the batch is cut into pieces and three HIP streams run concurrently: host->device DMA of piece i+1, kernels of
+#     piece i (torch's current stream), device->host DMA of piece i-1.
+# Results are identical to processing the batch at once: pieces are whole multiples of the noise chunk / reference
+# batch, and the generator bookkeeping happens on the host in submission order.
+# ------------------------------------------------------------------------------------------------------------
+
+#: results larger than this stay pageable (page-locked memory is not swappable) and are staged through a ring
+PIN_LIMIT_BYTES = 24 << 30
+
+
+class _Staging:
+    """Per-device side streams and (for results above PIN_LIMIT_BYTES) page-locked ring buffers; module-level cache
+    guarded by a lock because nodes and routes may enter from different host threads."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.buffers = {}      # (direction, slot) -> pinned uint8 tensor
+        self.streams = {}      # device index -> (h2d, d2h)
+
+    def pinned(self, slot, nbytes: int) -> torch.Tensor:
+        buf = self.buffers.get(slot)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, pin_memory=True)
+            self.buffers[slot] = buf
+        return buf
+
+    def side_streams(self, dev: torch.device):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if idx not in self.streams:
+            self.streams[idx] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self.streams[idx]
+
+
+_STAGING = _Staging()
+
+
+def piece_frames(n_frames: int, frame_bytes: int, multiple_of: int = 1) -> int:
+    per = max(1, PIPE_BYTES // max(frame_bytes, 1))
+    per = max(multiple_of, (per // multiple_of) * multiple_of)
+    return min(per, max(n_frames, 1))
+
+
+def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None) -> torch.Tensor:
+    """Run ``fn(gpu_frames, first_frame) -> gpu_frames`` over a CPU-resident batch with copies and kernels overlapped.
+    Returns a CPU tensor shaped like `images` (dtype `out_dtype`, default the input's), page-locked when it fits
+    PIN_LIMIT_BYTES."""
+    dev = compute_device()
+    images = images.contiguous()
+    F = int(images.shape[0])
+    out_dtype = out_dtype or images.dtype
+    if F == 0 or images[0].numel() == 0:
+        return torch.empty(images.shape, dtype=out_dtype)
+    out_fb = images[0].numel() * torch.empty((), dtype=out_dtype).element_size()
+    in_fb = images[0].numel() * images.element_size()
+    pin_out = F * out_fb <= PIN_LIMIT_BYTES
+    out = torch.empty(images.shape, dtype=out_dtype, pin_memory=pin_out)
+    per = piece_frames(F, max(in_fb, out_fb), multiple_of)
+    pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
+    compute = torch.cuda.current_stream(dev)
+    with _STAGING.lock:
+        h2d, d2h = _STAGING.side_streams(dev)
+        depth = min(PIPE_DEPTH, len(pieces))
+        ring = None if pin_out else [_STAGING.pinned(("out", k), per * out_fb) for k in range(depth)]
+        pending = []                    # (slot, s, e, d2h_done_event, keep_alive)
+
+        def retire(entry):
+            k, s, e, done, _keep = entry
+            done.synchronize()
+            if ring is not None:
+                out[s:e].copy_(ring[k][:(e - s) * out_fb].view(out_dtype).view(out[s:e].shape))
+
+        for i, (s, e) in enumerate(pieces):
+            k = i % depth
+            if len(pending) == depth:           # bounds the device memory in flight; frees ring slot k
+                retire(pending.pop(0))
+            with torch.cuda.stream(h2d):
+                # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
+                # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
+                # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
+                # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
+                # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
+                # than the copy.
+                gpu_in = images[s:e].to(dev, non_blocking=True)
+                up = torch.cuda.Event()
+                up.record(h2d)
+            compute.wait_event(up)
+            gpu_out = fn(gpu_in, s)                                 # kernels on the caller's current stream
+            if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
+                gpu_out = gpu_out.to(out_dtype).contiguous()
+            ran = torch.cuda.Event()
+            ran.record(compute)
+            dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
+            with torch.cuda.stream(d2h):
+                d2h.wait_event(ran)
+                dst.copy_(gpu_out, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(d2h)
+            pending.append((k, s, e, done, (gpu_in, gpu_out)))      # tensors stay referenced until their DMA retired
+        while pending:
+            retire(pending.pop(0))
+    return out

@@ -11,7 +11,7 @@ from typing import Tuple
 import torch
 
 from . import ops
-from ._devices import compute_device, frame_groups, intermediate_device
+from ._devices import compute_device, frame_groups, intermediate_device, stream_frames
 
 _IMAGE = ("IMAGE",)
 
@@ -24,6 +24,10 @@ def _frames_bytes(images: torch.Tensor) -> int:
     return int(images[0].numel()) * 4 if images.shape[0] else 0
 
 
+#: False selects the plain sequential upload / run / download per group (kept for A/B measurements)
+PIPELINED = True
+
+
 def _run_grouped(images, fn, multiple_of=1):
     """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame)` returns GPU frames."""
     dev = compute_device()
@@ -32,6 +36,9 @@ def _run_grouped(images, fn, multiple_of=1):
         return fn(images.to(dev), 0).to(out_dev)
     if images.dtype != torch.float32:
         images = images.float()
+    if PIPELINED and out_dev.type == "cpu" and images.shape[0] > 0:
+        # CPU in, CPU out (ComfyUI's default): H2D, kernels and D2H overlapped on three streams
+        return stream_frames(images, fn, multiple_of)
     pieces = []
     for s, e in frame_groups(images.shape[0], _frames_bytes(images), multiple_of):
         pieces.append(fn(images[s:e].to(dev), s).to(out_dev))

@@ -759,3 +759,45 @@ def test_full_size_4k_properties_adjust_and_u8(ops, pkg, dev):
     via = ops.f32_to_frames_u8(ops.fused_chain(ops.frames_u8_to_f32(u8), spec))
     assert torch.equal(direct, via)
     assert torch.equal(ops.adjust(u8, t_all), ops.f32_to_frames_u8(ops.adjust(ops.frames_u8_to_f32(u8), t_all)))
+
+
+# ---------------------------------------------------------------------------------------- host-fed pipeline
+def test_pipelined_host_staging_equals_sequential(pkg, dev, monkeypatch):
+    """CPU tensors in / out: the three-stream pipeline (pieces of a few frames, page-locked result) returns exactly
+    what the plain upload -> run -> download path returns, including the generator bookkeeping across pieces."""
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+    x = _rand((11, 48, 80, 3), 123)
+    ref = _rand((1, 20, 30, 3), 124)
+    frame_bytes = x[0].numel() * 4
+    calls = {
+        "grain bs=2": lambda: nodes.FastFilmGrain().apply_grain(x, 0.05, 0.5, 2)[0],
+        "grain bs=0": lambda: nodes.FastFilmGrain().apply_grain(x, 0.05, 0.5, 0)[0],
+        "unsharp": lambda: nodes.FastUnsharpSharpen().apply_unsharp(x, 0.7, False)[0],
+        "colour match": lambda: nodes.ColorMatchToReference().match_color(x, ref, 0.8, 3)[0],
+        "lut": lambda: iv.VRGDG_LUTS().apply_lut(x, "AMD_WarmFilm_25.cube", "auto", 7.0)[0],
+    }
+    for pipe_bytes in (frame_bytes * 3, frame_bytes // 2, 1 << 40):       # 3-frame pieces, 1-frame pieces, one piece
+        monkeypatch.setattr(_devices, "PIPE_BYTES", pipe_bytes)
+        for name, fn in calls.items():
+            monkeypatch.setattr(nodes, "PIPELINED", True)
+            torch.manual_seed(31)
+            a = fn()
+            after_a = torch.cuda.get_rng_state(dev)
+            assert a.device.type == "cpu" and a.dtype == torch.float32 and a.shape == x.shape
+            if name != "lut":
+                monkeypatch.setattr(nodes, "PIPELINED", False)
+                torch.manual_seed(31)
+                b = fn()
+                assert torch.equal(torch.cuda.get_rng_state(dev), after_a), name
+            else:
+                data = R.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_WarmFilm_25.cube"))
+                b = R.apply_lut_with_strength(x, data, 7.0)
+            assert torch.equal(a, b), (name, pipe_bytes)
+    # results above the page-lock limit are staged through the ring instead
+    monkeypatch.setattr(_devices, "PIN_LIMIT_BYTES", 0)
+    monkeypatch.setattr(_devices, "PIPE_BYTES", frame_bytes * 2)
+    monkeypatch.setattr(nodes, "PIPELINED", True)
+    a = calls["unsharp"]()
+    assert not a.is_pinned()
+    monkeypatch.setattr(nodes, "PIPELINED", False)
+    assert torch.equal(a, calls["unsharp"]())

@@ -108,6 +108,87 @@ def valu_rate(ops):
     return rows
 
 
+@section("host_fed")
+def host_fed(ops):
+    """ComfyUI-realistic rates: CPU tensors in, CPU tensors out (PCIe inclusive), sequential vs pipelined staging."""
+    import time as _t
+    import numpy as np
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_LUTVideoTools as LVT, VRGDG_IV_Adjustments as iv
+    dev = torch.device("cuda", 0)
+    rows = []
+    F, H, W = 16, 2160, 3840
+    x = torch.rand(F, H, W, 3)
+    px = F * H * W
+    nbytes = x.numel() * 4
+
+    def wall(fn, reps=3):
+        r = fn(); torch.cuda.synchronize(); del r
+        best = 1e9
+        for _ in range(reps):
+            t0 = _t.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, _t.perf_counter() - t0); del r
+        return best
+
+    pinned = torch.empty_like(x, pin_memory=True)
+    g = torch.empty_like(x, device=dev)
+    t0 = _t.perf_counter(); big = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True); t_pin = _t.perf_counter() - t0
+    del big
+    raw = {
+        "pageable H2D GB/s": nbytes / wall(lambda: g.copy_(x)) / 1e9,
+        "pinned H2D GB/s": nbytes / wall(lambda: g.copy_(pinned, non_blocking=True)) / 1e9,
+        "pageable D2H GB/s": nbytes / wall(lambda: x.copy_(g)) / 1e9,
+        "pinned D2H GB/s": nbytes / wall(lambda: pinned.copy_(g, non_blocking=True)) / 1e9,
+        "host copy_ pageable->pinned GB/s": nbytes / wall(lambda: pinned.copy_(x)) / 1e9,
+        "pin 1 GiB seconds": t_pin, "torch threads": torch.get_num_threads(),
+    }
+    print("[diag] host raw", {k: round(v, 2) for k, v in raw.items()}, flush=True)
+    rows.append({"raw": {k: round(v, 3) for k, v in raw.items()}})
+    del pinned, g
+    lut_name = "AMD_TealOrange_33.cube"
+    cases = [
+        ("FastUnsharpSharpen", lambda: nodes.FastUnsharpSharpen().apply_unsharp(x, 0.5, False)),
+        ("FastFilmGrain bs=4", lambda: nodes.FastFilmGrain().apply_grain(x, 0.04, 0.5, 4)),
+        ("ColorMatchToReference", lambda: nodes.ColorMatchToReference().match_color(x, x[:1], 1.0, 1)),
+    ]
+    torch.cuda.synchronize()
+    nodes.PIPELINED = True
+    t0 = _t.perf_counter(); r = cases[0][1](); torch.cuda.synchronize(); t_first = _t.perf_counter() - t0; del r
+    row = {"node": "FastUnsharpSharpen FIRST call (page-locks the result)", "seconds": round(t_first, 4), "mpix_s": round(px / t_first / 1e6, 1)}
+    rows.append(row)
+    print("[diag]", row, flush=True)
+    for name, fn in cases:
+        for mode in (False, True):
+            nodes.PIPELINED = mode
+            t = wall(fn, reps=2)
+            row = {"node": name, "pipelined": mode, "frames": F, "seconds": round(t, 4), "mpix_s": round(px / t / 1e6, 1),
+                   "pcie_gbs_each_way": round(nbytes / t / 1e9, 2)}
+            rows.append(row)
+            print("[diag]", row, flush=True)
+    nodes.PIPELINED = True
+    xp = x.pin_memory()
+    t = wall(lambda: nodes.FastUnsharpSharpen().apply_unsharp(xp, 0.5, False), reps=3)
+    row = {"node": "FastUnsharpSharpen, page-locked input (e.g. result of a previous node)", "seconds": round(t, 4), "mpix_s": round(px / t / 1e6, 1),
+           "pcie_gbs_each_way": round(nbytes / t / 1e9, 2)}
+    rows.append(row)
+    print("[diag]", row, flush=True)
+    del xp
+    # uint8 route batches: 8 decoded 4K frames per call, as the routes do
+
+    class Sink:
+        def write(self, frame):
+            pass
+
+    batch = [np.random.randint(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(8)]
+    t = wall(lambda: LVT._process_video_batch(batch, Sink(), lut_name, 10.0, "cuda"), reps=3)
+    row = {"route": "_process_video_batch (uint8 in/out, 8 x 4K)", "seconds": round(t, 4), "mpix_s": round(8 * H * W / t / 1e6, 1)}
+    rows.append(row)
+    print("[diag]", row, flush=True)
+    t = wall(lambda: LVT._tensor_to_frames(LVT._apply_lut_tensor(LVT._frames_to_tensor(batch), lut_name, 10.0, "cuda")), reps=3)
+    row = {"route": "convert -> _apply_lut_tensor -> convert (8 x 4K)", "seconds": round(t, 4), "mpix_s": round(8 * H * W / t / 1e6, 1)}
+    rows.append(row)
+    print("[diag]", row, flush=True)
+    return rows
+
+
 @section("kernels")
 def kernel_bench(ops, frames_4k, iters, match=""):
     from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
@@ -227,6 +308,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=16, help="4K frames per timing batch (1080p uses 4x)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--host", action="store_true", help="also measure host-fed (PCIe inclusive) node calls")
     ap.add_argument("--valu", action="store_true", help="also run the VALU issue-rate probe")
     ap.add_argument("--match", default="", help="only time kernels whose label contains this")
     ap.add_argument("--out", default=os.path.join(OUT_DIR, "diag.json"))
@@ -238,6 +320,8 @@ def main():
     noise_check(ops)
     if args.valu:
         valu_rate(ops)
+    if args.host:
+        host_fed(ops)
     kernel_bench(ops, args.frames, args.iters, args.match)
     with open(args.out, "w") as fh:
         json.dump(RESULT, fh, indent=1)
