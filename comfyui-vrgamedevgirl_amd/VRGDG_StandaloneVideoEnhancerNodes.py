@@ -24,7 +24,9 @@ def _apply_seeded_grain(images, intensity, saturation_mix, seed, frame_start):
 
 
 def _apply_effects_batch(images, settings, frame_start=0):
-    """sharpen (optional) then seeded grain (optional); returns a CPU tensor like the reference."""
+    """sharpen (optional) then seeded grain (optional).  A CPU tensor comes back as a CPU tensor like in the
+    reference; a GPU tensor (what this module's _frames_to_tensor produces) stays on the GPU so that the enhancer loop
+    decode -> _frames_to_tensor -> _process_with_retry -> _tensor_to_frames crosses PCIe once each way, in uint8."""
     use_gpu_flag = bool(settings.get("use_gpu", True))
     batch = images if images.is_cuda else images.to(compute_device())
     batch = batch.to(torch.float32)
@@ -33,7 +35,7 @@ def _apply_effects_batch(images, settings, frame_start=0):
     if settings.get("grain_enabled", False):
         batch = _apply_seeded_grain(batch, float(settings.get("grain_intensity", 0.04)),
                                     float(settings.get("saturation_mix", 0.5)), int(settings.get("seed", 42)), int(frame_start))
-    return batch.detach().cpu()
+    return batch.detach() if images.is_cuda else batch.detach().cpu()
 
 
 def _process_with_retry(images, settings, frame_start):

@@ -801,3 +801,26 @@ def test_pipelined_host_staging_equals_sequential(pkg, dev, monkeypatch):
     assert not a.is_pinned()
     monkeypatch.setattr(nodes, "PIPELINED", False)
     assert torch.equal(a, calls["unsharp"]())
+
+
+def test_enhancer_loop_stays_on_gpu_between_uint8_edges(pkg, dev):
+    """decode -> _frames_to_tensor -> _process_with_retry -> _tensor_to_frames (VRGDG_StandaloneVideoEnhancerNodes.py:405-420
+    of the reference): frames cross PCIe as uint8, the fp32 tensor never leaves the GPU, result == oracle from the bytes up."""
+    from comfyui_vrgamedevgirl_amd import VRGDG_StandaloneVideoEnhancerNodes as enh
+    g = torch.Generator().manual_seed(77)
+    frames = list(torch.randint(0, 256, (5, 36, 50, 3), generator=g, dtype=torch.uint8).numpy())
+    st = {"sharpen_enabled": True, "sharpen_strength": 0.6, "grain_enabled": True, "grain_intensity": 0.05, "saturation_mix": 0.4,
+          "seed": 9, "use_gpu": True}
+    tensor = enh._frames_to_tensor(frames)
+    enhanced, used = enh._process_with_retry(tensor, st, 30)
+    assert tensor.is_cuda and enhanced.is_cuda and used == 5
+    out = enh._tensor_to_frames(enhanced)
+
+    def noise_fn(fseed, shape):
+        gg = torch.Generator(device=dev).manual_seed(fseed)
+        return torch.randn(shape, generator=gg, device=dev).cpu()
+
+    want = R.seeded_grain(R.unsharp(R.frames_to_tensor(frames), 0.6, True).contiguous(), 0.05, 0.4, 9, 30, noise_fn=noise_fn)
+    _frames_eq(out, R.tensor_to_frames(want), "enhancer loop")
+    cpu_in = enh._apply_effects_batch(R.frames_to_tensor(frames), st, 30)         # CPU tensor in -> CPU tensor out, as in the reference
+    assert cpu_in.device.type == "cpu" and torch.equal(cpu_in, enhanced.cpu())
