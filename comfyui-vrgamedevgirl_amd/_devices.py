@@ -111,7 +111,13 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
     out_fb = images[0].numel() * torch.empty((), dtype=out_dtype).element_size()
     in_fb = images[0].numel() * images.element_size()
     pin_out = F * out_fb <= PIN_LIMIT_BYTES
-    out = torch.empty(images.shape, dtype=out_dtype, pin_memory=pin_out)
+    try:
+        out = torch.empty(images.shape, dtype=out_dtype, pin_memory=pin_out)
+    except RuntimeError:                      # the host refused to page-lock that much: pageable result + ring
+        if not pin_out:
+            raise
+        pin_out = False
+        out = torch.empty(images.shape, dtype=out_dtype)
     per = piece_frames(F, max(in_fb, out_fb), multiple_of)
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
     compute = torch.cuda.current_stream(dev)
