@@ -187,6 +187,24 @@ def main():
     except Exception:
         pass
 
+    # VALU issue roofline of the same pass (the one that actually binds it): lane-instructions per
+    # pixel from the committed PMC pass (SQ_INSTS_VALU, calibrated on the issue-rate probe) x this run's pixel rate,
+    # against the probe's measured peak for plain fp32 / integer ops
+    issue = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_valu_instr_per_px.json")) as fh:
+            recs = json.load(fh)
+        with open(os.path.join(ROOT, "profiles", "r01_valu_issue_rate.json")) as fh:
+            peak_t = max(r["tera_lane_instr_s"] for r in json.load(fh)["rows"] if r["instr"] == "v_fma_f32")
+        want = {"stats": "k_produce_lab<3, false>", "apply": "k_chain_tile<20" if "colormatch" in stages else "k_chain_march<3"}[dom]
+        ipp = next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
+        rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
+        issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
+                 "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4),
+                 "note": "unweighted; compare/select x1.5, integer multiply x1.75, transcendental x3 issue cost (profiles/r01_valu_issue_rate.json)"}
+    except Exception:
+        pass
+
     if rank == 0:
         line = {
             "metric": "Mpixels/s (grain+LUT+colormatch+sharpen) at 4K" if args.workload == "chain4_4k" else f"Mpixels/s ({'+'.join(stages)})",
@@ -203,7 +221,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
-                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}},
+                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "issue": issue},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
