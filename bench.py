@@ -167,7 +167,9 @@ def main():
     pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (segments of a step added up)
     algo_bpp = {"stats": 12, "apply": 24}
     kern_names = {"stats": "k_produce_lab (grain->LUT->Lab pass 1: shared Philox, stores Lab, per-frame statistics)",
-                  "apply": "k_chain_march (fused apply pass)"}
+                  "apply": "k_chain_tile<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, LDS tile)" if "colormatch" in stages
+                  else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
+                        else "k_chain_tile / k_chain_pointwise (fused apply pass)")}
     dom = max(pass_ms, key=pass_ms.get)
     kern_avg_ms = pass_ms[dom]
     algo_bytes = algo_bpp[dom] * px_rank
