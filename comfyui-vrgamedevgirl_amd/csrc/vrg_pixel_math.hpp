@@ -41,7 +41,16 @@ VRG_HD float f32_from_bits(uint32_t b) {
 }
 
 // clamp(v, 0, 1) with torch.clamp / np.clip NaN behaviour (NaN stays NaN).
-VRG_HD float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+// Device: one v_med3_f32 plus a NaN pass-through (v_cmp_u + v_cndmask) -- 4 issue units instead of the 6 of two
+// compare/select pairs (compare/select cost 1.5x, profiles/r01_valu_issue_rate.json); same value for every input.
+VRG_HD float clamp01(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float m = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+    return (v != v) ? v : m;
+#else
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+#endif
+}
 // clamp(v, min=lo)
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
 // clamp(v, 0, 1) in one v_med3_f32 where NaN cannot occur or the reference leaves NaN undefined (LUT index)
@@ -70,7 +79,7 @@ VRG_HD float div_const(float x, float c, float rc) {
 // x / 9.0f for the unsharp mean; +-Inf handled so that the result is IEEE for every input
 VRG_HD float div9(float x) {
     const float q = VRG_DIVC(x, 9.0f);
-    return (x - x == 0.0f) ? q : x;   // Inf/NaN pass through like x/9
+    return __builtin_isfinite(x) ? q : x;   // Inf/NaN pass through like x/9 (one v_cmp_class + v_cndmask)
 }
 
 
