@@ -44,34 +44,30 @@ __global__ __launch_bounds__(256) void k_adjust_point(const typename IO::elem* _
 // ---------------------------------------------------------------------------------------------------------
 // box-detail stencils, K = 9 (clarity, reflect border) and K = 3 (sharpen, replicate border).
 //
-// Tile 32 x 64 output pixels, 256 threads, each thread 4 adjacent columns x 2 adjacent rows.  The running sums
-// cannot be re-associated, so the work is 81 (9) dependent adds per pixel and channel; what can be saved is issue
-// slots and LDS traffic:
-//   * the tile (+ halo) is kept in LDS as VERTICAL PAIRS  V[r][c] = (T[r][c], T[r+1][c])  for every r, so the two
-//     rows a thread owns advance together through v_pk_add_f32 (one issue slot, two adds), with every operand an
-//     aligned register pair straight out of ds_read_b128 -- whatever the tap offset;
-//   * one row of 4 + K - 1 pairs feeds the 4 x 2 chains of a thread (K adds each).
+// Tile 32 x 64 output pixels (+ halo) in LDS as three planes, 256 threads, each thread 4 adjacent columns x 2 adjacent
+// rows.  The running sums cannot be re-associated, so the work is 81 (9) dependent adds per pixel and channel; what
+// can be saved is LDS traffic and issue slots around them: a tile row is read once (ds_read_b128) and feeds the chains
+// of both owned rows (row y uses tile rows ly..ly+K-1, row y+1 uses ly+1..ly+K) and of all four columns, every chain in
+// raster order.  [A vertical-pair layout V[r][c] = (T[r][c], T[r+1][c]) with v_pk_add_f32 chains was built and measured:
+// packed fp32 issues at 1.8x the cost of a plain add on this chip (profiles/r01_valu_issue_rate.json), so it saved
+// 10 % of the add slots, while its doubled LDS footprint (68 KB) halved the workgroups per CU -- 67 vs 81 Gpix/s.]
 // PRE: the input is the frame and the point stage is applied while filling LDS (recomputed for the halo instead of
 // stored); otherwise the input already is the clarity result.  TAIL: fade / vignette / clamp before storing.
 // ---------------------------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int AT_H = 32, AT_W = 64;
 
 template <int K, bool PRE, bool TAIL, class IN = IoF32, class OUT = IoF32>
 __global__ __launch_bounds__(256) void k_adjust_box(const typename IN::elem* __restrict__ in, typename OUT::elem* __restrict__ out,
-                                                     int32_t H, int32_t W, int32_t tiles_x, AdjustK A) {
-    constexpr int R = K / 2, LR = AT_H + 2 * R, LC = AT_W + 2 * R, VR = LR - 1, PITCH = LC + 2;   // LC even => PITCH even
-    constexpr int NCOL = 4 + K - 1;                                                                // pairs per row and thread
-    static_assert(PITCH % 2 == 0 && NCOL % 2 == 0, "b128 alignment");
-    __shared__ __attribute__((aligned(16))) f2 V[3][VR][PITCH];
+                                                           int32_t H, int32_t W, int32_t tiles_x, AdjustK A) {
+    constexpr int R = K / 2, LR = AT_H + 2 * R, LC = AT_W + 2 * R, PITCH = LC + 4;     // LC % 4 == 0 or 2: keep rows 16-B aligned
+    constexpr int NCOL = ((4 + K - 1) + 3) / 4 * 4;                                      // floats per row and thread (b128 multiples)
+    static_assert((LC + 4) % 2 == 0, "alignment");
+    __shared__ __attribute__((aligned(16))) float T[3][LR][PITCH + (PITCH % 4 ? 4 - PITCH % 4 : 0)];
     const int32_t ty0 = (blockIdx.x / tiles_x) * AT_H;
     const int32_t tx0 = (blockIdx.x % tiles_x) * AT_W;
     const int64_t fbase = (int64_t)blockIdx.y * H * W;
     const typename IN::elem* fin = in + fbase;
-
-    // fill: all global loads of the thread first (one memory latency per tile instead of one per element -- only two
-    // workgroups fit a CU next to 68 KB of LDS), then point stage and the two LDS copies of every element
     constexpr int NIT = (LR * LC + 255) / 256;
     px3 pre[NIT];
 #pragma unroll
@@ -79,15 +75,15 @@ __global__ __launch_bounds__(256) void k_adjust_box(const typename IN::elem* __r
         const int i = threadIdx.x + 256 * it;
         const int hy = i / LC, hx = i - hy * LC;
         int y = ty0 + hy - R, x = tx0 + hx - R;
-        if (K != 3) {                                     // F.pad(mode="reflect"); |offset| <= R < dim for real taps
+        if (K != 3) {
             if (y < 0) y = -y;
             if (y > H - 1) y = 2 * (H - 1) - y;
             if (x < 0) x = -x;
             if (x > W - 1) x = 2 * (W - 1) - x;
         }
-        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);          // replicate (K == 3); otherwise only positions no valid
-        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);          // output reads (past the frame in a partial tile)
-        pre[it] = IN::load(fin + (y * W + x));            // i >= LR*LC maps to some valid pixel as well: harmless
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+        pre[it] = IN::load(fin + (y * W + x));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -100,43 +96,45 @@ __global__ __launch_bounds__(256) void k_adjust_box(const typename IN::elem* __r
             adjust_point(A, v, o);
             v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (hy < VR) V[c][hy][hx].x = v[c];
-            if (hy > 0) V[c][hy - 1][hx].y = v[c];
-        }
+        T[0][hy][hx] = v[0];
+        T[1][hy][hx] = v[1];
+        T[2][hy][hx] = v[2];
     }
     __syncthreads();
 
     const int lx = (threadIdx.x & 15) * 4, ly = (threadIdx.x >> 4) * 2;
-    f2 blur[3][4];
+    float blur[3][2][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        f2 acc[4];
+        float acc[2][4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = f2{0.0f, 0.0f};
-        // raster order over the window: rows top to bottom, taps left to right (avg_pool2d's running sum)
+        for (int o = 0; o < 4; ++o) acc[0][o] = acc[1][o] = 0.0f;
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy) {
-            const f2* row = &V[c][ly + dy][lx];
-            f2 r[NCOL];
+        for (int rho = 0; rho <= K; ++rho) {
+            const float* row = &T[c][ly + rho][lx];
+            float r[NCOL];
 #pragma unroll
-            for (int j = 0; j < NCOL; j += 2) {
+            for (int j = 0; j < NCOL; j += 4) {
                 const f4 t = *reinterpret_cast<const f4*>(row + j);
-                r[j] = f2{t.x, t.y};
-                r[j + 1] = f2{t.z, t.w};
+                r[j] = t.x; r[j + 1] = t.y; r[j + 2] = t.z; r[j + 3] = t.w;
             }
+            if (rho < K) {
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
+                for (int dx = 0; dx < K; ++dx)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = acc[o] + r[o + dx];
+                    for (int o = 0; o < 4; ++o) acc[0][o] = acc[0][o] + r[o + dx];
+            }
+            if (rho > 0) {
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[1][o] = acc[1][o] + r[o + dx];
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            if (K == 3) blur[c][o] = f2{div9(acc[o].x), div9(acc[o].y)};
-            else blur[c][o] = f2{VRG_ADJ_DIV(acc[o].x, (float)(K * K)), VRG_ADJ_DIV(acc[o].y, (float)(K * K))};
-        }
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) blur[c][rr][o] = K == 3 ? div9(acc[rr][o]) : VRG_ADJ_DIV(acc[rr][o], (float)(K * K));
     }
     typename OUT::elem* fout = out + fbase;
 #pragma unroll
@@ -147,17 +145,13 @@ __global__ __launch_bounds__(256) void k_adjust_box(const typename IN::elem* __r
         for (int o = 0; o < 4; ++o) {
             const int x = tx0 + lx + o;
             if (x >= W) continue;
-            float ctr[3], bl[3], v[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const f2 cc = V[c][ly + R][lx + R + o];
-                ctr[c] = rr ? cc.y : cc.x;
-                bl[c] = rr ? blur[c][o].y : blur[c][o].x;
-            }
+            const float ctr[3] = {T[0][ly + rr + R][lx + R + o], T[1][ly + rr + R][lx + R + o], T[2][ly + rr + R][lx + R + o]};
+            const float bl[3] = {blur[0][rr][o], blur[1][rr][o], blur[2][rr][o]};
+            float v[3];
             if (K == 3) adjust_sharpen_mix(A, ctr, bl, v);
             else adjust_clarity_mix(A, ctr, bl, v);
             if (TAIL) adjust_tail(A, y, x, H, W, v);
-            OUT::store(fout + (y * W + x), px3{v[0], v[1], v[2]});   // plain store: a lane's 4 pixels are 4 instructions, L2 merges the lines
+            OUT::store(fout + (y * W + x), px3{v[0], v[1], v[2]});
         }
     }
 }
