@@ -9,7 +9,7 @@ import os
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
+LIB_PATH = os.environ.get("VRGDG_HIP_LIB") or os.path.join(PKG_DIR, "libvrgdg_hip.so")   # override: A/B builds (tools/ab_libs.sh)
 
 VRG_OK = 0
 BORDER_REPLICATE, BORDER_ZERO = 0, 1
