@@ -14,6 +14,8 @@ export TMPDIR=/tmp
   echo "=== $(date) rocprof stats"; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}.log 2>&1; cd $GRAFT_REPO_ROOT
   head -6 gpurun_out/prof_${TAG}/trace_kernel_stats.csv | cut -c1-200
   echo "=== $(date) traffic"; bash tools/gpu_traffic.sh ${TAG} 2>&1 | tail -4
+  echo "=== $(date) issue (VALU instr/px)"; bash tools/gpu_issue.sh ${TAG} 2>&1 | tail -3 | cut -c1-300
+  echo "=== $(date) diag (kernels, VALU probe, host-fed)"; timeout 900 python tools/gpu_diag.py --frames 16 --iters 5 --valu --host --out gpurun_out/diag_${TAG}.json 2>&1 | grep -v amdgpu.ids | grep "diag\]" > gpurun_out/diag_${TAG}.log; tail -2 gpurun_out/diag_${TAG}.log | cut -c1-300
   echo "=== $(date) done"
 } > gpurun_out/final_${TAG}.log 2>&1
 tail -6 gpurun_out/final_${TAG}.log | cut -c1-300
