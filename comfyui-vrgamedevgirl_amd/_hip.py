@@ -74,6 +74,7 @@ _SIGNATURES = {
                                      C.c_float, _P]),
     "vrg_adjust_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(AdjustDesc), _P]),
     "vrg_adjust_u8": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(AdjustDesc), _P]),
+    "vrg_u8_channel_sums": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "vrg_u8bgr_to_f32rgb": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_f32rgb_to_u8bgr": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_fused_chain_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),

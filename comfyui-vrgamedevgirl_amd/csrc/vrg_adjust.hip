@@ -254,6 +254,39 @@ __global__ __launch_bounds__(256) void k_f32_to_u8(const px3* __restrict__ in, b
     if (p < pixels) IoU8::store(out + p, load_px_stream(in + p));
 }
 
+// Exact per-frame channel sums of uint8 frames: sum and sum of squares per channel as 64-bit integers (what
+// PIL.ImageStat derives mean / stddev from in the reference's opening colour match, VRGDG_WorkflowRunnerNodes.py:4385-4392).
+// Integer arithmetic: bit-exact and independent of the reduction order, so plain 64-bit atomics are deterministic.
+__global__ __launch_bounds__(256) void k_u8_channel_sums(const uint8_t* __restrict__ frames, int64_t pixels, unsigned long long* __restrict__ sums) {
+    const uint8_t* f = frames + (int64_t)blockIdx.y * pixels * 3;
+    unsigned long long s[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint32_t v = f[3 * p + c];
+            s[c] += v;
+            q[c] += v * v;
+        }
+    }
+    __shared__ unsigned long long red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsigned long long a = s[c], b = q[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            b += __shfl_down(b, o, 64);
+        }
+        if (lane == 0) { red[wave][2 * c] = a; red[wave][2 * c + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(sums + (int64_t)blockIdx.y * 6 + threadIdx.x, t);
+    }
+}
+
 }  // namespace vrg
 
 using namespace vrg;
@@ -268,6 +301,19 @@ int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int3
 int vrg_adjust_u8(const uint8_t* in, uint8_t* out, float* tmp, int64_t frames, int32_t height, int32_t width, const vrg_adjust_desc* d,
                   void* stream) {
     return launch_adjust<IoU8>(in, out, tmp, frames, height, width, d, (hipStream_t)stream);
+}
+
+int vrg_u8_channel_sums(const uint8_t* frames, int64_t n_frames, int32_t height, int32_t width, unsigned long long* sums, void* stream) {
+    if (!frames || !sums || n_frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (n_frames == 0) return VRG_OK;
+    if (n_frames > 65535) return VRG_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, (size_t)n_frames * 6 * sizeof(unsigned long long), st) != hipSuccess) return VRG_ERR_LAUNCH;
+    const int64_t pixels = (int64_t)height * width;
+    int64_t blocks = (pixels + 256 * 16 - 1) / (256 * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_u8_channel_sums, dim3((uint32_t)blocks, (uint32_t)n_frames), dim3(256), 0, st, frames, pixels, sums);
+    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
 }
 
 int vrg_u8bgr_to_f32rgb(const uint8_t* in, float* out, int64_t pixels, void* stream) {

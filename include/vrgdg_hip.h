@@ -220,6 +220,11 @@ int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int3
  * ------------------------------------------------------------------------------------------- */
 int vrg_u8bgr_to_f32rgb(const uint8_t* in, float* out, int64_t pixels, void* stream);
 int vrg_f32rgb_to_u8bgr(const float* in, uint8_t* out, int64_t pixels, void* stream);
+/* Exact per-frame channel sums of uint8 frames, `sums` = [frames][3 channels in memory order][sum, sum of squares]
+ * as 64-bit integers (zeroed by the call).  Replaces PIL.ImageStat.Stat(...).sum / .sum2 in the opening colour match
+ * (VRGDG_WorkflowRunnerNodes.py:4385-4392); mean / stddev follow on the host in double exactly as ImageStat does. */
+int vrg_u8_channel_sums(const uint8_t* frames, int64_t frames_n, int32_t height, int32_t width, unsigned long long* sums,
+                        void* stream);
 /* grain / LUT / 3x3 sharpen in any combination (no colour match: VRG_ERR_UNSUPPORTED); desc as for vrg_fused_chain_f32 */
 int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width,
                        const vrg_chain_desc* desc, void* stream);

@@ -178,3 +178,30 @@ def load_standalone_enhancer():
         )
         _CACHE["sve"] = types.SimpleNamespace(**{k: v for k, v in ns.items() if k.startswith(("_a", "_p", "_f", "_t"))})
     return _CACHE["sve"]
+
+
+def opening_color_match_reference(reference_rgb, target_rgb, workdir, strength=0.85, fade_seconds=1.0):
+    """Run the numeric slice of the reference's ``_apply_scene_start_color_match``
+    (VRGDG_WorkflowRunnerNodes.py:4382-4407: PIL.ImageStat of the two frames -> scales / offsets -> the 17^3 ``.cube``
+    text and the ffmpeg blend-weight expression) on two HxWx3 uint8 RGB arrays.  The statements are taken from the
+    reference's AST and executed as they stand; the ffmpeg calls around them (frame extraction, lut3d filter) are not run.
+    Needs Pillow, which the reference imports for this function."""
+    import numpy as np
+    from PIL import Image, ImageStat
+    path = os.path.join(REFERENCE_ROOT, "VRGDG_WorkflowRunnerNodes.py")
+    with open(path, "r", encoding="utf-8") as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_apply_scene_start_color_match")
+    body = next(n for n in fn.body if isinstance(n, ast.Try)).body
+    first = next(i for i, n in enumerate(body) if isinstance(n, ast.With) and "Image.open" in ast.unparse(n.items[0]))
+    last = next(i for i, n in enumerate(body) if isinstance(n, ast.Assign) and ast.unparse(n.targets[0]) == "weight")
+    os.makedirs(workdir, exist_ok=True)
+    ns = {"Image": Image, "ImageStat": ImageStat, "os": os, "strength": float(strength), "fade_seconds": float(fade_seconds),
+          "reference_frame": os.path.join(workdir, "ref.png"), "target_frame": os.path.join(workdir, "tgt.png"),
+          "cube_path": os.path.join(workdir, "match.cube")}
+    Image.fromarray(np.ascontiguousarray(reference_rgb), "RGB").save(ns["reference_frame"])
+    Image.fromarray(np.ascontiguousarray(target_rgb), "RGB").save(ns["target_frame"])
+    exec(compile(ast.Module(body=body[first:last + 1], type_ignores=[]), path, "exec"), ns)
+    with open(ns["cube_path"], "r", encoding="utf-8") as fh:
+        cube_text = fh.read()
+    return {k: ns[k] for k in ("reference_mean", "reference_std", "target_mean", "target_std", "scales", "offsets", "weight")} | {"cube_text": cube_text}

@@ -13,6 +13,8 @@ convention ``[F, H, W, C]`` unless noted.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -501,6 +503,53 @@ def tensor_to_frames(tensor: torch.Tensor):
     RGB->BGR per frame."""
     array = np.clip(tensor.detach().cpu().numpy() * 255.0, 0, 255).astype(np.uint8)
     return [np.ascontiguousarray(frame[..., ::-1]) for frame in array]
+
+
+# --------------------------------------------------------------------------------------
+# Opening colour match of a new clip (SURVEY.md section 8f rank 4): statistics -> 17^3 cube
+# --------------------------------------------------------------------------------------
+
+def image_stat_rgb(frame_u8: np.ndarray):
+    """PIL.ImageStat.Stat(image).mean / .stddev of an HxWx3 uint8 frame, as ImageStat computes them: integer-valued
+    sums (from the histogram) in double, ``mean = sum / n``, ``var = (sum2 - sum**2.0 / n) / n``, ``sqrt``."""
+    a = np.asarray(frame_u8).reshape(-1, 3).astype(np.uint64)
+    n = a.shape[0]
+    mean, std = [], []
+    for c in range(3):
+        s = float(int(a[:, c].sum()))
+        s2 = float(int((a[:, c] * a[:, c]).sum()))
+        mean.append(s / n)
+        std.append(math.sqrt((s2 - (s ** 2.0) / n) / n))
+    return mean, std
+
+
+def opening_match_terms(reference_stats, target_stats):
+    """scales / offsets of VRGDG_WorkflowRunnerNodes.py:4386-4391: stddevs floored at 1, scale clamped to [0.25, 4]."""
+    (rm, rs), (tm, ts) = reference_stats, target_stats
+    rs = [max(1.0, float(v)) for v in rs]
+    ts = [max(1.0, float(v)) for v in ts]
+    scales = [max(0.25, min(4.0, rs[i] / ts[i])) for i in range(3)]
+    offsets = [float(rm[i]) - float(tm[i]) * scales[i] for i in range(3)]
+    return scales, offsets
+
+
+def opening_match_cube_text(scales, offsets, size=17) -> str:
+    """The ``.cube`` the reference hands to ffmpeg's lut3d (:4393-4405): red fastest, 8 decimals."""
+    out = ['TITLE "VRGDG opening color match"\n', f"LUT_3D_SIZE {size}\nDOMAIN_MIN 0.0 0.0 0.0\nDOMAIN_MAX 1.0 1.0 1.0\n"]
+    for blue in range(size):
+        for green in range(size):
+            for red in range(size):
+                idx = (red, green, blue)
+                v = [max(0.0, min(1.0, ((idx[i] / (size - 1)) * 255.0 * scales[i] + offsets[i]) / 255.0)) for i in range(3)]
+                out.append(f"{v[0]:.8f} {v[1]:.8f} {v[2]:.8f}\n")
+    return "".join(out)
+
+
+def opening_match_weight(frame_index: int, fps: float, strength: float, fade_seconds: float) -> float:
+    """ffmpeg blend weight ``max(0, min(1, strength * (1 - T / fade)))`` at T = frame_index / fps (:4407); the
+    expression text carries strength and fade with six decimals, so those are the values ffmpeg evaluates."""
+    s6, f6 = float(f"{strength:.6f}"), float(f"{fade_seconds:.6f}")
+    return max(0.0, min(1.0, s6 * (1.0 - (frame_index / fps) / f6)))
 
 
 # --------------------------------------------------------------------------------------

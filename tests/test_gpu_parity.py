@@ -824,3 +824,61 @@ def test_enhancer_loop_stays_on_gpu_between_uint8_edges(pkg, dev):
     _frames_eq(out, R.tensor_to_frames(want), "enhancer loop")
     cpu_in = enh._apply_effects_batch(R.frames_to_tensor(frames), st, 30)         # CPU tensor in -> CPU tensor out, as in the reference
     assert cpu_in.device.type == "cpu" and torch.equal(cpu_in, enhanced.cpu())
+
+
+# ---------------------------------------------------------------------------------------- opening colour match (8f-4)
+def test_u8_channel_sums_are_exact(pkg, dev):
+    from comfyui_vrgamedevgirl_amd import _hip
+    for shape in ((3, 37, 53, 3), (1, 1, 1, 3), (2, 2160, 3840, 3)):
+        g = torch.Generator().manual_seed(sum(shape))
+        frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        x = frames.to(dev)
+        sums = torch.full((shape[0], 3, 2), -1, dtype=torch.int64, device=dev)
+        _hip.check(_hip.lib().vrg_u8_channel_sums(_hip.ptr(x), shape[0], shape[1], shape[2], _hip.ptr(sums), _hip.current_stream()), "sums")
+        a = frames.numpy().reshape(shape[0], -1, 3).astype(np.uint64)
+        want = np.stack([a.sum(axis=1), (a * a).sum(axis=1)], axis=-1).astype(np.int64)
+        assert np.array_equal(sums.cpu().numpy(), want), shape
+
+
+def test_opening_colour_match_statistics_and_frames(pkg, ops, dev):
+    import json
+    from comfyui_vrgamedevgirl_amd import VRGDG_WorkflowRunnerNodes as WR
+    z = _npz("opening_match.npz")
+    with open(os.path.join(GOLDEN, "opening_match.json")) as fh:
+        meta = json.load(fh)
+    for name, m in meta.items():
+        ref_bgr = np.ascontiguousarray(z[f"{name}.ref"][..., ::-1])
+        tgt_bgr = np.ascontiguousarray(z[f"{name}.tgt"][..., ::-1])
+        rs, ts = WR._frame_channel_stats(ref_bgr), WR._frame_channel_stats(tgt_bgr)
+        assert rs[0] == m["reference_mean"] and ts[0] == m["target_mean"], name          # PIL.ImageStat, bit for bit (doubles)
+        assert [max(1.0, v) for v in rs[1]] == m["reference_std"] and [max(1.0, v) for v in ts[1]] == m["target_std"], name
+        # the clip: 6 frames shaped like the target, fps 4 -> weights fade over the first frames
+        g = np.random.default_rng(5)
+        clip = [g.integers(0, 256, tgt_bgr.shape, dtype=np.uint8) for _ in range(6)]
+        clip[0] = tgt_bgr
+        out, info = WR._apply_scene_start_color_match_frames(clip, ref_bgr, fps=4.0, fade_seconds=m["fade_seconds"], strength=m["strength"])
+        assert info["applied"] and info["scales"] == m["scales"] and info["offsets"] == m["offsets"]
+        assert hashlib_sha256(info["cube_text"]) == m["cube_sha256"]
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "c.cube")
+            with open(path, "w", encoding="utf-8", newline="\n") as fh:
+                fh.write(info["cube_text"])
+            lut = R.parse_cube_file(path)
+        fade = max(0.05, min(30.0, m["fade_seconds"]))
+        for i, frame in enumerate(clip):
+            w = R.opening_match_weight(i, 4.0, m["strength"], fade)
+            assert info["weights"][i] == w
+            want = frame if w <= 0.0 else R.tensor_to_frames(R.apply_lut_with_strength(R.frames_to_tensor([frame]), lut, 10.0 * w))[0]
+            _frames_eq(out[i], want, f"opening match {name} frame {i}")
+    # the reference's `float(payload.get("strength", 0.85) or 0.85)`: 0 is falsy -> 0.85; only a negative value clamps to 0
+    _, info = WR._apply_scene_start_color_match_frames(clip, ref_bgr, fps=4.0, strength=0.0)
+    assert info["applied"] and info["weights"][0] == 0.85
+    same, info = WR._apply_scene_start_color_match_frames(clip, ref_bgr, fps=4.0, strength=-1.0)
+    assert info == {"applied": False, "reason": "strength is zero"}
+    _frames_eq(same, clip, "strength <= 0 leaves the clip untouched")
+
+
+def hashlib_sha256(text):
+    import hashlib
+    return hashlib.sha256(text.encode()).hexdigest()

@@ -185,3 +185,21 @@ def test_adjust_normalization_and_terms(pkg):
     assert t.has_fade == 1 and t.has_vignette == 1
     off = ops.adjust_terms(LVT._normalize_adjust_settings(cases["disabled"]))
     assert off.enabled == 0
+
+
+def test_opening_match_host_terms_cube_and_weight(pkg):
+    """Host side of the opening colour match mirror against the reference fixtures (statistics need the GPU: -m gpu)."""
+    import hashlib
+    import json
+    from comfyui_vrgamedevgirl_amd import VRGDG_WorkflowRunnerNodes as WR
+    z = np.load(os.path.join(GOLDEN, "opening_match.npz"))
+    with open(os.path.join(GOLDEN, "opening_match.json")) as fh:
+        meta = json.load(fh)
+    for name, m in meta.items():
+        rs, ts = R.image_stat_rgb(z[f"{name}.ref"]), R.image_stat_rgb(z[f"{name}.tgt"])
+        scales, offsets = WR._opening_color_match_terms(rs, ts)
+        assert scales == m["scales"] and offsets == m["offsets"], name
+        assert hashlib.sha256(WR._opening_color_match_cube_text(scales, offsets).encode()).hexdigest() == m["cube_sha256"], name
+        for k in (0, 3, 29, 1000):
+            got = WR._opening_color_match_weight(k, 30.0, m["strength"], m["fade_seconds"])
+            assert got == R.opening_match_weight(k, 30.0, m["strength"], m["fade_seconds"])

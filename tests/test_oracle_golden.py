@@ -195,3 +195,43 @@ def test_u8_codec_edge_restatement_against_reference_fixtures():
     for name in ("all", "both", "fade_vig", "tone"):
         out = R.adjust_tensor(R.frames_to_tensor(frames), cases[name])
         assert np.array_equal(np.stack(R.tensor_to_frames(out), axis=0), z[f"batch.adjust.{name}"]), name
+
+
+# ------------------------------------------------------------------ opening colour match (section 8f rank 4)
+
+def _opening_meta():
+    with open(os.path.join(GOLDEN, "opening_match.json")) as fh:
+        return json.load(fh)
+
+
+def test_opening_match_restatement_against_reference_fixtures():
+    """Statistics (PIL.ImageStat), gains / offsets, the cube text and the blend weight: fixtures come from the
+    reference's own statements (oracle/reference_loader.py::opening_color_match_reference)."""
+    z = _npz("opening_match.npz")
+    for name, m in _opening_meta().items():
+        rs, ts = R.image_stat_rgb(z[f"{name}.ref"]), R.image_stat_rgb(z[f"{name}.tgt"])
+        assert rs[0] == m["reference_mean"] and ts[0] == m["target_mean"], name
+        assert [max(1.0, v) for v in rs[1]] == m["reference_std"] and [max(1.0, v) for v in ts[1]] == m["target_std"], name
+        scales, offsets = R.opening_match_terms(rs, ts)
+        assert scales == m["scales"] and offsets == m["offsets"], name
+        text = R.opening_match_cube_text(scales, offsets)
+        assert hashlib.sha256(text.encode()).hexdigest() == m["cube_sha256"], name
+        assert text.splitlines()[:6] == m["cube_head"] and text.splitlines()[-2:] == m["cube_tail"]
+        # the weight expression the reference formats for ffmpeg, evaluated at a few times
+        s6, f6 = m["weight"].split("*(1-T/")[0].split("\\,")[-1], m["weight"].split("*(1-T/")[1].rstrip(")")
+        for k in (0, 1, 7, 24, 500):
+            want = max(0.0, min(1.0, float(s6) * (1.0 - (k / 24.0) / float(f6))))
+            assert R.opening_match_weight(k, 24.0, m["strength"], m["fade_seconds"]) == want, (name, k)
+
+
+@pytest.mark.skipif(not RL.reference_available(), reason="reference checkout not present")
+def test_opening_match_against_live_reference():
+    pytest.importorskip("PIL")
+    import tempfile
+    g = np.random.default_rng(3)
+    ref = g.integers(0, 256, (21, 18, 3), dtype=np.uint8)
+    tgt = (g.integers(0, 256, (17, 23, 3)) * 0.4 + 90).astype(np.uint8)
+    with tempfile.TemporaryDirectory() as d:
+        out = RL.opening_color_match_reference(ref, tgt, d, 0.5, 3.0)
+    scales, offsets = R.opening_match_terms(R.image_stat_rgb(ref), R.image_stat_rgb(tgt))
+    assert scales == out["scales"] and offsets == out["offsets"] and R.opening_match_cube_text(scales, offsets) == out["cube_text"]
