@@ -882,3 +882,51 @@ def test_opening_colour_match_statistics_and_frames(pkg, ops, dev):
 def hashlib_sha256(text):
     import hashlib
     return hashlib.sha256(text.encode()).hexdigest()
+
+
+# ---------------------------------------------------------------------------------------- randomized sweep
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_chain_and_adjust_sweep(ops, pkg, dev, seed):
+    """Random shapes, stage subsets, strengths and slider sets (fixed seeds): fp32 and uint8 entry points against the
+    CPU oracle, bit for bit.  Covers combinations the hand-written lists do not."""
+    import random
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    rnd = random.Random(1000 + seed)
+    F, H, W = rnd.randint(1, 5), rnd.randint(1, 90), rnd.randint(1, 150)
+    name = rnd.choice(["AMD_TealOrange_33.cube", "AMD_WarmFilm_25.cube", "AMD_Identity_17.cube"])
+    data, dlut = _lut_pair(ops, dev, name)
+    grain = (round(rnd.uniform(0.001, 0.6), 3), round(rnd.uniform(0, 1), 2), rnd.choice([0, 1, 2, 3])) if rnd.random() < 0.7 else None
+    lut_s = rnd.choice([10.0, round(rnd.uniform(0.1, 9.9), 1)]) if rnd.random() < 0.7 else None
+    sharpen = (rnd.choice(["unsharp", "laplacian", "sobel"]), round(rnd.uniform(0.05, 2.0), 2), False) if rnd.random() < 0.7 else None
+    if grain is None and lut_s is None and sharpen is None:
+        lut_s = 10.0
+    use_u8 = rnd.random() < 0.5
+    g = torch.Generator().manual_seed(seed)
+    frames = torch.randint(0, 256, (F, H, W, 3), generator=g, dtype=torch.uint8)
+    x = R.frames_to_tensor(list(frames.numpy())) if use_u8 else torch.rand((F, H, W, 3), generator=g) * 1.1 - 0.05
+    spec = ops.ChainSpec(grain=grain, lut=(dlut, lut_s) if lut_s is not None else None, sharpen=sharpen, variant=rnd.choice([0, 1, 2]))
+    torch.manual_seed(seed)
+    got = ops.fused_chain(frames.to(dev) if use_u8 else x.to(dev), spec)
+    torch.manual_seed(seed)
+    o = x
+    if grain:
+        o = R.fast_film_grain(o, grain[0], grain[1], grain[2], noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    if lut_s is not None:
+        o = R.apply_lut_with_strength(o, data, lut_s)
+    if sharpen:
+        o = {"unsharp": R.unsharp, "laplacian": R.laplacian, "sobel": R.sobel}[sharpen[0]](o, sharpen[1], False)
+        o = o.contiguous()
+    if use_u8:
+        _frames_eq(got.cpu().numpy(), R.tensor_to_frames(o), f"sweep {seed} u8 {spec}")
+    else:
+        assert_bit_equal(got, o, f"sweep {seed} {spec}")
+    # Adjust with a random slider subset on the same frames
+    keys = ["temperature", "tint", "saturation", "exposure", "contrast", "highlights", "shadows", "whites", "blacks", "sharpen",
+            "clarity", "vignette", "fade"]
+    settings = {k: round(rnd.uniform(-100, 100), 1) for k in rnd.sample(keys, rnd.randint(1, 8))}
+    terms = ops.adjust_terms(LVT._normalize_adjust_settings(settings))
+    if use_u8:
+        want = R.tensor_to_frames(_adjust_want(x, settings))
+        _frames_eq(ops.adjust(frames.to(dev), terms).cpu().numpy(), want, f"sweep {seed} adjust u8 {settings}")
+    else:
+        assert_bit_equal(ops.adjust(x.to(dev), terms), _adjust_want(x, settings), f"sweep {seed} adjust {settings}")
