@@ -930,3 +930,36 @@ def test_randomized_chain_and_adjust_sweep(ops, pkg, dev, seed):
         _frames_eq(ops.adjust(frames.to(dev), terms).cpu().numpy(), want, f"sweep {seed} adjust u8 {settings}")
     else:
         assert_bit_equal(ops.adjust(x.to(dev), terms), _adjust_want(x, settings), f"sweep {seed} adjust {settings}")
+
+
+def test_nodes_are_reentrant_across_host_threads(pkg, dev):
+    """ComfyUI's worker, the aiohttp routes and the enhancer's daemon thread may enter the kernels concurrently
+    (threading): no shared mutable state besides the LUT cache and the staging ring."""
+    import threading
+    from comfyui_vrgamedevgirl_amd import nodes, VRGDG_IV_Adjustments as iv, VRGDG_LUTVideoTools as LVT
+    inputs = [_rand((3, 40 + 7 * i, 64 + 5 * i, 3), 900 + i) for i in range(6)]
+
+    def work(x):
+        a = nodes.FastUnsharpSharpen().apply_unsharp(x, 0.8, False)[0]
+        b = iv.VRGDG_LUTS().apply_lut(x, "AMD_WarmFilm_25.cube", "auto", 6.0)[0]
+        c = LVT._apply_adjust_tensor(x, {"clarity": 30, "sharpen": 20, "vignette": 40}, "cuda").cpu()
+        return a, b, c
+
+    want = [work(x) for x in inputs]
+    got = [None] * len(inputs)
+    errors = []
+
+    def run(i):
+        try:
+            for _ in range(3):
+                got[i] = work(inputs[i])
+        except Exception as exc:      # surfaced below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(inputs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for w, g in zip(want, got):
+        for a, b in zip(w, g):
+            assert torch.equal(a, b)
