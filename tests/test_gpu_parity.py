@@ -358,7 +358,7 @@ CHAIN_SHAPES = [(5, 45, 70, 3), (4, 64, 128, 3), (2, 1, 1, 3), (1, 3, 1, 3), (1,
                 (1, 7, 123, 3), (1, 15, 17, 3), (1, 10, 33, 3), (4, 30, 200, 3)]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", CHAIN_CASES)
 @pytest.mark.parametrize("shape", CHAIN_SHAPES)
 def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shape, variant):
@@ -397,7 +397,7 @@ def test_fused_chain_equals_sequential_operators_and_oracle(ops, dev, case, shap
     assert_bit_equal(fused, o, "fused vs oracle")
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("bs,shape", [(4, (3, 720, 1280, 3)), (0, (2, 600, 700, 3)), (1, (2, 540, 960, 3))])
 def test_fused_chain_across_several_philox_groups(ops, dev, variant, bs, shape):
     """Chunks larger than 4*G elements: several Philox call indices, ragged quarter rows, sibling strips that wrap
