@@ -96,6 +96,11 @@ def cpu_baseline(stages, cpu_frames, H, W, lut_cpu):
 
 def main():
     args = parse_args()
+    # stdout carries exactly one line, the JSON: everything else that writes to fd 1 while we run (RCCL prints a
+    # version banner to stdout when a communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from __graft_entry__ import load_package
     load_package()
     from comfyui_vrgamedevgirl_amd import ops, sharding
@@ -231,7 +236,8 @@ def main():
             except Exception as exc:      # never lose the GPU line to a host-side problem
                 line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
                                         "sample": f"failed: {type(exc).__name__}: {exc}"}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -92,7 +92,8 @@ def init_from_env(backend: Optional[str] = None):
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kwargs = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}      # bind the RCCL communicator to this rank's GPU
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     return rank, local, world
