@@ -235,3 +235,26 @@ def test_opening_match_against_live_reference():
         out = RL.opening_color_match_reference(ref, tgt, d, 0.5, 3.0)
     scales, offsets = R.opening_match_terms(R.image_stat_rgb(ref), R.image_stat_rgb(tgt))
     assert scales == out["scales"] and offsets == out["offsets"] and R.opening_match_cube_text(scales, offsets) == out["cube_text"]
+
+
+def test_lab_restatement_known_answers_from_colour_science():
+    """kornia is absent (colour match stays "parity unpinned"), so the restated transforms are anchored on published
+    CIELAB (D65, 2 deg) values of the sRGB primaries / secondaries -- the algorithm, not the last bit (kornia's 6-digit
+    ITU matrix moves them by ~1e-3)."""
+    known = {
+        (1.0, 0.0, 0.0): (53.2408, 80.0925, 67.2032),
+        (0.0, 1.0, 0.0): (87.7347, -86.1827, 83.1793),
+        (0.0, 0.0, 1.0): (32.2970, 79.1875, -107.8602),
+        (1.0, 1.0, 0.0): (97.1393, -21.5537, 94.4780),
+        (0.0, 1.0, 1.0): (91.1132, -48.0875, -14.1312),
+        (1.0, 0.0, 1.0): (60.3242, 98.2343, -60.8249),
+        (1.0, 1.0, 1.0): (100.0, 0.0, 0.0),
+        (128 / 255.0,) * 3: (53.5850, 0.0, 0.0),
+        (0.0, 0.0, 0.0): (0.0, 0.0, 0.0),
+    }
+    rgb = torch.tensor(list(known.keys()), dtype=torch.float32).t().reshape(1, 3, 1, -1)
+    lab = R.kornia_rgb_to_lab(rgb).reshape(3, -1).t()
+    want = torch.tensor(list(known.values()), dtype=torch.float32)
+    assert (lab - want).abs().max().item() < 0.05, (lab - want).abs().max().item()
+    back = R.kornia_lab_to_rgb(R.kornia_rgb_to_lab(rgb))
+    assert (back - rgb).abs().max().item() < 1e-5
