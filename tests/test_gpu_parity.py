@@ -963,3 +963,20 @@ def test_nodes_are_reentrant_across_host_threads(pkg, dev):
     for w, g in zip(want, got):
         for a, b in zip(w, g):
             assert torch.equal(a, b)
+
+
+def test_baseline_config_1_single_512_frame(pkg, ops, dev):
+    """BASELINE.json configs[0]: Fast Film Grain on one 512x512 RGB frame, torch.manual_seed(0), I=0.04, s=0.5, bs=4.
+    The reference's CPU noise (mt19937) cannot be reproduced in parallel, so the plumbing check injects it: the
+    reference node's own arithmetic on that noise (oracle) == the HIP kernel on the same noise, bit for bit; and the node
+    itself, on the device stream, == the oracle fed with torch's device noise."""
+    from comfyui_vrgamedevgirl_amd import nodes
+    torch.manual_seed(0)
+    x = torch.rand(1, 512, 512, 3)
+    noise = torch.randn(1, 512, 512, 3)
+    assert_bit_equal(ops.film_grain_injected(x.to(dev), noise.to(dev), 0.04, 0.5), R.grain_apply(x, noise, 0.04, 0.5), "config 1, injected noise")
+    torch.manual_seed(0)
+    (got,) = nodes.FastFilmGrain().apply_grain(x, 0.04, 0.5, 4)
+    torch.manual_seed(0)
+    want = R.fast_film_grain(x, 0.04, 0.5, 4, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    assert_bit_equal(got, want, "config 1, node on the device stream")

@@ -258,3 +258,17 @@ def test_lab_restatement_known_answers_from_colour_science():
     assert (lab - want).abs().max().item() < 0.05, (lab - want).abs().max().item()
     back = R.kornia_lab_to_rgb(R.kornia_rgb_to_lab(rgb))
     assert (back - rgb).abs().max().item() < 1e-5
+
+
+@pytest.mark.skipif(not RL.reference_available(), reason="reference checkout not present")
+def test_baseline_config_1_oracle_equals_reference_node_on_cpu():
+    """BASELINE.json configs[0] on the reference's own CPU path: same seed, same mt19937 noise -> the restatement and the
+    reference node agree bit for bit on the 512x512 frame."""
+    nodes = RL.load_nodes()
+    torch.manual_seed(0)
+    x = torch.rand(1, 512, 512, 3)
+    torch.manual_seed(1)
+    want = nodes.FastFilmGrain().apply_grain(x, 0.04, 0.5, 4)[0]
+    torch.manual_seed(1)
+    got = R.fast_film_grain(x, 0.04, 0.5, 4)
+    assert torch.equal(got, want)
