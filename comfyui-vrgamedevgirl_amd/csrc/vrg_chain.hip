@@ -97,22 +97,36 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
         tile[2][hy][hx] = o[2];
     }
     __syncthreads();
+    // Each thread owns one column of the tile and 8 consecutive rows: adjacent lanes are adjacent pixels (coalesced
+    // streaming stores, conflict-free LDS rows), the 3x3 window slides down in registers (30 LDS reads per channel for
+    // 8 pixels instead of 72) and the index arithmetic is paid once per thread.
     typename IO::elem* fout = out + f * ppf;
-    for (int i = threadIdx.x; i < TILE_H * TILE_W; i += 256) {
-        const int ly = i / TILE_W, lx = i - ly * TILE_W;
-        const int y = ty0 + ly, x = tx0 + lx;
-        if (y >= H || x >= W) continue;
-        float o[3];
+    const int lx = threadIdx.x & (TILE_W - 1), ly0 = (threadIdx.x / TILE_W) * 8;
+    const int x = tx0 + lx;
+    if (x >= W) return;
+    float res[8][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float p[3][3];
+    for (int c = 0; c < 3; ++c) {
+        float p[3][3];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) p[dy][dx] = tile[c][ly + dy][lx + dx];
-            o[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
+            for (int dx = 0; dx < 3; ++dx) p[dy + 1][dx] = tile[c][ly0 + dy][lx + dx];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                p[0][dx] = p[1][dx];
+                p[1][dx] = p[2][dx];
+                p[2][dx] = tile[c][ly0 + k + 2][lx + dx];
+            }
+            res[k][c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
         }
-        IO::store_stream(fout + (y * W + x), px3{o[0], o[1], o[2]});
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = ty0 + ly0 + k;
+        if (y < H) IO::store_stream(fout + (y * W + x), px3{res[k][0], res[k][1], res[k][2]});
     }
 }
 
