@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ i
     const float top = (float)(n - 1);
     const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
     const int nc = n - 1;
-    const int cell = (B.cell * nc + G.cell) * n + R.cell;
-    constexpr int STRIDE = MODE == 3 ? 16 : 12;   // floats per record
+    // MODE 4: cell-major table, one 128-byte aligned record per (b0, g0, r0) cell = all 24 corner values of the cell
+    const int cell = MODE == 4 ? (B.cell * nc + G.cell) * nc + R.cell : (B.cell * nc + G.cell) * n + R.cell;
+    constexpr int STRIDE = MODE == 4 ? 32 : (MODE == 3 ? 16 : 12);   // floats per record
     float acc = 0.0f;
-    if (MODE == 0 || MODE == 3 || MODE == 1) {
+    if (MODE == 0 || MODE == 3 || MODE == 1 || MODE == 4) {
         const f32x4* q = reinterpret_cast<const f32x4*>(cells + (size_t)cell * STRIDE);
         constexpr int NQ = MODE == 1 ? 3 : 6;
 #pragma unroll
@@ -158,14 +159,15 @@ int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode,
 }
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
-    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 3) return VRG_ERR_BAD_ARG;
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 4) return VRG_ERR_BAD_ARG;
     const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
     const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
     switch (mode) {
         case 0: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
         case 1: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
         case 2: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
-        default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        case 3: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
     }
     VRG_CHECK_LAUNCH();
     return VRG_OK;

@@ -249,7 +249,7 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
- * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 128-B record stride. */
+ * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records. */
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
 /* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
  * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,

@@ -283,8 +283,14 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             probe = torch.empty((px,), dtype=torch.float32, device=dev)
             wide = torch.zeros(((lut33.size - 1) ** 2 * lut33.size * 16 + 16,), dtype=torch.float32, device=dev)   # 64-B records for mode 3
             wide[:-16].view(-1, 16)[:, :12] = lut33.table.view(-1, 12)
+            nc = lut33.size - 1
+            recs = lut33.table.view(nc * nc, lut33.size, 12)
+            cellmajor = torch.zeros((nc * nc, nc, 32), dtype=torch.float32, device=dev)     # 128-B aligned record per cell (mode 4)
+            cellmajor[:, :, :12] = recs[:, :-1]
+            cellmajor[:, :, 12:24] = recs[:, 1:]
+            cellmajor = cellmajor.reshape(-1).contiguous()
             for src_name, src in (("uniform", x), ("smooth", smooth)):
-                for mode, tab in ((0, lut33.table), (1, lut33.table), (2, lut33.table), (3, wide)):
+                for mode, tab in ((0, lut33.table), (1, lut33.table), (2, lut33.table), (3, wide), (4, cellmajor)):
                     cases.append((f"probe lut fetch mode {mode} {src_name}", 16, (lambda m=mode, t=tab, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
                         _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), lut33.size, m, _hip.current_stream()), "probe"))))
         for name, bpp, fn in cases:

@@ -41,6 +41,16 @@ if which == "traffic":
     torch.cuda.synchronize()
     print("done traffic")
     sys.exit(0)
+if which == "l2":
+    # L2 request counts of the march vs the tile form, with and without the LUT / grain stages
+    import dataclasses
+    for name in ("sharpen", "lutsharp", "grainsharp", "chain3"):
+        for v in (1, 2):
+            ops.fused_chain(x, dataclasses.replace(specs[name], variant=v), generator=gen, out=out)
+    ops.lut3d(x, lut, 10.0)
+    torch.cuda.synchronize()
+    print("done l2")
+    sys.exit(0)
 if which == "issue":
     # calibration (known instruction count) + the kernels whose VALU instruction counts DESIGN.md quotes
     from comfyui_vrgamedevgirl_amd import _hip, VRGDG_LUTVideoTools as LVT
