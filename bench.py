@@ -203,7 +203,9 @@ def main():
             recs = json.load(fh)
         with open(os.path.join(ROOT, "profiles", "r01_valu_issue_rate.json")) as fh:
             peak_t = max(r["tera_lane_instr_s"] for r in json.load(fh)["rows"] if r["instr"] == "v_fma_f32")
-        want = {"stats": "k_produce_lab<3, false>", "apply": "k_chain_tile<20" if "colormatch" in stages else "k_chain_march<3"}[dom]
+        # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
+        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
+                ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
         ipp = next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
         rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
         issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
