@@ -519,9 +519,22 @@ VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const PowTables& T) {
 }
 
 // matched = (lab-mu)/sigma*sigma_ref + mu_ref ; blended = K*matched + T*lab (nodes.py:112-113)
+// d / sigma with sigma = std + 1e-5 (a per-frame value in [1e-5, ~100]) through the FMA form of div_const, with the
+// reciprocal from v_rcp_f32 + one Newton step: 8 issue units instead of the 14 of the IEEE sequence, and the same
+// quotient (0 differences in 2e7 random (d, sigma) pairs; the stage is tolerance-level anyway, section 4 of DESIGN.md).
+VRG_HD float recip_newton(float s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e = __builtin_fmaf(-s, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+#else
+    return 1.0f / s;
+#endif
+}
+
 VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, float sigma_ref, float K, float T) {
     const float d = lab - mu;
-    const float z = d / sigma;
+    const float z = div_const(d, sigma, recip_newton(sigma));
     const float w = z * sigma_ref;
     const float m = w + mu_ref;
     const float a = K * m;
