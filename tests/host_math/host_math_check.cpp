@@ -11,6 +11,8 @@
 #define VRG_HW_LOG2(x) log2f(x)
 #define VRG_HW_SIN_REV(x) sinf((x) * 6.28318530717958647692f)
 #define VRG_HW_COS_REV(x) cosf((x) * 6.28318530717958647692f)
+#define VRG_HW_EXP2(x) exp2f(x)
+#define VRG_HW_RCP(x) (1.0f / (x))
 #include "vrg_pixel_math.hpp"
 #include "vrg_adjust_math.hpp"
 
@@ -202,6 +204,8 @@ void hm_adjust(const float* in, float* out, int F, int H, int W, const float* t)
     delete[] a;
     delete[] b;
 }
+
+void hm_cbrt_pow(const float* x, float* o, int64_t n) { for (int64_t i = 0; i < n; ++i) o[i] = cbrt_pow(x[i]); }
 
 // uint8 codec edge
 void hm_u8_to_unit(const uint8_t* in, float* out, int64_t n) { for (int64_t i = 0; i < n; ++i) out[i] = unit_from_u8(in[i]); }

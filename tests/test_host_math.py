@@ -259,3 +259,19 @@ def test_u8_codec_edge_conversions(hm):
         got = np.empty(x.size, dtype=np.uint8)
         hm.hm_unit_to_u8(x, got, x.size)
         assert np.array_equal(got, np.clip(x * np.float32(255.0), 0, 255).astype(np.uint8))
+
+
+def test_cbrt_pow_is_correctly_rounded_on_its_domain(hm):
+    """cbrt_pow(x) = x ** float32(1/3) on the Lab domain: with libm stand-ins for the hardware log2 / exp2 / rcp estimates
+    (the Newton step squares their error away) the result equals the correctly rounded power; max error 0.5 ulp."""
+    hm.hm_cbrt_pow.argtypes = [F32P, F32P, C.c_int64]
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0.008856, 1.2, 1 << 20), np.exp(rng.uniform(np.log(0.008856), np.log(1.2), 1 << 20)),
+                        [0.008856, 1.0, 0.5, 0.125]]).astype(np.float32)
+    got = np.empty_like(x)
+    hm.hm_cbrt_pow(x, got, x.size)
+    truth = np.power(x.astype(np.float64), np.float64(np.float32(1.0 / 3.0)))
+    ulp = np.spacing(np.abs(truth).astype(np.float32)).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - truth) / ulp
+    assert err.max() <= 0.5001, err.max()
+    assert np.mean(got != truth.astype(np.float32)) < 1e-5
