@@ -1012,3 +1012,19 @@ def test_baseline_scale_batch_crosses_32bit_element_counts(ops, dev):
     whole = ops.adjust(x, t)
     for a, b in probes:
         assert torch.equal(ops.adjust(x[a:b], t), whole[a:b]), (a, b)
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 64])
+def test_lut_extreme_sizes(ops, dev, n):
+    """Smallest legal cubes (one or two cells per axis) and a large one (64^3: 9.4 MB of records, beyond one XCD's L2)."""
+    g = torch.Generator().manual_seed(n)
+    table = torch.rand((n, n, n, 3), generator=g)
+    data = {"size": n, "lut": table, "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}
+    x = torch.cat([_rand((2, 33, 47, 3), 5 + n, -0.2, 1.2).reshape(1, 1, -1, 3),
+                   torch.tensor([0.0, 1.0, 0.5, 1.0 / max(n - 1, 1), 0.999999]).repeat(3, 1).t().reshape(1, 1, -1, 3)], dim=2)
+    dlut = ops.upload_lut(data, dev)
+    for s in (10.0, 3.7):
+        assert_bit_equal(ops.lut3d(x.to(dev), dlut, s), R.apply_lut_with_strength(x, data, s), f"lut {n}^3 strength {s}")
+    u8 = torch.randint(0, 256, (2, 19, 23, 3), generator=g, dtype=torch.uint8)
+    got = ops.fused_chain(u8.to(dev), ops.ChainSpec(lut=(dlut, 10.0)))
+    _frames_eq(got.cpu().numpy(), R.tensor_to_frames(R.apply_lut_with_strength(R.frames_to_tensor(list(u8.numpy())), data, 10.0)), f"u8 lut {n}^3")
