@@ -225,15 +225,16 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
                     }
                     const int li = rowbase - E + offm[m];
                     const uint32_t idx = (uint32_t)(bo + M.s[m] + 3 * lane);   // subsequence of channel 0 (wraps to huge if negative)
-                    if (lane_out && (uint32_t)li < px_limit) {
-                        const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
-                        if (a0 && a1 && a2) {
-                            *reinterpret_cast<px3*>(cout + li) = px3{res[0], res[1], res[2]};
-                        } else {
-                            if (a0) cout[li] = res[0];
-                            if (a1) cout[li + 1] = res[1];
-                            if (a2) cout[li + 2] = res[2];
-                        }
+                    const bool act = lane_out && (uint32_t)li < px_limit;
+                    const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
+                    // wave-uniform split: in all but the rows that touch the end of the Philox quarter every active lane
+                    // stores a whole pixel -> one global_store_dwordx3 (the merged form costs a dword + a dwordx2 per pixel)
+                    if (__builtin_amdgcn_ballot_w64(act && !(a0 && a1 && a2)) == 0) {
+                        if (act) *reinterpret_cast<px3*>(cout + li) = px3{res[0], res[1], res[2]};
+                    } else if (act) {
+                        if (a0) cout[li] = res[0];
+                        if (a1) cout[li + 1] = res[1];
+                        if (a2) cout[li + 2] = res[2];
                     }
                 }
             }
@@ -248,15 +249,14 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
             for (int m = 0; m < 4; ++m) {
                 const int li = rowbase + offm[m];
                 const uint32_t idx = (uint32_t)(b0 + M.s[m] + 3 * lane);
-                if (lane_out && (uint32_t)li < px_limit) {
-                    const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
-                    if (a0 && a1 && a2) {
-                        *reinterpret_cast<px3*>(cout + li) = px3{Dn[m][0], Dn[m][1], Dn[m][2]};
-                    } else {
-                        if (a0) cout[li] = Dn[m][0];
-                        if (a1) cout[li + 1] = Dn[m][1];
-                        if (a2) cout[li + 2] = Dn[m][2];
-                    }
+                const bool act = lane_out && (uint32_t)li < px_limit;
+                const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
+                if (__builtin_amdgcn_ballot_w64(act && !(a0 && a1 && a2)) == 0) {
+                    if (act) *reinterpret_cast<px3*>(cout + li) = px3{Dn[m][0], Dn[m][1], Dn[m][2]};
+                } else if (act) {
+                    if (a0) cout[li] = Dn[m][0];
+                    if (a1) cout[li + 1] = Dn[m][1];
+                    if (a2) cout[li + 2] = Dn[m][2];
                 }
             }
         }
