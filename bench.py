@@ -190,7 +190,9 @@ def main():
         if summ.get(key, {}).get("total"):
             traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
             traffic_note = (f"GB per launch = {summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
-                            "FETCH_SIZE / WRITE_SIZE, separate passes, 16x4K frames, FETCH_SIZE x2 per the gfx950 calibration) x pixels")
+                            "FETCH_SIZE / WRITE_SIZE, separate passes, 16x4K frames, FETCH_SIZE x2 per the gfx950 calibration) x pixels"
+                            + ("; the written bytes are the Lab image kept for pass 2 (design choice measured in DESIGN.md section 3: "
+                               "40.3 vs 25.4 Gpix/s against the recomputing form), not re-reads" if key == "stats" else ""))
     except Exception:
         pass
 
