@@ -885,7 +885,7 @@ def hashlib_sha256(text):
 
 
 # ---------------------------------------------------------------------------------------- randomized sweep
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VRG_SWEEP_SEEDS", "24"))))
 def test_randomized_chain_and_adjust_sweep(ops, pkg, dev, seed):
     """Random shapes, stage subsets, strengths and slider sets (fixed seeds): fp32 and uint8 entry points against the
     CPU oracle, bit for bit.  Covers combinations the hand-written lists do not."""
