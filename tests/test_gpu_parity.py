@@ -1028,3 +1028,38 @@ def test_lut_extreme_sizes(ops, dev, n):
     u8 = torch.randint(0, 256, (2, 19, 23, 3), generator=g, dtype=torch.uint8)
     got = ops.fused_chain(u8.to(dev), ops.ChainSpec(lut=(dlut, 10.0)))
     _frames_eq(got.cpu().numpy(), R.tensor_to_frames(R.apply_lut_with_strength(R.frames_to_tensor(list(u8.numpy())), data, 10.0)), f"u8 lut {n}^3")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VRG_SWEEP_SEEDS", "16"))))
+def test_randomized_colour_match_chain_sweep(ops, pkg, dev, seed):
+    """Random shapes / reference batches / strengths for chains that contain colour match: within CM_ABS_TOL of the
+    oracle (the stage is tolerance-level: kornia unpinned, torch's own fp32 reductions), fused == stand-alone operators."""
+    import random
+    rnd = random.Random(5000 + seed)
+    H, W = rnd.randint(6, 80), rnd.randint(6, 120)
+    n_ref = rnd.choice([1, 1, 2, 3])
+    F = n_ref * rnd.randint(1, 3)
+    data, dlut = _lut_pair(ops, dev, rnd.choice(["AMD_TealOrange_33.cube", "AMD_WarmFilm_25.cube"]))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((F, H, W, 3), generator=g)
+    ref = torch.rand((n_ref, rnd.randint(4, 40), rnd.randint(4, 40), 3), generator=g)
+    k = round(rnd.uniform(0.05, 1.0), 2)
+    grain = (round(rnd.uniform(0.01, 0.2), 3), round(rnd.uniform(0, 1), 2), n_ref) if rnd.random() < 0.6 else None
+    lut_s = rnd.choice([10.0, 6.5]) if rnd.random() < 0.6 else None
+    sharpen = ("unsharp", round(rnd.uniform(0.1, 1.5), 2), False) if rnd.random() < 0.6 else None
+    ref_ms = ops.finalize_stats(ops.lab_stats(ref.to(dev)))
+    spec = ops.ChainSpec(grain=grain, lut=(dlut, lut_s) if lut_s is not None else None, colormatch=(ref_ms, k), sharpen=sharpen)
+    torch.manual_seed(seed)
+    got = ops.fused_chain(x.to(dev), spec)
+    torch.manual_seed(seed)
+    o = x
+    if grain:
+        o = R.fast_film_grain(o, grain[0], grain[1], grain[2], noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    if lut_s is not None:
+        o = R.apply_lut_with_strength(o, data, lut_s)
+    o = R.color_match(o, ref, k, n_ref).contiguous()
+    if sharpen:
+        o = R.unsharp(o, sharpen[1], False).contiguous()
+    err = (got.cpu() - o).abs().max().item()
+    amp = 1.0 + (sharpen[1] * 2 if sharpen else 0.0)           # unsharp amplifies a difference by up to 1 + 2*strength*(8/9)
+    assert err <= CM_ABS_TOL * amp, (seed, err, spec)
