@@ -342,6 +342,8 @@ static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) 
 
 int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st);
 bool produce_applicable(int stages, int64_t frame_elems);
+bool lut_lds_applicable(int lut_size, int64_t pixels);
+int launch_lut_lds(const void* in, void* out, int64_t pixels, const LutParams& P, bool u8, hipStream_t st);
 int64_t produce_scratch_bytes(const ChainK& D, int64_t frames, int64_t fe);
 int launch_produce(const float* in, float* lab_out, int64_t frames, int32_t H, int32_t W, const ChainK& D, int stages, double* stats,
                    void* scratch, hipStream_t st);
@@ -447,6 +449,8 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (variant == 0)
         variant = ((desc->stages & VRG_STAGE_GRAIN) && (desc->stages & VRG_STAGE_SHARPEN) && !(desc->stages & VRG_STAGE_COLORMATCH)) ? 2 : 1;
     if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
+    if ((desc->variant & 0xff) == 0 && desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
+        return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, false, (hipStream_t)stream);   // small cube: table in LDS
     if (desc->stages & VRG_STAGE_FROM_LAB)
         return launch_chain<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream);
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
@@ -467,6 +471,8 @@ int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t 
     if (rc) return rc;
     const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
+        return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, true, st);                      // small cube: table in LDS
     switch (desc->stages & 3) {
         case 0: return launch_chain<0, IoU8>(in, out, frames, height, width, D, sharpen, st);
         case 1: return launch_chain<1, IoU8>(in, out, frames, height, width, D, sharpen, st);

@@ -178,6 +178,90 @@ __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, flo
 }
 
 // ----------------------------------------------------------------------------------------------
+// Small cubes (N^3 * 16 B fits the LDS: N <= 21, e.g. the common 17^3): the whole LUT lives in LDS, one float4 per
+// grid node, and a pixel's eight corners are eight ds_read_b128 -- no trip through the L1 / L2 gather path that bounds
+// the global-memory kernel.  Persistent workgroups (as many as fit next to the table) walk the pixels grid-stride, so
+// the table is staged once per workgroup.  Same corner order and arithmetic as lut_pixel (bit-identical results).
+// The node values are read back out of the record table (vrg_lut_prepare_f32), so the ABI needs no second layout.
+// ----------------------------------------------------------------------------------------------
+template <class IO>
+__global__ __launch_bounds__(1024) void k_lut3d_lds(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
+                                                     int64_t pixels, LutParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds_nodes[];          // [b][g][r] x {R, G, B, pad}
+    const int n = P.n, nc = n - 1, nodes = n * n * n;
+    for (int i = threadIdx.x; i < nodes; i += 1024) {
+        const int r = i % n, g = (i / n) % n, b = i / (n * n);
+        const int b0 = b < nc ? b : nc - 1, g0 = g < nc ? g : nc - 1;
+        const int k = (g - g0) * 2 + (b - b0);
+        const float* rec = P.cells + (size_t)((b0 * nc + g0) * n + r) * LUT_REC_FLOATS;
+        f32x4 v;
+        v.x = rec[k]; v.y = rec[4 + k]; v.z = rec[8 + k]; v.w = 0.0f;
+        reinterpret_cast<f32x4*>(lds_nodes)[i] = v;
+    }
+    __syncthreads();
+    const f32x4* T = reinterpret_cast<const f32x4*>(lds_nodes);
+    for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 1024) {
+        const px3 v = IO::load_stream(in + p);
+        const float x[3] = {v.r, v.g, v.b};
+        const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
+        const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
+        const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
+        const int base = (B.cell * n + G.cell) * n + R.cell;
+        const f32x4 q000 = T[base], q001 = T[base + n * n];                    // (g0, b0), (g0, b1) at red r0
+        const f32x4 q010 = T[base + n], q011 = T[base + n * n + n];            // (g1, b0), (g1, b1)
+        const f32x4 q100 = T[base + 1], q101 = T[base + n * n + 1];            // red r0 + 1
+        const f32x4 q110 = T[base + n + 1], q111 = T[base + n * n + n + 1];
+        float y[3];
+#define VRG_LDS_LERP(CH)                                                                       \
+        {                                                                                      \
+            const float c00 = lerp2(q000.CH, B.u, q001.CH, B.f);                               \
+            const float c01 = lerp2(q010.CH, B.u, q011.CH, B.f);                               \
+            const float c10 = lerp2(q100.CH, B.u, q101.CH, B.f);                               \
+            const float c11 = lerp2(q110.CH, B.u, q111.CH, B.f);                               \
+            const float c0 = lerp2(c00, G.u, c01, G.f);                                        \
+            const float c1 = lerp2(c10, G.u, c11, G.f);                                        \
+            yy = clamp01_finite(lerp2(c0, R.u, c1, R.f));                                      \
+        }
+        float yy;
+        VRG_LDS_LERP(x) y[0] = yy;
+        VRG_LDS_LERP(y) y[1] = yy;
+        VRG_LDS_LERP(z) y[2] = yy;
+#undef VRG_LDS_LERP
+        float o[3];
+        if (P.blend_mode == 2) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) o[ch] = lerp2(x[ch], P.one_minus_blend, y[ch], P.blend);
+        } else {
+            o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
+        }
+        IO::store_stream(out + p, px3{o[0], o[1], o[2]});
+    }
+}
+
+// the table must fit the LDS next to nothing else, and there must be enough pixels to pay for staging it
+bool lut_lds_applicable(int lut_size, int64_t pixels) {
+    return (size_t)lut_size * lut_size * lut_size * 16 <= 152 * 1024 && pixels >= (1 << 16);
+}
+
+template <class IO>
+static int launch_lut_lds_t(const void* in, void* out, int64_t pixels, const LutParams& P, hipStream_t st) {
+    const size_t lds_bytes = (size_t)P.n * P.n * P.n * 16;
+    int32_t cus = 0, tpc = 0;
+    if (vrg_device_info(&cus, &tpc) != VRG_OK) return VRG_ERR_NO_DEVICE;
+    const int per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;      // persistent 1024-thread workgroups, as many per CU as fit
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lut3d_lds<IO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
+        hipSuccess)
+        return VRG_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_lut3d_lds<IO>, dim3((uint32_t)(cus * per_cu)), dim3(1024), lds_bytes, st,
+                       reinterpret_cast<const typename IO::elem*>(in), reinterpret_cast<typename IO::elem*>(out), pixels, P);
+    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+}
+
+int launch_lut_lds(const void* in, void* out, int64_t pixels, const LutParams& P, bool u8, hipStream_t st) {
+    return u8 ? launch_lut_lds_t<IoU8>(in, out, pixels, P, st) : launch_lut_lds_t<IoF32>(in, out, pixels, P, st);
+}
+
+// ----------------------------------------------------------------------------------------------
 // Colour-match apply (pass 2).  ms arrays: [frame][3][2] = {mean, std + 1e-5}.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict__ in, px3* __restrict__ out,
@@ -284,7 +368,9 @@ int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels,
     const LutParams P = make_lut(lut, lut_size, domain_min, domain_max, blend_mode, blend, one_minus_blend);
     const uint64_t blocks = (uint64_t)(pixels + 255) / 256;
     if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
-    if (channels == 3)
+    if (channels == 3 && lut_lds_applicable(lut_size, pixels)) {
+        return launch_lut_lds(in, out, pixels, P, false, (hipStream_t)stream);      // LDS-resident table
+    } else if (channels == 3)
         hipLaunchKernelGGL(k_lut3d<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, pixels, channels, P);
     else
         hipLaunchKernelGGL(k_lut3d<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, pixels, channels, P);

@@ -1063,3 +1063,37 @@ def test_randomized_colour_match_chain_sweep(ops, pkg, dev, seed):
     err = (got.cpu() - o).abs().max().item()
     amp = 1.0 + (sharpen[1] * 2 if sharpen else 0.0)           # unsharp amplifies a difference by up to 1 + 2*strength*(8/9)
     assert err <= CM_ABS_TOL * amp, (seed, err, spec)
+
+
+@pytest.mark.parametrize("n", [2, 5, 9, 17, 21, 22])
+def test_lut_lds_resident_path(ops, dev, n):
+    """Cubes whose node table fits the LDS (N <= 21) take the LDS-resident kernel once there are >= 65536 pixels;
+    22^3 is the first size that stays on the global-memory gather kernel.  Both must equal the oracle bit for bit,
+    for unit and non-unit domains and for blended strengths."""
+    g = torch.Generator().manual_seed(100 + n)
+    table = torch.rand((n, n, n, 3), generator=g)
+    x = torch.cat([_rand((2, 200, 170, 3), 9 + n, -0.2, 1.3).reshape(1, 1, -1, 3),
+                   torch.tensor([0.0, 1.0, 0.5, 1.0 / max(n - 1, 1), 0.999999]).repeat(3, 1).t().reshape(1, 1, -1, 3)], dim=2)
+    assert x.shape[2] >= 65536
+    for dmin, dmax in ((torch.zeros(3), torch.ones(3)), (torch.tensor([-0.25, 0.0, 0.125]), torch.tensor([1.5, 1.0, 0.875]))):
+        data = {"size": n, "lut": table, "domain_min": dmin, "domain_max": dmax}
+        dlut = ops.upload_lut(data, dev)
+        for s in (10.0, 4.2):
+            assert_bit_equal(ops.lut3d(x.to(dev), dlut, s), R.apply_lut_with_strength(x, data, s), f"lut {n}^3 strength {s}")
+
+
+def test_lut_lds_resident_path_uint8_and_chain_entry(ops, dev):
+    """The LDS-resident small-cube kernel behind the fused-chain entry points (LUT-only chains on fp32 and on uint8 frames:
+    the route's _process_video_batch and the opening colour match use exactly this with 17^3 cubes)."""
+    data, dlut = _lut_pair(ops, dev, "AMD_Identity_17.cube")
+    g = torch.Generator().manual_seed(17)
+    table = torch.rand((17, 17, 17, 3), generator=g)
+    data2 = {"size": 17, "lut": table, "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}
+    dlut2 = ops.upload_lut(data2, dev)
+    u8 = torch.randint(0, 256, (3, 160, 200, 3), generator=g, dtype=torch.uint8)          # 96,000 pixels >= 65,536
+    x = R.frames_to_tensor(list(u8.numpy()))
+    for d, dl in ((data, dlut), (data2, dlut2)):
+        for s in (10.0, 3.3):
+            want = R.apply_lut_with_strength(x, d, s)
+            assert_bit_equal(ops.fused_chain(x.to(dev), ops.ChainSpec(lut=(dl, s))), want, f"chain entry, LDS LUT, strength {s}")
+            _frames_eq(ops.fused_chain(u8.to(dev), ops.ChainSpec(lut=(dl, s))).cpu().numpy(), R.tensor_to_frames(want), f"u8 LDS LUT {s}")

@@ -197,6 +197,8 @@ def kernel_bench(ops, frames_4k, iters, match=""):
     rows = []
     lut33 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
     lut25 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_WarmFilm_25.cube")), dev)
+    lut17 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_Identity_17.cube")), dev)
+    lut21 = ops.upload_lut({"lut": torch.rand(21, 21, 21, 3), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}, dev)
     for label, H, W, F in (("4K", 2160, 3840, frames_4k), ("1080p", 1080, 1920, frames_4k * 4)):
         g = torch.Generator(device=dev).manual_seed(3)
         x = torch.rand((F, H, W, 3), generator=g, device=dev)
@@ -217,6 +219,9 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             ("lut33 uniform", 24, lambda: ops.lut3d(x, lut33, 10.0)),
             ("lut33 smooth", 24, lambda: ops.lut3d(smooth, lut33, 10.0)),
             ("lut25 uniform", 24, lambda: ops.lut3d(x, lut25, 10.0)),
+            ("lut17 uniform (LDS-resident table)", 24, lambda: ops.lut3d(x, lut17, 10.0)),
+            ("lut21 uniform (LDS-resident table)", 24, lambda: ops.lut3d(x, lut21, 10.0)),
+            ("lut17 smooth (LDS-resident table)", 24, lambda: ops.lut3d(smooth, lut17, 10.0)),
             ("lut33 blend 0.5", 24, lambda: ops.lut3d(x, lut33, 5.0)),
             ("unsharp replicate", 24, lambda: ops.stencil3x3(x, "unsharp", 0.5, False)),
             ("unsharp zero", 24, lambda: ops.stencil3x3(x, "unsharp", 0.5, True)),
