@@ -246,8 +246,9 @@ bool lut_lds_applicable(int lut_size, int64_t pixels) {
 template <class IO>
 static int launch_lut_lds_t(const void* in, void* out, int64_t pixels, const LutParams& P, hipStream_t st) {
     const size_t lds_bytes = (size_t)P.n * P.n * P.n * 16;
-    int32_t cus = 0, tpc = 0;
-    if (vrg_device_info(&cus, &tpc) != VRG_OK) return VRG_ERR_NO_DEVICE;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return VRG_ERR_NO_DEVICE;
     const int per_cu = lds_bytes <= 78 * 1024 ? 2 : 1;      // persistent 1024-thread workgroups, as many per CU as fit
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lut3d_lds<IO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) !=
         hipSuccess)
