@@ -9,7 +9,7 @@ namespace vrg {
 // grain (with the pixel's three raw normals n) -> LUT -> colour match for a pixel of frame f (of this call)
 template <int STAGES>
 __device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, const float xin[3], const float n[3], float o[3],
-                                                   const PowTables& PT) {
+                                                   const PowTables& PT, const f32x4* lut_nodes = nullptr) {
     float v[3] = {xin[0], xin[1], xin[2]};
     if (STAGES & VRG_STAGE_GRAIN) {
         float g[3];
@@ -18,7 +18,8 @@ __device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, c
     }
     if (STAGES & VRG_STAGE_LUT) {
         float g[3];
-        lut_pixel(D.lut, v, g);
+        if (lut_nodes) lut_pixel_nodes(D.lut, lut_nodes, v, g);      // small cube staged in LDS by the kernel (uniform choice)
+        else lut_pixel(D.lut, v, g);
         v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
     }
     if (STAGES & VRG_STAGE_COLORMATCH) {

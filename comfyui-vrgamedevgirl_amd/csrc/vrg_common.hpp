@@ -60,6 +60,21 @@ struct IoU8 {
     static __device__ __forceinline__ void store_stream(elem* p, const px3& v) { store(p, v); }
 };
 
+// Stage the node table of a small cube into LDS (one float4 per node) from the record table of vrg_lut_prepare_f32.
+// Every thread of the workgroup must call it; the caller synchronises afterwards.
+__device__ __forceinline__ void lut_nodes_to_lds(const LutParams& P, f32x4* nodes, int tid, int nthreads) {
+    const int n = P.n, nc = n - 1, total = n * n * n;
+    for (int i = tid; i < total; i += nthreads) {
+        const int r = i % n, g = (i / n) % n, b = i / (n * n);
+        const int b0 = b < nc ? b : nc - 1, g0 = g < nc ? g : nc - 1;
+        const int k = (g - g0) * 2 + (b - b0);
+        const float* rec = P.cells + (size_t)((b0 * nc + g0) * n + r) * LUT_REC_FLOATS;
+        f32x4 v;
+        v.x = rec[k]; v.y = rec[4 + k]; v.z = rec[8 + k]; v.w = 0.0f;
+        nodes[i] = v;
+    }
+}
+
 // Device copy of vrg_noise_desc plus the per-call geometry the noise mapping needs.
 struct NoiseK {
     uint64_t seed0, seed_stride, off0, off_stride;

@@ -54,19 +54,26 @@ __global__ void k_selftest_lanes(float* out) {
     out[64 + threadIdx.x] = lane_next(v);
 }
 
-template <int STAGES, bool SHARPEN>
-__global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
+// WAVES = 4: one job per wave, nothing shared.  WAVES = 12 (LUT stage with a cube of at most 21^3): the workgroup first
+// stages the cube's node table in LDS (dynamic shared memory, one float4 per node) and the gathers of the LUT stage
+// become ds_read_b128 -- the L1 / L2 gather path that holds the global-table form at ~65 Gpix/s is not used at all.
+template <int STAGES, bool SHARPEN, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
     __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
-    if (STAGES & VRG_STAGE_COLORMATCH) {
-        pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
-        __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) float march_lut_nodes[];
+    const f32x4* lut_nodes = nullptr;
+    if (WAVES != 4) {
+        lut_nodes_to_lds(D.lut, reinterpret_cast<f32x4*>(march_lut_nodes), (int)threadIdx.x, 64 * WAVES);
+        lut_nodes = reinterpret_cast<const f32x4*>(march_lut_nodes);
     }
+    if (STAGES & VRG_STAGE_COLORMATCH) pow_tables_fill(pow_lds, (int)threadIdx.x, 64 * WAVES);
+    if ((STAGES & VRG_STAGE_COLORMATCH) || WAVES != 4) __syncthreads();
     const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
 
     constexpr int CLO = SHARPEN ? 1 : 0;     // first lane that produces output
     constexpr int CW = SHARPEN ? 61 : 63;    // output lanes per wave (lane 63 only provides noise)
     const int lane = threadIdx.x & 63;
-    const uint32_t job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    const uint32_t job = __builtin_amdgcn_readfirstlane(blockIdx.x * (uint32_t)WAVES + (threadIdx.x >> 6));
     const uint32_t jobs_per_chunk = M.K * M.T;
     const uint32_t chunk = job / jobs_per_chunk;
     if (chunk >= M.chunks) return;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
             int fidx = fc[m];
             fidx = fidx < 0 ? 0 : (fidx > M.chunk_frames - 1 ? M.chunk_frames - 1 : fidx);
             float o[3];
-            chain_apply_stages<STAGES>(D, (int64_t)chunk * M.chunk_frames + fidx, x, n, o, PT);
+            chain_apply_stages<STAGES>(D, (int64_t)chunk * M.chunk_frames + fidx, x, n, o, PT, lut_nodes);
             Dn[m][0] = valid ? o[0] : 0.0f; Dn[m][1] = valid ? o[1] : 0.0f; Dn[m][2] = valid ? o[2] : 0.0f;
             xin[m] = xnext[m];
         }
@@ -270,6 +277,18 @@ __global__ __launch_bounds__(256) void k_chain_march(const float* __restrict__ i
 template <int STAGES, bool SHARPEN>
 static int launch_march_t(const float* in, float* out, const MarchK& M, const ChainK& D, hipStream_t st) {
     const uint64_t jobs = (uint64_t)M.chunks * M.K * M.T;
+    const size_t lut_bytes = (STAGES & VRG_STAGE_LUT) ? (size_t)D.lut.n * D.lut.n * D.lut.n * 16 : 0;
+    if ((STAGES & VRG_STAGE_LUT) && !(STAGES & VRG_STAGE_COLORMATCH) && lut_bytes <= 152 * 1024 && jobs >= 3072) {
+        // small cube: node table in LDS, 12-wave workgroups (one per CU next to the table)
+        constexpr int WV = 12;
+        const uint64_t blocks = (jobs + WV - 1) / WV;
+        if (blocks >= (1ull << 22)) return VRG_ERR_UNSUPPORTED;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_march<STAGES, SHARPEN, WV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lut_bytes) != hipSuccess)
+            return VRG_ERR_LAUNCH;
+        hipLaunchKernelGGL((k_chain_march<STAGES, SHARPEN, WV>), dim3((uint32_t)blocks), dim3(64 * WV), lut_bytes, st, in, out, M, D);
+        return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+    }
     const uint64_t blocks = (jobs + 3) / 4;
     if (blocks >= (1ull << 24)) return VRG_ERR_UNSUPPORTED;      // work-items per launch are counted in 32 bits
     hipLaunchKernelGGL((k_chain_march<STAGES, SHARPEN>), dim3((uint32_t)blocks), dim3(256), 0, st, in, out, M, D);

@@ -290,6 +290,41 @@ VRG_HD void lut_pixel_raw(const LutParams& P, const float x[3], float y[3]) {
     }
 }
 
+// Same pixel from a node table held in LDS (one float4 {R, G, B, pad} per grid node, index [b][g][r]): cubes up to 21^3.
+// Corner order and arithmetic are those of lut_pixel_raw, so the result is bit-identical.
+VRG_HD void lut_pixel_nodes(const LutParams& P, const f32x4* T, const float x[3], float o[3]) {
+    const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
+    const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
+    const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
+    const int n = P.n;
+    const int base = (B.cell * n + G.cell) * n + R.cell;
+    const f32x4 q000 = T[base], q001 = T[base + n * n];                    // (g0, b0), (g0, b1) at red r0
+    const f32x4 q010 = T[base + n], q011 = T[base + n * n + n];            // (g1, b0), (g1, b1)
+    const f32x4 q100 = T[base + 1], q101 = T[base + n * n + 1];            // red r0 + 1
+    const f32x4 q110 = T[base + n + 1], q111 = T[base + n * n + n + 1];
+    float y[3];
+#define VRG_NODE_LERP(CH, DST)                                                         \
+    {                                                                                  \
+        const float c00 = lerp2(q000.CH, B.u, q001.CH, B.f);                           \
+        const float c01 = lerp2(q010.CH, B.u, q011.CH, B.f);                           \
+        const float c10 = lerp2(q100.CH, B.u, q101.CH, B.f);                           \
+        const float c11 = lerp2(q110.CH, B.u, q111.CH, B.f);                           \
+        const float c0 = lerp2(c00, G.u, c01, G.f);                                    \
+        const float c1 = lerp2(c10, G.u, c11, G.f);                                    \
+        DST = clamp01_finite(lerp2(c0, R.u, c1, R.f));                                 \
+    }
+    VRG_NODE_LERP(x, y[0])
+    VRG_NODE_LERP(y, y[1])
+    VRG_NODE_LERP(z, y[2])
+#undef VRG_NODE_LERP
+    if (P.blend_mode == 2) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch] = lerp2(x[ch], P.one_minus_blend, y[ch], P.blend);
+    } else {
+        o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
+    }
+}
+
 VRG_HD void lut_pixel(const LutParams& P, const float x[3], float o[3]) {
     float y[3];
     lut_pixel_raw(P, x, y);

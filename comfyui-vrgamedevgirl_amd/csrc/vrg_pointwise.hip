@@ -188,52 +188,14 @@ template <class IO>
 __global__ __launch_bounds__(1024) void k_lut3d_lds(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
                                                      int64_t pixels, LutParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds_nodes[];          // [b][g][r] x {R, G, B, pad}
-    const int n = P.n, nc = n - 1, nodes = n * n * n;
-    for (int i = threadIdx.x; i < nodes; i += 1024) {
-        const int r = i % n, g = (i / n) % n, b = i / (n * n);
-        const int b0 = b < nc ? b : nc - 1, g0 = g < nc ? g : nc - 1;
-        const int k = (g - g0) * 2 + (b - b0);
-        const float* rec = P.cells + (size_t)((b0 * nc + g0) * n + r) * LUT_REC_FLOATS;
-        f32x4 v;
-        v.x = rec[k]; v.y = rec[4 + k]; v.z = rec[8 + k]; v.w = 0.0f;
-        reinterpret_cast<f32x4*>(lds_nodes)[i] = v;
-    }
+    lut_nodes_to_lds(P, reinterpret_cast<f32x4*>(lds_nodes), (int)threadIdx.x, 1024);
     __syncthreads();
     const f32x4* T = reinterpret_cast<const f32x4*>(lds_nodes);
     for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 1024) {
         const px3 v = IO::load_stream(in + p);
         const float x[3] = {v.r, v.g, v.b};
-        const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
-        const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
-        const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
-        const int base = (B.cell * n + G.cell) * n + R.cell;
-        const f32x4 q000 = T[base], q001 = T[base + n * n];                    // (g0, b0), (g0, b1) at red r0
-        const f32x4 q010 = T[base + n], q011 = T[base + n * n + n];            // (g1, b0), (g1, b1)
-        const f32x4 q100 = T[base + 1], q101 = T[base + n * n + 1];            // red r0 + 1
-        const f32x4 q110 = T[base + n + 1], q111 = T[base + n * n + n + 1];
-        float y[3];
-#define VRG_LDS_LERP(CH)                                                                       \
-        {                                                                                      \
-            const float c00 = lerp2(q000.CH, B.u, q001.CH, B.f);                               \
-            const float c01 = lerp2(q010.CH, B.u, q011.CH, B.f);                               \
-            const float c10 = lerp2(q100.CH, B.u, q101.CH, B.f);                               \
-            const float c11 = lerp2(q110.CH, B.u, q111.CH, B.f);                               \
-            const float c0 = lerp2(c00, G.u, c01, G.f);                                        \
-            const float c1 = lerp2(c10, G.u, c11, G.f);                                        \
-            yy = clamp01_finite(lerp2(c0, R.u, c1, R.f));                                      \
-        }
-        float yy;
-        VRG_LDS_LERP(x) y[0] = yy;
-        VRG_LDS_LERP(y) y[1] = yy;
-        VRG_LDS_LERP(z) y[2] = yy;
-#undef VRG_LDS_LERP
         float o[3];
-        if (P.blend_mode == 2) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) o[ch] = lerp2(x[ch], P.one_minus_blend, y[ch], P.blend);
-        } else {
-            o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
-        }
+        lut_pixel_nodes(P, T, x, o);
         IO::store_stream(out + p, px3{o[0], o[1], o[2]});
     }
 }

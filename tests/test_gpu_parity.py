@@ -1097,3 +1097,32 @@ def test_lut_lds_resident_path_uint8_and_chain_entry(ops, dev):
             want = R.apply_lut_with_strength(x, d, s)
             assert_bit_equal(ops.fused_chain(x.to(dev), ops.ChainSpec(lut=(dl, s))), want, f"chain entry, LDS LUT, strength {s}")
             _frames_eq(ops.fused_chain(u8.to(dev), ops.ChainSpec(lut=(dl, s))).cpu().numpy(), R.tensor_to_frames(want), f"u8 LDS LUT {s}")
+
+
+@pytest.mark.parametrize("lut_name", ["AMD_Identity_17.cube", None])
+def test_march_with_lds_resident_lut(ops, dev, lut_name):
+    """grain -> LUT -> sharpen with a cube of at most 21^3 on enough frames: the march kernel stages the node table in
+    LDS (12-wave workgroups).  Must equal the LDS-tile kernel with the global record table (itself oracle-checked) and,
+    on a slab, the CPU oracle."""
+    if lut_name is None:
+        g = torch.Generator().manual_seed(3)
+        data = {"size": 21, "lut": torch.rand((21, 21, 21, 3), generator=g), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}
+        dlut = ops.upload_lut(data, dev)
+    else:
+        data, dlut = _lut_pair(ops, dev, lut_name)
+    gd = torch.Generator(device=dev).manual_seed(12)
+    x = torch.rand((8, 2160, 3840, 3), generator=gd, device=dev)
+    for grain in ((0.05, 0.5, 4), None):
+        for sharpen in (("unsharp", 0.6, False), None):
+            if grain is None and sharpen is None:
+                continue
+            gen = torch.Generator(device=dev).manual_seed(5)
+            a = ops.fused_chain(x, ops.ChainSpec(grain=grain, lut=(dlut, 8.5), sharpen=sharpen, variant=2), generator=gen)
+            gen = torch.Generator(device=dev).manual_seed(5)
+            b = ops.fused_chain(x, ops.ChainSpec(grain=grain, lut=(dlut, 8.5), sharpen=sharpen, variant=1), generator=gen)
+            assert torch.equal(a, b), (grain, sharpen)
+            del b
+    cpu = x[0:1, 0:4].cpu()
+    want = R.unsharp(R.apply_lut_with_strength(cpu, data, 10.0), 0.5, False)
+    got = ops.fused_chain(x, ops.ChainSpec(lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=2))
+    assert torch.equal(got[0, 0:3].cpu(), want[0, 0:3])

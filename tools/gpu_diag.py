@@ -235,6 +235,9 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             ("fused lut+sharpen smooth", 24, chain(ops.ChainSpec(lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)), smooth)),
             ("fused grain+lut", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0)))),
             ("fused grain+lut+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), sharpen=("unsharp", 0.5, False)))),
+            ("fused grain+lut17+sharpen (LUT in LDS)", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False)))),
+            ("fused lut17+sharpen march (LUT in LDS)", 24, chain(ops.ChainSpec(lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False), variant=2))),
+            ("fused lut17+sharpen tile (global LUT)", 24, chain(ops.ChainSpec(lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False), variant=1))),
             ("fused grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)))),
             ("fused 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)))),
             ("v1 tile sharpen only", 24, chain(ops.ChainSpec(sharpen=("unsharp", 0.5, False), variant=1))),
