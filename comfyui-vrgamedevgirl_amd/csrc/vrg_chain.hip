@@ -446,8 +446,14 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     // bound and the march wins (Philox shared across four strips, no LDS); point-wise chains, chains without
     // grain and the colour-match apply pass run faster on the higher-occupancy tile / point-wise kernels.
     int variant = desc->variant & 0xff;
-    if (variant == 0)
+    if (variant == 0) {
         variant = ((desc->stages & VRG_STAGE_GRAIN) && (desc->stages & VRG_STAGE_SHARPEN) && !(desc->stages & VRG_STAGE_COLORMATCH)) ? 2 : 1;
+        // a cube of at most 21^3 lives in LDS inside the march kernel: no gather path, so it also wins for LUT -> sharpen
+        // (126 vs 66 Gpix/s with a 17^3 cube) and grain -> LUT (118 vs 70); LUT-only chains take k_lut3d_lds below
+        if ((desc->stages & VRG_STAGE_LUT) && !(desc->stages & VRG_STAGE_COLORMATCH) && desc->stages != VRG_STAGE_LUT &&
+            lut_lds_applicable(desc->lut_size, frames * (int64_t)height * width) && frames * (int64_t)height * width >= (1 << 22))
+            variant = 2;
+    }
     if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
     if ((desc->variant & 0xff) == 0 && desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
         return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, false, (hipStream_t)stream);   // small cube: table in LDS

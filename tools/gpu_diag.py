@@ -238,6 +238,9 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             ("fused grain+lut17+sharpen (LUT in LDS)", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False)))),
             ("fused lut17+sharpen march (LUT in LDS)", 24, chain(ops.ChainSpec(lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False), variant=2))),
             ("fused lut17+sharpen tile (global LUT)", 24, chain(ops.ChainSpec(lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False), variant=1))),
+            ("fused grain+lut17 auto", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut17, 10.0)))),
+            ("fused grain+lut17 pointwise (global LUT)", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut17, 10.0), variant=1))),
+            ("fused lut17+sharpen auto", 24, chain(ops.ChainSpec(lut=(lut17, 10.0), sharpen=("unsharp", 0.5, False)))),
             ("fused grain+sharpen", 24, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)))),
             ("fused 4-stage", 36, chain(ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut33, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)))),
             ("v1 tile sharpen only", 24, chain(ops.ChainSpec(sharpen=("unsharp", 0.5, False), variant=1))),
