@@ -1122,6 +1122,10 @@ def test_march_with_lds_resident_lut(ops, dev, lut_name):
             b = ops.fused_chain(x, ops.ChainSpec(grain=grain, lut=(dlut, 8.5), sharpen=sharpen, variant=1), generator=gen)
             assert torch.equal(a, b), (grain, sharpen)
             del b
+            gen = torch.Generator(device=dev).manual_seed(5)
+            c = ops.fused_chain(x, ops.ChainSpec(grain=grain, lut=(dlut, 8.5), sharpen=sharpen), generator=gen)      # automatic choice
+            assert torch.equal(a, c), (grain, sharpen, "auto")
+            del c
     cpu = x[0:1, 0:4].cpu()
     want = R.unsharp(R.apply_lut_with_strength(cpu, data, 10.0), 0.5, False)
     got = ops.fused_chain(x, ops.ChainSpec(lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=2))
