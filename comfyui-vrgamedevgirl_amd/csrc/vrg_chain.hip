@@ -451,7 +451,7 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
         // a cube of at most 21^3 lives in LDS inside the march kernel: no gather path, so it also wins for LUT -> sharpen
         // (126 vs 66 Gpix/s with a 17^3 cube) and grain -> LUT (118 vs 70); LUT-only chains take k_lut3d_lds below
         if ((desc->stages & VRG_STAGE_LUT) && !(desc->stages & VRG_STAGE_COLORMATCH) && desc->stages != VRG_STAGE_LUT &&
-            lut_lds_applicable(desc->lut_size, frames * (int64_t)height * width) && frames * (int64_t)height * width >= (1 << 22))
+            lut_lds_applicable(desc->lut_size, frames * (int64_t)height * width) && frames * (int64_t)height * width >= 24000000ll)   // enough strips for 12-wave workgroups on every CU
             variant = 2;
     }
     if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);

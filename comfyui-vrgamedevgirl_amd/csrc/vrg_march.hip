@@ -278,7 +278,7 @@ template <int STAGES, bool SHARPEN>
 static int launch_march_t(const float* in, float* out, const MarchK& M, const ChainK& D, hipStream_t st) {
     const uint64_t jobs = (uint64_t)M.chunks * M.K * M.T;
     const size_t lut_bytes = (STAGES & VRG_STAGE_LUT) ? (size_t)D.lut.n * D.lut.n * D.lut.n * 16 : 0;
-    if ((STAGES & VRG_STAGE_LUT) && !(STAGES & VRG_STAGE_COLORMATCH) && lut_bytes <= 152 * 1024 && jobs >= 3072) {
+    if ((STAGES & VRG_STAGE_LUT) && !(STAGES & VRG_STAGE_COLORMATCH) && lut_bytes <= 152 * 1024 && jobs >= 1536) {
         // small cube: node table in LDS, 12-wave workgroups (one per CU next to the table)
         constexpr int WV = 12;
         const uint64_t blocks = (jobs + WV - 1) / WV;
