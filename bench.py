@@ -10,9 +10,14 @@ reference frame (k=1) -> Fast Unsharp (0.5, edge-replicate).  A step = one pass 
 batch: reference-frame statistics (rows split across ranks + all-reduce when N>1), the statistics pass over the
 batch, and the fused apply pass.  Weak scaling: per-GPU work is fixed, value = all ranks' pixels / max time.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fused apply pass, 24 B/px
-algorithmic: 12 read + 12 written), timed with HIP events on the stream it is launched on; `cpu_baseline` is the
-oracle (a port of the reference's eager torch/numpy ops) on the host cores over a bounded sample.
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the step, timed with HIP events on the stream
+it is launched on; `cpu_baseline` times the reference's own node classes on the host cores where the reference checkout
+exists (the build container: kind "reference"), otherwise the oracle port of them (kind "port"), on a bounded sample.
+
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under `python -m torch.distributed.run` (one rank
+per GPU, RCCL); it fails loudly when fewer than N GPUs are visible.  Colour-match arithmetic: the default "device" policy
+(bit-equal to torch-ROCm's element-wise ops); the "fast" policy is timed next to it and reported
+under `fast_variant`, never as `value`.
 """
 from __future__ import annotations
 
@@ -47,8 +52,30 @@ def parse_args():
     ap.add_argument("--workload", default="chain4_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--dist", default="uniform", choices=["uniform", "video"], help="synthetic pixel distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="4K frames of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="4K frames of the bounded CPU-baseline sample (x4 at 1080p)")
+    ap.add_argument("--no-fast-variant", action="store_true", help="skip the extra timing of the fast colour-match policy")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible to PyTorch-ROCm; "
+                         "refusing to print a line for fewer GPUs than asked for\n")
+        raise SystemExit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def make_frames(n, H, W, dev, seed, dist):
@@ -71,31 +98,63 @@ def make_frames(n, H, W, dev, seed, dist):
     return x
 
 
-def cpu_baseline(stages, cpu_frames, H, W, lut_cpu):
-    """Oracle (port of the reference's eager ops) on the host cores, bounded sample."""
-    from oracle import restated as R
+def _median_time(fn, warmup=1, reps=3):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(stages, cpu_frames, H, W, lut_cpu, per_node=False):
+    """The chain on the host cores over a bounded sample: warm-up 1, median of 3.  kind "reference": the reference's own
+    node classes (FastFilmGrain / VRGDG_LUTS / ColorMatchToReference / FastUnsharpSharpen, stub-loaded by
+    oracle/reference_loader.py; kornia's Lab transforms are the restated ones) -- only where the reference checkout exists,
+    i.e. not on the GPU box; kind "port": oracle/restated.py, the op-for-op port of them."""
+    from oracle import reference_loader as RL
     g = torch.Generator().manual_seed(7)
     x = torch.rand((cpu_frames, H, W, 3), generator=g)
     ref = torch.rand((1, H, W, 3), generator=g)
-    t0 = time.perf_counter()
-    y = x
-    if "grain" in stages:
-        y = R.fast_film_grain(y, 0.04, 0.5, 4)
-    if "lut" in stages:
-        y = R.apply_lut_with_strength(y, lut_cpu, 10.0)
-    if "colormatch" in stages:
-        y = R.color_match(y, ref, 1.0, 1)
-    if "sharpen" in stages:
-        y = R.unsharp(y, 0.5, False)
-    dt = time.perf_counter() - t0
     mpix = cpu_frames * H * W / 1e6
-    return {"value": round(mpix / dt, 2), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{cpu_frames} frames {W}x{H}, same chain via oracle/restated.py (torch-CPU eager ops, numpy unsharp is "
-                      f"single-threaded), {dt:.1f} s, host os.cpu_count()={os.cpu_count()}"}
+    if RL.reference_available():
+        nodes, iv = RL.load_nodes(), RL.load_iv_adjustments()
+        lut_name = "Vintage Color.cube"                      # the reference's own 33^3 asset
+        fns = {"grain": lambda y: nodes.FastFilmGrain().apply_grain(y, 0.04, 0.5, 4)[0],
+               "lut": lambda y: iv.VRGDG_LUTS().apply_lut(y, lut_name, "cpu", 10.0)[0],
+               "colormatch": lambda y: nodes.ColorMatchToReference().match_color(y, ref, 1.0, 1)[0],
+               "sharpen": lambda y: nodes.FastUnsharpSharpen().apply_unsharp(y, 0.5, False)[0]}
+        kind, what = "reference", "the reference's node classes (oracle/reference_loader.py; kornia Lab transforms restated)"
+    else:
+        from oracle import restated as R
+        fns = {"grain": lambda y: R.fast_film_grain(y, 0.04, 0.5, 4),
+               "lut": lambda y: R.apply_lut_with_strength(y, lut_cpu, 10.0),
+               "colormatch": lambda y: R.color_match(y, ref, 1.0, 1),
+               "sharpen": lambda y: R.unsharp(y, 0.5, False)}
+        kind, what = "port", "oracle/restated.py (op-for-op port of the reference's eager torch / numpy ops)"
+
+    def chain():
+        y = x
+        for st in ("grain", "lut", "colormatch", "sharpen"):
+            if st in stages:
+                y = fns[st](y)
+        return y
+
+    dt = _median_time(chain)
+    out = {"value": round(mpix / dt, 2), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": kind,
+           "sample": f"{cpu_frames} frames {W}x{H}, chain {'+'.join(stages)} via {what}; warm-up 1, median of 3 = {dt:.2f} s; "
+                     f"os.cpu_count()={os.cpu_count()}, torch.get_num_threads()={torch.get_num_threads()} (numpy unsharp is single-threaded)"}
+    if per_node:
+        out["per_node_mpix_s"] = {st: round(mpix / _median_time(lambda st=st: fns[st](x)), 2) for st in stages}
+    return out
 
 
 def main():
     args = parse_args()
+    self_launch(args)
     # stdout carries exactly one line, the JSON: everything else that writes to fd 1 while we run (RCCL prints a
     # version banner to stdout when a communicator is created) is sent to stderr
     sys.stdout.flush()
@@ -109,8 +168,12 @@ def main():
     import torch.distributed as dist
 
     rank, local, world = sharding.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun --nproc-per-node {args.gpus}, or let "
+                         "bench.py launch itself)")
+    if world > 1:
+        if not dist.is_initialized() or dist.get_world_size() != world or dist.get_backend() != "nccl":
+            raise SystemExit("bench.py: RCCL process group did not come up with the requested world size")
     dev = torch.device("cuda", torch.cuda.current_device())
     H, W, stages = WORKLOADS[args.workload]
     frames = args.frames or (128 if H == 1080 else 256)
@@ -131,17 +194,25 @@ def main():
         gen = torch.Generator(device=dev).manual_seed(42)
         geom_stream = ops.rng.reserve(chunk * fe, world * frames // chunk, dev, gen)
 
-    def step(kernel_events=None):
+    ref_events = []
+
+    def step(kernel_events=None, cm_math=None):
         ref_ms = None
         if "colormatch" in stages:
-            ref_ms = sharding.reference_stats_sharded(ref, rank, world)
+            if kernel_events is not None:
+                r0, r1 = ops.HipEvent(), ops.HipEvent()
+                r0.record()
+            ref_ms = sharding.reference_stats_sharded(ref, rank, world, cm_math=cm_math)
+            if kernel_events is not None:
+                r1.record()
+                ref_events.append((r0, r1))
         plans = None
         if geom_stream is not None:
             plans = (ops.NoisePlan(chunk, geom_stream, chunk0=rank * (frames // chunk)), None, frames // chunk)
         spec = ops.ChainSpec(grain=(0.04, 0.5, chunk) if "grain" in stages else None,
                              lut=(lut, 10.0) if "lut" in stages else None,
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
-                             sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None)
+                             sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math)
         ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws)
 
     def barrier():
@@ -158,10 +229,32 @@ def main():
         step(events)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 3) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the fast colour-match policy, same data, timed the same way (reported beside the headline, never as `value`)
+    fast_variant = None
+    if "colormatch" in stages and not args.no_fast_variant:
+        step(cm_math="fast")
+        barrier()
+        f0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(cm_math="fast")
+        barrier()
+        fel = time.perf_counter() - f0
+        if dist.is_initialized():
+            t = torch.tensor([fel], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fel = float(t.item())
+        fast_variant = {"cm_math": "fast", "value": round(world * frames * H * W * args.steps / fel / 1e6, 1), "unit": "Mpixels/s",
+                        "ms_per_step": round(fel / args.steps * 1e3, 3),
+                        "note": "table-driven powers (<= 0.534 ulp) instead of ocml powf: a few ulp from the reference, not bit-equal "
+                                "to its device arithmetic (DESIGN.md section 4)"}
 
     px_rank = frames * H * W
     value = world * px_rank * args.steps / elapsed / 1e6
@@ -216,17 +309,23 @@ def main():
     except Exception:
         pass
 
+    ref_ms_per_step = round(sum(a.elapsed_ms(b) for a, b in ref_events) / max(args.steps, 1), 4) if ref_events else None
     if rank == 0:
         line = {
             "metric": "Mpixels/s (grain+LUT+colormatch+sharpen) at 4K" if args.workload == "chain4_4k" else f"Mpixels/s ({'+'.join(stages)})",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": f"synthetic-{args.dist} (generated on device, resident in HBM)",
-            "config": {"workload": f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)} fused chain, LUT 33^3, grain chunk {chunk} "
+            "config": {"workload": f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)} fused chain, LUT 33^3 (AMD_TealOrange_33.cube, this "
+                                   f"pack's own cube: same size as the reference's Vintage Color.cube), grain chunk {chunk} "
                                    f"(BASELINE configs[4] per-GPU shard)" if args.workload == "chain4_4k"
                        else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
-                       "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain},
+                       "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
+                       "cm_math": "device" if "colormatch" in stages else None},
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "per_rank_ms_per_step": per_rank_ms,
+            "reference_stats_ms_per_step": ref_ms_per_step,
             "chain_hbm_frac": round(value / world * bytes_per_px_chain * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": kern_names[dom],
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -234,6 +333,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "issue": issue},
         }
+        if fast_variant is not None:
+            line["fast_variant"] = fast_variant
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(stages, args.cpu_frames if H > 1080 else 4 * args.cpu_frames, H, W, lut_cpu)

@@ -2,9 +2,10 @@
 stream a CPU-resident batch through the GPU in bounded pieces."""
 from __future__ import annotations
 
-import torch
-
+import os
 import threading
+
+import torch
 
 #: upper bound of one host->device staging transfer (bytes of fp32 frames) -- sequential fallback path
 STAGE_BYTES = 1 << 30
@@ -62,8 +63,11 @@ def frame_groups(n_frames: int, frame_bytes: int, multiple_of: int = 1):
 # batch, and the generator bookkeeping happens on the host in submission order.
 # ------------------------------------------------------------------------------------------------------------
 
-#: results larger than this stay pageable (page-locked memory is not swappable) and are staged through a ring
-PIN_LIMIT_BYTES = 24 << 30
+#: Results larger than this stay pageable and are staged through a page-locked ring.  Page-locked memory is not
+#: swappable and torch's caching host allocator never returns it to the OS, while ComfyUI caches node outputs: a
+#: grain -> LUT -> match -> sharpen graph keeps four results alive, so the default bounds the footprint at 4 x 8 GiB.
+#: VRGDG_PIN_LIMIT_GB overrides it (0 = never page-lock results).
+PIN_LIMIT_BYTES = int(float(os.environ.get("VRGDG_PIN_LIMIT_GB", "8")) * (1 << 30))
 
 
 class _Staging:
@@ -103,6 +107,11 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
     Returns a CPU tensor shaped like `images` (dtype `out_dtype`, default the input's), page-locked when it fits
     PIN_LIMIT_BYTES."""
     dev = compute_device()
+    with torch.cuda.device(dev):          # kernels, side streams and events all on the compute device
+        return _stream_frames_on(dev, images, fn, multiple_of, out_dtype)
+
+
+def _stream_frames_on(dev, images, fn, multiple_of, out_dtype):
     images = images.contiguous()
     F = int(images.shape[0])
     out_dtype = out_dtype or images.dtype

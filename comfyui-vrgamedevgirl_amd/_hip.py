@@ -15,6 +15,8 @@ VRG_OK = 0
 BORDER_REPLICATE, BORDER_ZERO = 0, 1
 STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
+CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
+ABI_VERSION = 2
 
 
 class NoiseDesc(C.Structure):
@@ -34,7 +36,8 @@ class ChainDesc(C.Structure):
                 ("blend_mode", C.c_int32), ("blend", C.c_float), ("one_minus_blend", C.c_float),
                 ("img_ms", C.c_void_p), ("ref_ms", C.c_void_p), ("ref_frames", C.c_int32),
                 ("k", C.c_float), ("one_minus_k", C.c_float),
-                ("stencil_op", C.c_int32), ("border", C.c_int32), ("strength", C.c_float)]
+                ("stencil_op", C.c_int32), ("border", C.c_int32), ("strength", C.c_float),
+                ("cm_math", C.c_int32)]
 
 
 class AdjustDesc(C.Structure):
@@ -60,6 +63,7 @@ _SIGNATURES = {
     "vrg_event_destroy": (C.c_int, [_P]),
     "vrg_selftest_divconst": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
+    "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
@@ -79,10 +83,10 @@ _SIGNATURES = {
     "vrg_f32rgb_to_u8bgr": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_fused_chain_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_lab_stats_scratch_bytes": (C.c_int64, [C.c_int64]),
-    "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
+    "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_colormatch_apply_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float,
-                                           C.c_float, _P]),
+                                           C.c_float, C.c_int32, _P]),
     "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
     "vrg_chain_stats_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc)]),
@@ -107,7 +111,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.vrg_abi_version() != 1:
+    if lib.vrg_abi_version() != ABI_VERSION:
         raise RuntimeError("libvrgdg_hip.so ABI version mismatch")
     return lib
 
@@ -139,5 +143,7 @@ def ptr(t) -> C.c_void_p:
 
 
 def current_stream() -> C.c_void_p:
+    """torch's current stream of the CURRENT device.  ops.* make the tensors' device current first (ops._on_device), so
+    that the stream, the kernels' hipGetDevice() and the pointers always belong to the same GPU."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -49,15 +49,51 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def _object_digest(name: str) -> str:
+    h = hashlib.sha256()
+    for dep in (name,) + HEADERS:
+        with open(os.path.join(CSRC, dep), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(INCLUDE, "vrgdg_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every translation unit to an object (in parallel, cached by content digest under csrc/.obj) and link."""
     want = _digest()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == want:
                 return LIB_PATH
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-I", INCLUDE, "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(CSRC, ".obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(name: str) -> str:
+        obj = os.path.join(obj_dir, name + ".o")
+        stamp = obj + ".stamp"
+        dig = _object_digest(name)
+        if not force and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as fh:
+                if fh.read().strip() == dig:
+                    return obj
+        cmd = [hipcc, *cflags, "-I", INCLUDE, "-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print("[vrgdg-amd] compiling:", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(stamp, "w") as fh:
+            fh.write(dig)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
     if verbose:
-        print("[vrgdg-amd] building:", " ".join(cmd), flush=True)
+        print("[vrgdg-amd] linking:", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     with open(STAMP, "w") as fh:
         fh.write(want)

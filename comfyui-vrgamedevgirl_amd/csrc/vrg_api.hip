@@ -77,6 +77,38 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ i
     if (p < pixels) out[p] = acc;
 }
 
+// Element-wise pieces of the colour-match arithmetic, one fp32 in -> one fp32 out, so that tests can compare each with
+// the torch op the reference executes on this GPU (tests/test_gpu_parity.py::test_device_math_pieces_equal_torch):
+//  op 0: __ocml_pow_f32(x, y) with y a kernel argument      (torch.pow(x, y))
+//  op 1: x * fl(1/y)                                         (x / python_scalar on the GPU)
+//  op 2: x / y, IEEE                                         (x / tensor)
+//  op 3: pow_pos(x, y)      op 4: cbrt_pow(x)                (the fast policy's powers)
+//  op 5: Lab of an RGB triple / op 6: RGB of a Lab triple, device policy; op 7 / 8: the same with the fast policy
+__global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ in, float* __restrict__ out, int64_t n, int op, float y,
+                                                      DevMath dm) {
+    VRG_CM_MATH(PT, true, true, dm);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (op <= 4) {
+        const float x = in[i];
+        float r;
+        if (op == 0) r = VRG_LIB_POWF(x, y);
+        else if (op == 1) r = x * (float)(1.0 / (double)y);      // caller passes constants that are exact in fp32, or checks 1.055 via op 5
+        else if (op == 2) r = x / y;
+        else if (op == 3) r = pow_pos(x, y, PT);
+        else r = cbrt_pow(x);
+        out[i] = r;
+    } else {
+        const float x[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
+        float o[3];
+        if (op == 5) rgb_to_lab(x, o, dm);
+        else if (op == 6) lab_to_rgb(x, o, dm);
+        else if (op == 7) rgb_to_lab(x, o, PT);
+        else lab_to_rgb(x, o, PT);
+        out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+    }
+}
+
 }  // namespace vrg
 
 namespace vrg {
@@ -154,6 +186,15 @@ int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode,
         case 6: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<6>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         default: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<7>, dim3(blocks), dim3(256), 0, st, out, iters); break;
     }
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream) {
+    if (!in || !out || n <= 0 || op < 0 || op > 8) return VRG_ERR_BAD_ARG;
+    const uint64_t blocks = (uint64_t)(n + 255) / 256;
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(vrg::k_dbg_cm_math, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n, op, y, vrg::host_dev_math());
     VRG_CHECK_LAUNCH();
     return VRG_OK;
 }

@@ -26,12 +26,7 @@ __host__ __device__ inline int stats_blocks_per_frame(int64_t pixels) {
 template <int STAGES, class IO>
 __global__ __launch_bounds__(256) void k_chain_pointwise(const typename IO::elem* __restrict__ in, typename IO::elem* __restrict__ out,
                                                           int32_t ppf, ChainK D) {
-    __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
-    if (STAGES & VRG_STAGE_COLORMATCH) {
-        pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
-        __syncthreads();
-    }
-    const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
+    VRG_CM_MATH(PT, (STAGES & VRG_STAGE_COLORMATCH) != 0, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= ppf) return;
     const int64_t f = blockIdx.y;
@@ -60,12 +55,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
                                                      int32_t H, int32_t W, int32_t tiles_x, int32_t tiles_per_frame, uint32_t total_work,
                                                      ChainK D) {
     __shared__ float tile[3][HALO_H][LDS_PITCH];
-    __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
-    if (STAGES & VRG_STAGE_COLORMATCH) {
-        pow_tables_fill(pow_lds, (int)threadIdx.x, 256);
-        __syncthreads();
-    }
-    const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
+    VRG_CM_MATH(PT, (STAGES & VRG_STAGE_COLORMATCH) != 0, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const uint32_t per_xcd = (total_work + 7u) / 8u;
     const uint32_t work = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || work >= total_work) return;      // uniform per workgroup (after the barrier above)
@@ -144,11 +134,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int STAGES, int UNROLL = 1>
+template <int STAGES>
 __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                        double* __restrict__ partials, px3* __restrict__ lab_out) {
     __shared__ double red[4][6];
-    VRG_STAGE_POW_TABLES(PT);
+    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int64_t f = blockIdx.y;
     const px3* fin = in + f * ppf;
     float pivot[3];
@@ -163,31 +153,18 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
     const int32_t lo = blockIdx.x * per;
     const int32_t hi = lo + per < ppf ? lo + per : ppf;
     double s1[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0};
-    // UNROLL independent pixels per iteration: one pixel's LUT gather overlaps the other's Philox / pow work
-    for (int32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 256 * UNROLL) {
-        float lab[UNROLL][3];
+    for (int32_t p = lo + threadIdx.x; p < hi; p += 256) {
+        const px3 v = load_px_stream(fin + p);
+        const float x[3] = {v.r, v.g, v.b};
+        float pre[3], lab[3];
+        chain_pre<STAGES>(D, f, p, x, pre, PT);
+        rgb_to_lab(pre, lab, PT);
+        if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[0], lab[1], lab[2]});
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int32_t p = p0 + 256 * u;
-            const int32_t pc = p < hi ? p : hi - 1;
-            const px3 v = load_px_stream(fin + pc);
-            const float x[3] = {v.r, v.g, v.b};
-            float pre[3];
-            chain_pre<STAGES>(D, f, pc, x, pre, PT);
-            rgb_to_lab(pre, lab[u], PT);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int32_t p = p0 + 256 * u;
-            if (p < hi) {
-                if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[u][0], lab[u][1], lab[u][2]});
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const double d = (double)lab[u][c] - (double)pivot[c];
-                    s1[c] += d;
-                    s2[c] += d * d;
-                }
-            }
+        for (int c = 0; c < 3; ++c) {
+            const double d = (double)lab[c] - (double)pivot[c];
+            s1[c] += d;
+            s2[c] += d * d;
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,7 +184,7 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
 template <int STAGES>
 __global__ __launch_bounds__(64) void k_lab_merge(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                    const double* __restrict__ partials, double* __restrict__ stats) {
-    VRG_STAGE_POW_TABLES(PT);
+    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int64_t f = blockIdx.x;
     float pivot[3];
     {
@@ -246,7 +223,7 @@ __global__ void k_stats_finalize(const double* __restrict__ stats, float* __rest
 
 template <int STAGES>
 static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, const ChainK& D, double* stats, void* scratch,
-                        hipStream_t st, float* lab_out = nullptr, int unroll = 1) {
+                        hipStream_t st, float* lab_out = nullptr) {
     const int64_t ppf = (int64_t)H * W;
     const int bpf = stats_blocks_per_frame(ppf);
     double* partials = reinterpret_cast<double*>(scratch);
@@ -258,12 +235,8 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
             d.noise.chunk0 += f0 / D.noise.chunk_frames;
         }
         const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
-        if (unroll == 2)
-            hipLaunchKernelGGL((k_lab_partials<STAGES, 2>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
-                               partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
-        else
-            hipLaunchKernelGGL((k_lab_partials<STAGES, 1>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
-                               partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
+        hipLaunchKernelGGL((k_lab_partials<STAGES>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
+                           partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
         hipLaunchKernelGGL(k_lab_merge<STAGES>, dim3((uint32_t)nf), dim3(64), 0, st, src, (int32_t)ppf, bpf, d,
                            partials + f0 * bpf * 6, stats + f0 * 9);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
@@ -320,6 +293,7 @@ static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, in
 static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) {
     D = ChainK{};
     D.stages = d->stages;
+    D.dm = host_dev_math();
     if (d->stages & VRG_STAGE_GRAIN) {
         if (d->noise.chunk_frames < 1 || d->noise.grid_threads == 0 || (d->noise.grid_threads % 256u)) return VRG_ERR_BAD_ARG;
         if ((int64_t)d->noise.chunk_frames * H * W * 3 > 0x7fffffffll) return VRG_ERR_UNSUPPORTED;
@@ -352,18 +326,6 @@ int launch_produce(const float* in, float* lab_out, int64_t frames, int32_t H, i
 
 using namespace vrg;
 
-#define VRG_DISPATCH_PRE(STG, CALL)                       \
-    switch ((STG) & 7) {                                  \
-        case 0: return CALL(0);                           \
-        case 1: return CALL(1);                           \
-        case 2: return CALL(2);                           \
-        case 3: return CALL(3);                           \
-        case 4: return CALL(4);                           \
-        case 5: return CALL(5);                           \
-        case 6: return CALL(6);                           \
-        default: return CALL(7);                          \
-    }
-
 extern "C" {
 
 int64_t vrg_lab_stats_scratch_bytes(int64_t frames) { return frames < 0 ? 0 : frames * STATS_BPF_MAX * 6 * (int64_t)sizeof(double); }
@@ -382,11 +344,15 @@ int64_t vrg_chain_stats_scratch_bytes(int64_t frames, int32_t height, int32_t wi
     return need;
 }
 
-int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, double* stats, void* scratch, void* stream) {
-    if (!in || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width, double* stats, void* scratch, int32_t cm_math,
+                      void* stream) {
+    if (!in || !stats || !scratch || frames < 0 || height <= 0 || width <= 0 || (cm_math != VRG_CM_MATH_DEVICE && cm_math != VRG_CM_MATH_FAST))
+        return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff) return VRG_ERR_UNSUPPORTED;
     ChainK D{};
+    D.dm = host_dev_math();
+    if (cm_math == VRG_CM_MATH_FAST) return launch_stats<VRG_STAGE_FASTMATH>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
     return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream);
 }
 
@@ -415,17 +381,25 @@ int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int
     ChainK D;
     const int rc = fill_chain(&pre, height, width, D);
     if (rc) return rc;
-    const int unroll = (desc->variant & 0x100) ? 2 : 1;     // A/B knob: pixels per loop iteration of the reduction
+    if (desc->cm_math != VRG_CM_MATH_DEVICE && desc->cm_math != VRG_CM_MATH_FAST) return VRG_ERR_BAD_ARG;
+    const bool fast = desc->cm_math == VRG_CM_MATH_FAST;
     // chains that start with grain: shared-Philox pass (vrg_produce.hip) unless the A/B knob 0x200 asks for the
     // general kernel; tiny frames always take the general kernel
     if (!(desc->variant & 0x200) && produce_applicable(pre.stages, (int64_t)height * width * 3) && frames % D.noise.chunk_frames == 0)
-        return launch_produce(in, lab_out, frames, height, width, D, pre.stages, stats, scratch, (hipStream_t)stream);
-    switch (pre.stages & 3) {
-        case 0: return launch_stats<0>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
-        case 1: return launch_stats<1>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
-        case 2: return launch_stats<2>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
-        default: return launch_stats<3>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out, unroll);
+        return launch_produce(in, lab_out, frames, height, width, D, pre.stages | (fast ? VRG_STAGE_FASTMATH : 0), stats, scratch,
+                              (hipStream_t)stream);
+#define CALL(S) launch_stats<S>(in, frames, height, width, D, stats, scratch, (hipStream_t)stream, lab_out)
+    switch ((pre.stages & 3) | (fast ? 4 : 0)) {
+        case 0: return CALL(0);
+        case 1: return CALL(1);
+        case 2: return CALL(2);
+        case 3: return CALL(3);
+        case 4: return CALL(0 | VRG_STAGE_FASTMATH);
+        case 5: return CALL(1 | VRG_STAGE_FASTMATH);
+        case 6: return CALL(2 | VRG_STAGE_FASTMATH);
+        default: return CALL(3 | VRG_STAGE_FASTMATH);
     }
+#undef CALL
 }
 
 int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, const vrg_chain_desc* desc,
@@ -436,7 +410,8 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     if ((desc->stages & VRG_STAGE_COLORMATCH) && (!desc->img_ms || !desc->ref_ms || desc->ref_frames < 1)) return VRG_ERR_BAD_ARG;
-    if ((desc->variant & 0xff) > 2 || (desc->variant & ~0x3ff)) return VRG_ERR_UNSUPPORTED;
+    if ((desc->variant & 0xff) > 2 || (desc->variant & ~0x2ff)) return VRG_ERR_UNSUPPORTED;
+    if (desc->cm_math != VRG_CM_MATH_DEVICE && desc->cm_math != VRG_CM_MATH_FAST) return VRG_ERR_BAD_ARG;
     ChainK D;
     const int rc = fill_chain(desc, height, width, D);
     if (rc) return rc;
@@ -454,13 +429,40 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
             lut_lds_applicable(desc->lut_size, frames * (int64_t)height * width) && frames * (int64_t)height * width >= 24000000ll)   // enough strips for 12-wave workgroups on every CU
             variant = 2;
     }
-    if (variant == 2) return launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
+    if (variant == 2) {
+        // the march kernel has no colour-match stage and addresses a chunk with 32-bit element offsets (<= 0x60000000
+        // elements): what it cannot take goes to the tile / point-wise kernels below (any variant: same results)
+        const int rc = launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
+        if (rc != VRG_ERR_UNSUPPORTED) return rc;
+    }
     if ((desc->variant & 0xff) == 0 && desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
         return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, false, (hipStream_t)stream);   // small cube: table in LDS
-    if (desc->stages & VRG_STAGE_FROM_LAB)
-        return launch_chain<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream);
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)
-    VRG_DISPATCH_PRE(desc->stages, CALL)
+    if (!(desc->stages & VRG_STAGE_COLORMATCH)) {
+        switch (desc->stages & 3) {
+            case 0: return CALL(0);
+            case 1: return CALL(1);
+            case 2: return CALL(2);
+            default: return CALL(3);
+        }
+    }
+    constexpr int CM = VRG_STAGE_COLORMATCH, FM = VRG_STAGE_FASTMATH;
+    if (desc->cm_math == VRG_CM_MATH_FAST) {
+        if (desc->stages & VRG_STAGE_FROM_LAB) return CALL(CM | VRG_STAGE_FROM_LAB | FM);
+        switch (desc->stages & 3) {
+            case 0: return CALL(CM | FM);
+            case 1: return CALL(CM | 1 | FM);
+            case 2: return CALL(CM | 2 | FM);
+            default: return CALL(CM | 3 | FM);
+        }
+    }
+    if (desc->stages & VRG_STAGE_FROM_LAB) return CALL(CM | VRG_STAGE_FROM_LAB);
+    switch (desc->stages & 3) {
+        case 0: return CALL(CM);
+        case 1: return CALL(CM | 1);
+        case 2: return CALL(CM | 2);
+        default: return CALL(CM | 3);
+    }
 #undef CALL
 }
 

@@ -7,9 +7,9 @@
 namespace vrg {
 
 // grain (with the pixel's three raw normals n) -> LUT -> colour match for a pixel of frame f (of this call)
-template <int STAGES>
+template <int STAGES, class MATH>
 __device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, const float xin[3], const float n[3], float o[3],
-                                                   const PowTables& PT, const f32x4* lut_nodes = nullptr) {
+                                                   const MATH& PT, const f32x4* lut_nodes = nullptr) {
     float v[3] = {xin[0], xin[1], xin[2]};
     if (STAGES & VRG_STAGE_GRAIN) {
         float g[3];
@@ -37,9 +37,9 @@ __device__ __forceinline__ void chain_apply_stages(const ChainK& D, int64_t f, c
 
 // Same, drawing the pixel's normals with the general per-element routine (one Philox call per element):
 // for the pixel at (frame f of this call, pixel p of the frame).
-template <int STAGES>
+template <int STAGES, class MATH>
 __device__ __forceinline__ void chain_pre(const ChainK& D, int64_t f, int32_t p, const float xin[3], float o[3],
-                                          const PowTables& PT) {
+                                          const MATH& PT) {
     float n[3] = {0.0f, 0.0f, 0.0f};
     if (STAGES & VRG_STAGE_GRAIN) {
         const int64_t chunk = f / D.noise.chunk_frames;

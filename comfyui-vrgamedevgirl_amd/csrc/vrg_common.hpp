@@ -100,9 +100,21 @@ struct ChainK {
     NoiseK noise;
     LutParams lut;
     CmK cm;
+    DevMath dm;             // pow exponents of the "device" colour-match arithmetic (runtime values, see vrg_pixel_math.hpp)
     int32_t stencil_op, zero_border;
     float strength;
 };
+
+// Internal template bit next to the public VRG_STAGE_* bits: Lab / colour-match arithmetic with the fast policy
+// (PowTables) instead of the default device policy (DevMath).  Never part of vrg_chain_desc::stages; set from cm_math.
+constexpr int VRG_STAGE_FASTMATH = 32;
+
+inline DevMath host_dev_math() { return DevMath{(float)2.4, (float)(1.0 / 2.4), (float)(1.0 / 3.0)}; }
+
+template <bool FAST> struct CmMathSel { typedef DevMath type; };
+template <> struct CmMathSel<true> { typedef PowTables type; };
+__device__ __forceinline__ PowTables cm_make_math(const float* lds, const DevMath&, const PowTables*) { return PowTables{lds, lds + 512}; }
+__device__ __forceinline__ DevMath cm_make_math(const float*, const DevMath& dm, const DevMath*) { return dm; }
 
 inline NoiseK make_noise(const vrg_noise_desc* d, int64_t frame_elems) {
     NoiseK n;
@@ -126,12 +138,17 @@ inline LutParams make_lut(const float* cells, int n, const float dmin[3], const 
     return P;
 }
 
-// Stage the pow tables in LDS (2.5 KB) and return the views; every thread of the block must call it.
-#define VRG_STAGE_POW_TABLES(PT)                                                 \
-    __shared__ __attribute__((aligned(16))) float vrg_pow_lds_[::vrg::POW_TABLE_WORDS]; \
-    ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);      \
-    __syncthreads();                                                             \
-    const ::vrg::PowTables PT{vrg_pow_lds_, vrg_pow_lds_ + 512}
+// The colour-match arithmetic object of a kernel: NEED = does the kernel evaluate Lab at all, FAST = policy.  The fast
+// policy stages its pow tables in LDS (2.5 KB); the device policy only carries the three exponents.  Every thread of the
+// block must execute it (barrier).
+#define VRG_CM_MATH(PT, NEED, FAST, DM)                                                                       \
+    __shared__ __attribute__((aligned(16))) float vrg_pow_lds_[((NEED) && (FAST)) ? ::vrg::POW_TABLE_WORDS : 4]; \
+    if ((NEED) && (FAST)) {                                                                                    \
+        ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);                              \
+        __syncthreads();                                                                                       \
+    }                                                                                                          \
+    typedef typename ::vrg::CmMathSel<(FAST)>::type PT##_t;                                                    \
+    const PT##_t PT = ::vrg::cm_make_math(vrg_pow_lds_, (DM), (const PT##_t*)nullptr)
 
 #define VRG_CHECK_LAUNCH()                                   \
     do {                                                     \

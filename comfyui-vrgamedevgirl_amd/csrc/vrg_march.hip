@@ -59,16 +59,15 @@ __global__ void k_selftest_lanes(float* out) {
 // become ds_read_b128 -- the L1 / L2 gather path that holds the global-table form at ~65 Gpix/s is not used at all.
 template <int STAGES, bool SHARPEN, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
-    __shared__ __attribute__((aligned(16))) float pow_lds[(STAGES & VRG_STAGE_COLORMATCH) ? POW_TABLE_WORDS : 4];
+    static_assert(!(STAGES & VRG_STAGE_COLORMATCH), "colour-match chains run on the tile / point-wise kernels");
     extern __shared__ __attribute__((aligned(16))) float march_lut_nodes[];
     const f32x4* lut_nodes = nullptr;
     if (WAVES != 4) {
         lut_nodes_to_lds(D.lut, reinterpret_cast<f32x4*>(march_lut_nodes), (int)threadIdx.x, 64 * WAVES);
         lut_nodes = reinterpret_cast<const f32x4*>(march_lut_nodes);
     }
-    if (STAGES & VRG_STAGE_COLORMATCH) pow_tables_fill(pow_lds, (int)threadIdx.x, 64 * WAVES);
-    if ((STAGES & VRG_STAGE_COLORMATCH) || WAVES != 4) __syncthreads();
-    const PowTables PT{pow_lds, pow_lds + ((STAGES & VRG_STAGE_COLORMATCH) ? 512 : 0)};
+    if (WAVES != 4) __syncthreads();
+    const DevMath PT = D.dm;      // unused: no Lab arithmetic in this kernel
 
     constexpr int CLO = SHARPEN ? 1 : 0;     // first lane that produces output
     constexpr int CW = SHARPEN ? 61 : 63;    // output lanes per wave (lane 63 only provides noise)
@@ -278,7 +277,7 @@ template <int STAGES, bool SHARPEN>
 static int launch_march_t(const float* in, float* out, const MarchK& M, const ChainK& D, hipStream_t st) {
     const uint64_t jobs = (uint64_t)M.chunks * M.K * M.T;
     const size_t lut_bytes = (STAGES & VRG_STAGE_LUT) ? (size_t)D.lut.n * D.lut.n * D.lut.n * 16 : 0;
-    if ((STAGES & VRG_STAGE_LUT) && !(STAGES & VRG_STAGE_COLORMATCH) && lut_bytes <= 152 * 1024 && jobs >= 1536) {
+    if ((STAGES & VRG_STAGE_LUT) && lut_bytes <= 152 * 1024 && jobs >= 1536) {
         // small cube: node table in LDS, 12-wave workgroups (one per CU next to the table)
         constexpr int WV = 12;
         const uint64_t blocks = (jobs + WV - 1) / WV;
@@ -303,6 +302,7 @@ static int launch_march_s(const float* in, float* out, const MarchK& M, const Ch
 // One launch per run of equal chunks.  With a grain stage the chunk is the RNG chunk; without, frames are
 // grouped so that a chunk stays below 2^31 elements and G is a synthetic 48-row band.
 int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st) {
+    if (stages & (VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB)) return VRG_ERR_UNSUPPORTED;
     const bool sharpen = (stages & VRG_STAGE_SHARPEN) != 0;
     const bool grain = (stages & VRG_STAGE_GRAIN) != 0;
     const int64_t fe = (int64_t)H * W * 3;
@@ -316,10 +316,6 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
         cf = 0x60000000ll / fe;
         if (cf < 1) return VRG_ERR_UNSUPPORTED;
         if (cf > frames) cf = frames;
-        if ((stages & VRG_STAGE_COLORMATCH) && D0.cm.ref_frames != 1) {   // keep reference pairing aligned
-            cf -= cf % D0.cm.ref_frames;
-            if (cf < 1) return VRG_ERR_UNSUPPORTED;
-        }
         const int64_t band = 48ll * W * 3;
         G = (uint32_t)(band < 0x08000000ll ? band : 0x08000000ll);
     }
@@ -345,21 +341,14 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
         ChainK D = D0;
         const int64_t chunk_index0 = done / cf;
         if (grain) D.noise.chunk0 += chunk_index0;
-        if (stages & VRG_STAGE_COLORMATCH) D.cm.img_ms += done * 6;
         const float* src = in + done * fe;
         float* dst = out + done * fe;
         int rc;
-        if (stages & VRG_STAGE_FROM_LAB) {
-            rc = launch_march_s<VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB>(src, dst, M, D, sharpen, st);
-        } else switch (stages & 7) {
+        switch (stages & 3) {
             case 0: rc = launch_march_s<0>(src, dst, M, D, sharpen, st); break;
             case 1: rc = launch_march_s<1>(src, dst, M, D, sharpen, st); break;
             case 2: rc = launch_march_s<2>(src, dst, M, D, sharpen, st); break;
-            case 3: rc = launch_march_s<3>(src, dst, M, D, sharpen, st); break;
-            case 4: rc = launch_march_s<4>(src, dst, M, D, sharpen, st); break;
-            case 5: rc = launch_march_s<5>(src, dst, M, D, sharpen, st); break;
-            case 6: rc = launch_march_s<6>(src, dst, M, D, sharpen, st); break;
-            default: rc = launch_march_s<7>(src, dst, M, D, sharpen, st); break;
+            default: rc = launch_march_s<3>(src, dst, M, D, sharpen, st); break;
         }
         if (rc) return rc;
         done += nchunks * cfr;

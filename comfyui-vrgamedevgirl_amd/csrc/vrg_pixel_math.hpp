@@ -479,8 +479,42 @@ VRG_HD float pow_pos(float x, float y, const PowTables& T) {
 
 // ------------------------------------------------------------------------------------------
 // kornia.color Lab transforms (external to the reference, restated: oracle/restated.py).  Operation
-// order and rounding points are kornia's; pow and the constant divisions are evaluated as above.
+// order and rounding points are kornia's.  TWO arithmetic policies, chosen by the type of the last argument:
+//
+//  DevMath   ("device" -- the default of the nodes): every op is what torch-ROCm executes for it on this GPU, i.e. what
+//            the reference computes when ComfyUI runs it on the MI355X (nodes.py:98-115 under get_torch_device()):
+//              * tensor / python_scalar  ->  x * fl32(1.0 / c)          (ATen BinaryDivTrueKernel: a * reciprocal(b), with the
+//                                            reciprocal of the PYTHON DOUBLE formed in double and rounded once: for 1.055 that
+//                                            is one ulp away from 1.0f / 1.055f; measured on the MI355X, profiles/r02_cm_parity.json)
+//              * torch.pow(x, y)         ->  __ocml_pow_f32(x, y)       (ATen PowKernel: ::pow -> ocml; the exponent is a
+//                                            RUNTIME value there, and is one here, so no specialisation can differ)
+//              * torch.pow(x, 3.0)       ->  (x * x) * x                (PowKernel's d_exp == 3 special case)
+//              * tensor / tensor         ->  IEEE quotient              (xyz / white, (lab - mean) / std)
+//            tests/test_gpu_parity.py holds the element-wise path BIT-EQUAL to oracle/restated.py evaluated by torch on
+//            the device (Lab image, and apply with injected statistics).
+//  PowTables ("fast"): IEEE quotients (= torch on the CPU) and pow_pos / cbrt_pow below (0.53 / 0.50 ulp) instead of the
+//            ~190-instruction ocml powf; within a few ulp of either reference, ~2.3x the throughput.
 // ------------------------------------------------------------------------------------------
+struct DevMath {
+    float e24, e1_24, e1_3;     // 2.4f, (float)(1/2.4), (float)(1/3.0): kernel arguments, not literals
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+extern "C" __device__ float __ocml_pow_f32(float, float);
+#define VRG_LIB_POWF(x, y) __ocml_pow_f32((x), (y))
+#else
+#define VRG_LIB_POWF(x, y) __builtin_powf((x), (y))      /* host checker only (tests/host_math) */
+#endif
+
+// x / c for a Python-scalar c (written as a double literal): fast = the IEEE quotient by (float)c; device = x * (float)(1.0 / c)
+VRG_HD float cm_div_scalar(float x, float c, float rc, float, const PowTables&) { return div_const(x, c, rc); }
+VRG_HD float cm_div_scalar(float x, float, float, float rc_dev, const DevMath&) { return x * rc_dev; }
+#define VRG_CM_DIVS(x, c, M) ::vrg::cm_div_scalar((x), (float)(c), 1.0f / (float)(c), (float)(1.0 / (double)(c)), (M))
+// x / c for a tensor-valued constant c (the D65 white point)
+VRG_HD float cm_div_tensor(float x, float c, float rc, const PowTables&) { return div_const(x, c, rc); }
+VRG_HD float cm_div_tensor(float x, float c, float, const DevMath&) { return x / c; }
+#define VRG_CM_DIVT(x, c, M) ::vrg::cm_div_tensor((x), (c), 1.0f / (c), (M))
+
 VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float t = v + 0.055f;
     const float q = VRG_DIVC(t, 1.055f);
@@ -489,11 +523,26 @@ VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float lo = VRG_DIVC(v, 12.92f);
     return v > 0.04045f ? hi : lo;
 }
+VRG_HD float srgb_to_linear(float v, const DevMath& M) {
+    const float t = v + 0.055f;
+    const float q = VRG_CM_DIVS(t, 1.055, M);
+    const float hi = VRG_LIB_POWF(q, M.e24);
+    const float lo = VRG_CM_DIVS(v, 12.92, M);
+    return v > 0.04045f ? hi : lo;
+}
 
 VRG_HD float linear_to_srgb(float v, const PowTables& T) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
     const float pw = pow_pos(base, (float)(1.0 / 2.4), T);
+    const float hi = 1.055f * pw - 0.055f;
+    const float lo = 12.92f * v;
+    return v > thr ? hi : lo;
+}
+VRG_HD float linear_to_srgb(float v, const DevMath& M) {
+    const float thr = 0.0031308f;
+    const float base = clamp_min(v, thr);
+    const float pw = VRG_LIB_POWF(base, M.e1_24);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
@@ -520,10 +569,13 @@ VRG_HD float cbrt_pow(float x) {
     return __builtin_fmaf(t0, d, t0);
 }
 
-VRG_HD float lab_f(float t, const PowTables& T) {
+VRG_HD float lab_cbrt(float t, const PowTables&) { return cbrt_pow(t); }
+VRG_HD float lab_cbrt(float t, const DevMath& M) { return VRG_LIB_POWF(t, M.e1_3); }
+
+template <class MATH>
+VRG_HD float lab_f(float t, const MATH& T) {
     const float thr = 0.008856f;
-    (void)T;
-    const float pw = cbrt_pow(clamp_min(t, thr));
+    const float pw = lab_cbrt(clamp_min(t, thr), T);
     const float sc = 7.787f * t + (float)(4.0 / 29.0);
     return t > thr ? pw : sc;
 }
@@ -536,13 +588,14 @@ VRG_HD float dot3(float a, float x, float b, float y, float c, float z) {
     return s + r;
 }
 
-VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const PowTables& T) {
+template <class MATH>
+VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const MATH& T) {
     const float r = srgb_to_linear(rgb[0], T);
     const float g = srgb_to_linear(rgb[1], T);
     const float b = srgb_to_linear(rgb[2], T);
-    const float X = VRG_DIVC(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f);
+    const float X = VRG_CM_DIVT(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f, T);
     const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b);   // / 1.0
-    const float Z = VRG_DIVC(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f);
+    const float Z = VRG_CM_DIVT(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f, T);
     const float fx = lab_f(X, T), fy = lab_f(Y, T), fz = lab_f(Z, T);
     lab[0] = 116.0f * fy - 16.0f;
     const float dxy = fx - fy;
@@ -551,24 +604,26 @@ VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const PowTables& T) {
     lab[2] = 200.0f * dyz;
 }
 
-VRG_HD float lab_finv(float f) {
+template <class MATH>
+VRG_HD float lab_finv(float f, const MATH& T) {
     const float cube = (f * f) * f;
     const float d = f - (float)(4.0 / 29.0);
-    const float sc = VRG_DIVC(d, 7.787f);
+    const float sc = VRG_CM_DIVS(d, 7.787, T);
     return f > 0.2068966f ? cube : sc;
 }
 
-VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const PowTables& T) {
+template <class MATH>
+VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const MATH& T) {
     const float l16 = lab[0] + 16.0f;
-    const float fy = VRG_DIVC(l16, 116.0f);
-    const float a5 = VRG_DIVC(lab[1], 500.0f);
+    const float fy = VRG_CM_DIVS(l16, 116.0, T);
+    const float a5 = VRG_CM_DIVS(lab[1], 500.0, T);
     const float fx = a5 + fy;
-    const float b2 = VRG_DIVC(lab[2], 200.0f);
+    const float b2 = VRG_CM_DIVS(lab[2], 200.0, T);
     const float fzr = fy - b2;
     const float fz = clamp_min(fzr, 0.0f);
-    const float X = lab_finv(fx) * 0.95047f;
-    const float Y = lab_finv(fy);   // * 1.0
-    const float Z = lab_finv(fz) * 1.08883f;
+    const float X = lab_finv(fx, T) * 0.95047f;
+    const float Y = lab_finv(fy, T);   // * 1.0
+    const float Z = lab_finv(fz, T) * 1.08883f;
     const float lr = dot3((float)3.2404813432005266, X, (float)-1.5371515162713185, Y, (float)-0.4985363261688878, Z);
     const float lg = dot3((float)-0.9692549499965682, X, (float)1.8759900014898907, Y, (float)0.0415559265582928, Z);
     const float lb = dot3((float)0.0556466391351772, X, (float)-0.2040413383665112, Y, (float)1.0573110696453443, Z);
@@ -578,9 +633,9 @@ VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const PowTables& T) {
 }
 
 // matched = (lab-mu)/sigma*sigma_ref + mu_ref ; blended = K*matched + T*lab (nodes.py:112-113)
-// d / sigma with sigma = std + 1e-5 (a per-frame value in [1e-5, ~100]) through the FMA form of div_const, with the
+// fast: d / sigma with sigma = std + 1e-5 (a per-frame value in [1e-5, ~100]) through the FMA form of div_const, with the
 // reciprocal from v_rcp_f32 + one Newton step: 8 issue units instead of the 14 of the IEEE sequence, and the same
-// quotient (0 differences in 2e7 random (d, sigma) pairs; the stage is tolerance-level anyway, section 4 of DESIGN.md).
+// quotient in 2e7 random (d, sigma) pairs.  device: the IEEE quotient itself (tensor / tensor).
 VRG_HD float recip_newton(float s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float r0 = __builtin_amdgcn_rcpf(s);
@@ -590,10 +645,13 @@ VRG_HD float recip_newton(float s) {
     return 1.0f / s;
 #endif
 }
+VRG_HD float cm_div_sigma(float d, float sigma, const PowTables&) { return div_const(d, sigma, recip_newton(sigma)); }
+VRG_HD float cm_div_sigma(float d, float sigma, const DevMath&) { return d / sigma; }
 
-VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, float sigma_ref, float K, float T) {
+template <class MATH>
+VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, float sigma_ref, float K, float T, const MATH& M) {
     const float d = lab - mu;
-    const float z = div_const(d, sigma, recip_newton(sigma));
+    const float z = cm_div_sigma(d, sigma, M);
     const float w = z * sigma_ref;
     const float m = w + mu_ref;
     const float a = K * m;
@@ -602,18 +660,20 @@ VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, 
 }
 
 // ms: {mean, std+1e-5} per channel.  Lab of the pixel -> matched, blended, back to RGB.
+template <class MATH>
 VRG_HD void colormatch_from_lab(const float lab[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
-                                const PowTables& PT) {
+                                const MATH& PT) {
     float bl[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-        bl[c] = colormatch_channel(lab[c], img_ms[2 * c], img_ms[2 * c + 1], ref_ms[2 * c], ref_ms[2 * c + 1], K, T);
+        bl[c] = colormatch_channel(lab[c], img_ms[2 * c], img_ms[2 * c + 1], ref_ms[2 * c], ref_ms[2 * c + 1], K, T, PT);
     lab_to_rgb(bl, o, PT);
     // final .clamp(0,1) of nodes.py:121 is idempotent after lab_to_rgb's clip
 }
 
+template <class MATH>
 VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
-                             const PowTables& PT) {
+                             const MATH& PT) {
     float lab[3];
     rgb_to_lab(rgb, lab, PT);
     colormatch_from_lab(lab, img_ms, ref_ms, K, T, o, PT);

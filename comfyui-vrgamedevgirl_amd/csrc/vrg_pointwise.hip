@@ -227,9 +227,10 @@ int launch_lut_lds(const void* in, void* out, int64_t pixels, const LutParams& P
 // ----------------------------------------------------------------------------------------------
 // Colour-match apply (pass 2).  ms arrays: [frame][3][2] = {mean, std + 1e-5}.
 // ----------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict__ in, px3* __restrict__ out,
-                                                           int32_t pixels_per_frame, CmK cm) {
-    VRG_STAGE_POW_TABLES(PT);
+                                                           int32_t pixels_per_frame, CmK cm, DevMath dm) {
+    VRG_CM_MATH(PT, true, FAST, dm);
     const int32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p >= pixels_per_frame) return;
     const int64_t f = blockIdx.y;
@@ -342,8 +343,10 @@ int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels,
 }
 
 int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, const float* img_ms,
-                             const float* ref_ms, int32_t ref_frames, float k, float one_minus_k, void* stream) {
-    if (!in || !out || !img_ms || !ref_ms || frames < 0 || height <= 0 || width <= 0 || ref_frames < 1) return VRG_ERR_BAD_ARG;
+                             const float* ref_ms, int32_t ref_frames, float k, float one_minus_k, int32_t cm_math, void* stream) {
+    if (!in || !out || !img_ms || !ref_ms || frames < 0 || height <= 0 || width <= 0 || ref_frames < 1 ||
+        (cm_math != VRG_CM_MATH_DEVICE && cm_math != VRG_CM_MATH_FAST))
+        return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     const int64_t ppf = (int64_t)height * width;
     if (ppf > 0x7fffffff) return VRG_ERR_UNSUPPORTED;
@@ -356,8 +359,12 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
         // ref frame index uses f % ref_frames relative to the call start; 32768 is a multiple of any
         // chunk size only if ref_frames divides it -- keep the mapping exact by offsetting explicitly.
         if (ref_frames != 1 && (f0 % ref_frames) != 0) return VRG_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(k_colormatch_apply, dim3(bx, (uint32_t)nf), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const px3*>(in) + f0 * ppf, reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c);
+        if (cm_math == VRG_CM_MATH_FAST)
+            hipLaunchKernelGGL(k_colormatch_apply<true>, dim3(bx, (uint32_t)nf), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const px3*>(in) + f0 * ppf, reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c, host_dev_math());
+        else
+            hipLaunchKernelGGL(k_colormatch_apply<false>, dim3(bx, (uint32_t)nf), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const px3*>(in) + f0 * ppf, reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c, host_dev_math());
         VRG_CHECK_LAUNCH();
     }
     return VRG_OK;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ i
                                                       int32_t* __restrict__ rec_frame) {
     __shared__ float sn[4][PR_SUB + 4];
     __shared__ double red[4][12];
-    VRG_STAGE_POW_TABLES(PT);
+    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const uint32_t per_chunk = P.K * P.NB;
     const uint32_t G = P.G;
     uint32_t chunk, k, ib;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ i
 // Lab of every frame's first pixel after the pre stages: the pivot of that frame's shifted sums
 template <int STAGES>
 __global__ __launch_bounds__(64) void k_frame_pivots(const px3* __restrict__ in, int32_t ppf, int64_t frames, ChainK D, float* __restrict__ pivots) {
-    VRG_STAGE_POW_TABLES(PT);
+    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (f >= frames) return;
     const px3 v0 = in[f * ppf];
@@ -302,6 +302,10 @@ static int launch_produce_t(const float* in, float* lab_out, int64_t frames, int
 
 int launch_produce(const float* in, float* lab_out, int64_t frames, int32_t H, int32_t W, const ChainK& D, int stages, double* stats,
                    void* scratch, hipStream_t st) {
+    if (stages & VRG_STAGE_FASTMATH) {
+        if ((stages & 3) == 3) return launch_produce_t<3 | VRG_STAGE_FASTMATH>(in, lab_out, frames, H, W, D, stats, scratch, st);
+        return launch_produce_t<1 | VRG_STAGE_FASTMATH>(in, lab_out, frames, H, W, D, stats, scratch, st);
+    }
     if ((stages & 3) == 3) return launch_produce_t<3>(in, lab_out, frames, H, W, D, stats, scratch, st);
     return launch_produce_t<1>(in, lab_out, frames, H, W, D, stats, scratch, st);
 }

@@ -11,6 +11,8 @@ on the data path and no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import functools
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -20,6 +22,42 @@ import torch
 from . import _hip, rng
 
 _F3 = C.c_float * 3
+
+#: Arithmetic policy of the Lab transforms / statistics transfer (include/vrgdg_hip.h, enum vrg_cm_math).
+#: "device" (default): each element-wise op is the one torch-ROCm runs for it on this GPU (bit-equal to the reference's
+#: colour match executed on the MI355X, given the same statistics); "fast": table-driven powers, a few ulp away, ~2.3x faster.
+CM_MATH = {"device": _hip.CM_MATH_DEVICE, "fast": _hip.CM_MATH_FAST}
+
+
+def default_cm_math() -> int:
+    name = os.environ.get("VRGDG_CM_MATH", "device").strip().lower()
+    if name not in CM_MATH:
+        raise ValueError(f"VRGDG_CM_MATH must be one of {sorted(CM_MATH)}, got {name!r}")
+    return CM_MATH[name]
+
+
+def _cm_math(value) -> int:
+    if value is None:
+        return default_cm_math()
+    if isinstance(value, str):
+        return CM_MATH[value]
+    return int(value)
+
+
+def _on_device(fn):
+    """Run `fn` with the device of its first tensor argument current: the kernels are enqueued on torch's current
+    stream of the current device and the C side asks hipGetDevice(), so a tensor on cuda:1 while cuda:0 is current
+    would otherwise get device-1 pointers on a device-0 stream."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        first = next((a for a in args if isinstance(a, torch.Tensor)), None)
+        if first is None:
+            first = next((a for a in kwargs.values() if isinstance(a, torch.Tensor)), None)
+        if first is not None and first.is_cuda and first.device.index != torch.cuda.current_device():
+            with torch.cuda.device(first.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapped
 
 
 def _f32(v: float) -> float:
@@ -93,6 +131,7 @@ def _grain_call(x, out, f0, nf, plan: NoisePlan, I32, S32, T32):
                                        _hip.current_stream()), "vrg_grain_f32")
 
 
+@_on_device
 def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: float, chunk_frames: int = 0,
                generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
     """Film grain with in-register Philox noise, bit-identical to the reference run on this GPU with the same
@@ -114,6 +153,7 @@ def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: flo
     return out
 
 
+@_on_device
 def film_grain_seeded_frames(images: torch.Tensor, grain_intensity: float, saturation_mix: float, seed: int,
                              frame_start: int = 0) -> torch.Tensor:
     """Per-frame seeded grain: frame i uses generator seed (seed + frame_start + i) & 0x7FFFFFFF, offset 0
@@ -136,6 +176,7 @@ def film_grain_seeded_frames(images: torch.Tensor, grain_intensity: float, satur
     return out
 
 
+@_on_device
 def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensity: float, saturation_mix: float) -> torch.Tensor:
     """Grain arithmetic with caller-supplied N(0,1) noise (same shape): the noise-injection parity form."""
     x = _check_frames(images, channels=3)
@@ -165,6 +206,10 @@ class DeviceLut:
 def upload_lut(lut_data: dict, device) -> DeviceLut:
     """Upload a parsed .cube table ([N,N,N,3], index [b][g][r]) and rewrite it on the device into the
     cell-major form the kernels read (values copied verbatim)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+        with torch.cuda.device(device):
+            return upload_lut(lut_data, device)
     raw = lut_data["lut"].to(device=device, dtype=torch.float32).contiguous()
     if raw.ndim != 4 or raw.shape[-1] != 3 or not (raw.shape[0] == raw.shape[1] == raw.shape[2]):
         raise ValueError("LUT table must be [N, N, N, 3]")
@@ -190,6 +235,7 @@ def blend_terms(strength: float):
     return 1, 1.0, 0.0
 
 
+@_on_device
 def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.Tensor:
     if image.ndim != 4 or image.shape[-1] < 3:
         raise ValueError("VRGDG_LUTS expects IMAGE input shaped like [batch, height, width, channels].")
@@ -214,6 +260,7 @@ def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.
 _STENCIL = {"unsharp": _hip.STENCIL_UNSHARP, "laplacian": _hip.STENCIL_LAPLACIAN, "sobel": _hip.STENCIL_SOBEL}
 
 
+@_on_device
 def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool = False) -> torch.Tensor:
     """unsharp / laplacian / sobel.  zero_border=False is the reference's default numpy path (edge replicate);
     True is its ``use_gpu`` path (zero padding, and for laplacian/sobel the conv2d sign/epsilon conventions)."""
@@ -264,6 +311,7 @@ def adjust_terms(adjust: dict) -> "_hip.AdjustDesc":
     return d
 
 
+@_on_device
 def adjust(images: torch.Tensor, terms: "_hip.AdjustDesc", out: torch.Tensor | None = None,
            workspace: torch.Tensor | None = None) -> torch.Tensor:
     """Run the Adjust kernels on ``[F,H,W,3]`` frames: fp32 R,G,B tensors, or uint8 B,G,R decoded frames (then the
@@ -295,6 +343,7 @@ def adjust(images: torch.Tensor, terms: "_hip.AdjustDesc", out: torch.Tensor | N
 # uint8 BGR frames <-> fp32 RGB tensors (video I/O edge)
 # ------------------------------------------------------------------------------------------------
 
+@_on_device
 def frames_u8_to_f32(frames_bgr: torch.Tensor) -> torch.Tensor:
     """``[F,H,W,3]`` uint8 B,G,R on the GPU -> fp32 R,G,B in [0,1] (``/ 255.0``)."""
     x = _check_frames(frames_bgr, "frames", channels=3, dtype=torch.uint8)
@@ -305,6 +354,7 @@ def frames_u8_to_f32(frames_bgr: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def f32_to_frames_u8(images: torch.Tensor) -> torch.Tensor:
     """fp32 R,G,B -> ``clip(x * 255, 0, 255)`` truncated to uint8, B,G,R order."""
     x = _check_frames(images, channels=3)
@@ -324,7 +374,8 @@ def _stats_scratch(frames: int, device) -> torch.Tensor:
     return torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device=device)
 
 
-def lab_stats(images: torch.Tensor) -> torch.Tensor:
+@_on_device
+def lab_stats(images: torch.Tensor, cm_math=None) -> torch.Tensor:
     """Per-frame Lab statistics as fp64 ``[F, 3, 3]`` = (n, mean, M2) per channel L,a,b."""
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
@@ -332,11 +383,12 @@ def lab_stats(images: torch.Tensor) -> torch.Tensor:
     if F == 0:
         return stats
     scratch = _stats_scratch(F, x.device)
-    _hip.check(_hip.lib().vrg_lab_stats_f32(_hip.ptr(x), F, H, W, _hip.ptr(stats), _hip.ptr(scratch), _hip.current_stream()),
-               "vrg_lab_stats_f32")
+    _hip.check(_hip.lib().vrg_lab_stats_f32(_hip.ptr(x), F, H, W, _hip.ptr(stats), _hip.ptr(scratch), _cm_math(cm_math),
+                                           _hip.current_stream()), "vrg_lab_stats_f32")
     return stats
 
 
+@_on_device
 def finalize_stats(stats: torch.Tensor) -> torch.Tensor:
     """(n, mean, M2) fp64 -> fp32 ``[F, 3, 2]`` = (mean, unbiased std + 1e-5) (nodes.py:99-100, 109-110)."""
     F = stats.shape[0]
@@ -362,7 +414,9 @@ def merge_stats(parts: torch.Tensor) -> torch.Tensor:
     return acc
 
 
-def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.Tensor, match_strength: float) -> torch.Tensor:
+@_on_device
+def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.Tensor, match_strength: float,
+                     cm_math=None) -> torch.Tensor:
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
     out = torch.empty_like(x)
@@ -372,23 +426,25 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
     if R != 1 and F % R != 0:
         raise RuntimeError(f"The size of tensor a ({F}) must match the size of tensor b ({R}) at non-singleton dimension 0")
     _hip.check(_hip.lib().vrg_colormatch_apply_f32(_hip.ptr(x), _hip.ptr(out), F, H, W, _hip.ptr(img_ms), _hip.ptr(ref_ms), R,
-                                                  _f32(match_strength), _f32(1.0 - match_strength), _hip.current_stream()),
+                                                  _f32(match_strength), _f32(1.0 - match_strength), _cm_math(cm_math),
+                                                  _hip.current_stream()),
                "vrg_colormatch_apply_f32")
     return out
 
 
+@_on_device
 def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
-                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
+                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None) -> torch.Tensor:
     """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124).  Two passes over HBM:
     statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain."""
     x = _check_frames(images, channels=3)
     if ref_ms is None:
         ref = _check_frames(reference_image.to(x.device), "reference_image", channels=3)
-        ref_ms = finalize_stats(lab_stats(ref))
+        ref_ms = finalize_stats(lab_stats(ref, cm_math))
     if cache_lab:
-        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength)))
-    img_ms = finalize_stats(lab_stats(x))
-    return colormatch_apply(x, img_ms, ref_ms, match_strength)
+        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math))
+    img_ms = finalize_stats(lab_stats(x, cm_math))
+    return colormatch_apply(x, img_ms, ref_ms, match_strength, cm_math)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -403,6 +459,7 @@ class ChainSpec:
     colormatch: Optional[tuple] = None     # (ref_ms [R,3,2] fp32 device tensor, match_strength)
     sharpen: Optional[tuple] = None        # (op name, strength, zero_border)
     variant: int = 0
+    cm_math: object = None                 # None = default_cm_math(); "device" / "fast" (colour-match arithmetic policy)
 
 
 def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
@@ -436,9 +493,11 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
         d.strength = _f32(strength)
     d.stages = stages
     d.variant = spec.variant
+    d.cm_math = _cm_math(spec.cm_math)
     return d
 
 
+@_on_device
 def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 lab_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Colour-match pass 1 on its own: fp64 (n, mean, M2) of Lab(grain -> LUT (images)) per frame, optionally
@@ -458,7 +517,7 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     lib = _hip.lib()
     for f0, nf, plan in segments:
         keep = []
-        d = _chain_desc(ChainSpec(grain=spec.grain, lut=spec.lut, variant=spec.variant), plan, keep)
+        d = _chain_desc(ChainSpec(grain=spec.grain, lut=spec.lut, variant=spec.variant, cm_math=spec.cm_math), plan, keep)
         nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
         scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
         src = C.c_void_p(x.data_ptr() + f0 * fe * 4)
@@ -468,6 +527,7 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     return stats
 
 
+@_on_device
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
                 lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:

@@ -64,13 +64,13 @@ def allreduce_stats(local: torch.Tensor, group=None, mode: str = "allreduce") ->
 
 
 def reference_stats_sharded(reference_image: torch.Tensor, rank: int, world: int, group=None,
-                            mode: str = "allreduce") -> torch.Tensor:
+                            mode: str = "allreduce", cm_math=None) -> torch.Tensor:
     """Lab (mean, std+1e-5) of the reference frame(s) with the rows split across the ranks: each rank reduces
     its H/world rows on its own GPU, then one collective merges the triples.  Returns fp32 ``[R, 3, 2]``."""
     from . import ops
     r0, r1 = row_slice(int(reference_image.shape[1]), rank, world)
     if r1 > r0:
-        part = ops.lab_stats(reference_image[:, r0:r1].contiguous())
+        part = ops.lab_stats(reference_image[:, r0:r1].contiguous(), cm_math)
     else:   # more ranks than rows: contribute the neutral element
         part = torch.zeros((reference_image.shape[0], 3, 3), dtype=torch.float64, device=reference_image.device)
     merged = allreduce_stats(part, group=group, mode=mode)

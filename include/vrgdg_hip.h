@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 1
+#define VRG_ABI_VERSION 2
 
 enum vrg_status {
     VRG_OK = 0,
@@ -121,6 +121,15 @@ int vrg_lut3d_f32(const float* in, float* out, int64_t pixels, int32_t channels,
 int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
                        int32_t channels, int32_t op, int32_t border, float strength, void* stream);
 
+/* Arithmetic policy of the Lab transforms and the statistics transfer (a7/a8).
+ *   VRG_CM_MATH_DEVICE (default): every element-wise op is the one torch-ROCm executes for it on this GPU -- what the
+ *       reference computes when ComfyUI runs ColorMatchToReference on the MI355X (nodes.py:98-115): `tensor / python
+ *       scalar` = x * fl(1/c), torch.pow = ocml powf, tensor / tensor = IEEE quotient.  Bit-equal to the restated kornia
+ *       formulas evaluated by torch on the device (tests/test_gpu_parity.py), given the same statistics.
+ *   VRG_CM_MATH_FAST: IEEE quotients (torch-CPU behaviour) and table-driven powers with <= 0.534 ulp error instead of
+ *       ocml powf (~190 instructions): a few ulp from either reference, about 2.3x faster. */
+enum vrg_cm_math { VRG_CM_MATH_DEVICE = 0, VRG_CM_MATH_FAST = 1 };
+
 /* ---------------------------------------------------------------------------------------------
  * a7/a8  Colour match (nodes.py:91-124 + kornia.color Lab transforms).
  * Pass 1: per-frame Lab statistics.  stats[f][c] = {n, mean, M2} in fp64 (M2 = sum (x-mean)^2),
@@ -132,11 +141,11 @@ int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, int32_t heig
  * ------------------------------------------------------------------------------------------- */
 int64_t vrg_lab_stats_scratch_bytes(int64_t frames);
 int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
-                      double* stats, void* scratch, void* stream);
+                      double* stats, void* scratch, int32_t cm_math, void* stream);
 int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames, void* stream);
 int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
                              const float* img_ms, const float* ref_ms, int32_t ref_frames,
-                             float k, float one_minus_k, void* stream);
+                             float k, float one_minus_k, int32_t cm_math, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused chain: grain -> LUT -> colour match -> 3x3 sharpen in one pass over HBM (12 B/px read +
@@ -153,7 +162,8 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
 
 typedef struct vrg_chain_desc {
     int32_t stages;               /* VRG_STAGE_* bits */
-    int32_t variant;              /* 0 = automatic; 1 = LDS-tile / point-wise kernels; 2 = register-resident wave-march kernel */
+    int32_t variant;              /* 0 = automatic; 1 = LDS-tile / point-wise kernels; 2 = register-resident wave-march kernel
+                                     (chains it cannot take -- colour match, chunks > 0x60000000 elements -- use 1) */
     /* grain */
     float intensity, sat, one_minus_sat;
     vrg_noise_desc noise;
@@ -166,6 +176,8 @@ typedef struct vrg_chain_desc {
     float k, one_minus_k;
     /* sharpen */
     int32_t stencil_op, border; float strength;
+    /* colour-match arithmetic policy: enum vrg_cm_math (0 = device-exact, the default) */
+    int32_t cm_math;
 } vrg_chain_desc;
 
 int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
@@ -248,6 +260,10 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);
+/* Element-wise pieces of the colour-match arithmetic for the parity tests (n values, or n triples for op >= 5):
+ * op 0 ocml powf(x, y); 1 x * fl(1/y); 2 x / y; 3 fast-policy pow_pos(x, y); 4 fast-policy cube root;
+ * 5 / 6 rgb->Lab / Lab->rgb with the device policy; 7 / 8 the same with the fast policy. */
+int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records. */
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);

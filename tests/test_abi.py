@@ -38,7 +38,7 @@ def test_struct_layouts_match_the_header(hip):
 
 def test_versions_and_error_strings(hip):
     lib = hip.load_library()
-    assert lib.vrg_abi_version() == 1
+    assert lib.vrg_abi_version() == 2
     assert lib.vrg_error_string(0) == b"ok"
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8
@@ -64,7 +64,7 @@ def test_argument_validation_without_device(hip):
     assert lib.vrg_stencil3x3_f32(one, one, 0, 4, 4, 3, 0, 0, 0.5, null) == 0
     assert lib.vrg_stencil3x3_f32(one, one, 1, 4, 4, 3, 9, 0, 0.5, null) == 1
     assert lib.vrg_stencil3x3_f32(one, one, 1, 4, 4, 3, 0, 5, 0.5, null) == 1
-    assert lib.vrg_colormatch_apply_f32(one, one, 1, 4, 4, null, one, 1, 1.0, 0.0, null) == 1
+    assert lib.vrg_colormatch_apply_f32(one, one, 1, 4, 4, null, one, 1, 1.0, 0.0, 0, null) == 1
     cd = hip.ChainDesc(stages=0)
     assert lib.vrg_fused_chain_f32(one, one, 1, 4, 4, C.byref(cd), null) == 1
     cd = hip.ChainDesc(stages=8, variant=99, stencil_op=0, border=0)

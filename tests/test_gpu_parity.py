@@ -1,7 +1,9 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the committed reference
 fixtures, on a real MI355X.  Integer / index work and everything whose arithmetic is fully specified
-(grain, LUT, stencils, fused chains without colour match) is BIT-EXACT; colour match is held to a stated
-tolerance (powf is an ulp-level library choice and kornia is unpinned).
+(grain, LUT, stencils, fused chains without colour match) is BIT-EXACT.  Colour match: the element-wise path of the
+default "device" policy is BIT-EQUAL to the device oracle (the restated kornia formulas evaluated by torch on this GPU);
+what remains -- per-frame fp32 reductions whose value depends on the batch shape in the reference itself -- is held to
+a budget stated in ulps (kornia itself is unpinned: the restatement is the oracle).
 
 Noise: the reference draws grain with torch.randn on the device; the device oracle for "identical seeds" is
 therefore torch.randn itself on this GPU -- our in-register Philox/Box-Muller must reproduce it bit for bit,
@@ -59,7 +61,7 @@ def assert_bit_equal(got, want, what=""):
 def test_native_library_is_loaded(pkg):
     from comfyui_vrgamedevgirl_amd import _hip
     lib = _hip.lib()
-    assert lib.vrg_abi_version() == 1
+    assert lib.vrg_abi_version() == 2
     with open("/proc/self/maps") as fh:
         assert any("libvrgdg_hip.so" in line for line in fh), "HIP extension not mapped into the process"
     import ctypes as C
@@ -274,47 +276,235 @@ def test_sharpen_nodes(pkg, dev):
 
 
 # ---------------------------------------------------------------------------------------- colour match
-CM_ABS_TOL = 2e-5   # fp32 RGB; powf (ocml vs Sleef) differs by an ulp per call and a,b amplify it by 500 / 200
+# Two arithmetic policies (include/vrgdg_hip.h, enum vrg_cm_math):
+#   "device" (default): held BIT-EQUAL to the device oracle -- oracle/restated.py (kornia's Lab formulas + nodes.py:91-124)
+#       evaluated by torch on this GPU, which is what the reference executes here -- for the whole element-wise path: every
+#       piece, the Lab image, and the apply pass given the same statistics.  The per-frame mean / std are torch fp32
+#       reductions in the reference (their value depends on the batch shape, i.e. on the node's own batch_size widget);
+#       ours are fp64-accumulated: compared in ulps against the fp64 statistics of the same Lab image.
+#   "fast": table-driven powers; compared with both references in units of ulp(1.0) = 2^-23 of the [0,1] output.
+# Budgets below are 2x the maxima measured on MI355X (profiles/r02_cm_parity.json); they replace round 1's 2e-5 (168 ulp).
+ULP1 = 2.0 ** -23
+CM_E2E_DEVICE_ULP = 48      # device policy vs device oracle, end to end: statistics differences only (measured max 19.25)
+CM_FAST_VS_CPU_ULP = 64     # fast policy vs the reference on the CPU (Sleef powf, IEEE division) (measured max 26 on large frames)
+CM_CROSS_REF_ULP = 192      # a policy against the OTHER reference on small frames (the two references themselves differ by up to 31
+                            # ulp on 540p frames and more on thumbnails, where a statistics ulp moves every pixel)
+MEASURED = {}
 
 
-def test_lab_statistics_against_fp64_truth(ops, dev):
-    x = _rand((3, 96, 128, 3), 41)
+def _unit_ulps(got, want):
+    return float((got.double().cpu() - want.double().cpu()).abs().max() / ULP1)
+
+
+def _record(key, value):
+    MEASURED[key] = max(MEASURED.get(key, 0.0), float(value))
+    try:
+        import json
+        os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "cm_test_measured.json"), "w") as fh:
+            json.dump(MEASURED, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _cm_image(shape, seed):
+    x = _rand(shape, seed)
+    x[0, 0, :8, :] = torch.tensor([0.0, 1.0, 0.04045, 0.040450003, 0.5, 1e-6, 0.0031308, 0.9999999]).view(8, 1)
+    return x
+
+
+def _dbg(pkg, x, op, y=0.0, triples=False):
+    from comfyui_vrgamedevgirl_amd import _hip
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    n = x.numel() // (3 if triples else 1)
+    _hip.check(_hip.lib().vrg_debug_cm_math(_hip.ptr(x), _hip.ptr(out), n, op, float(np.float32(y)), _hip.current_stream()), "vrg_debug_cm_math")
+    return out
+
+
+def _all_floats(lo, hi, dev):
+    a, b = int(np.float32(lo).view(np.int32)), int(np.float32(hi).view(np.int32))
+    return torch.arange(a, b + 1, dtype=torch.int32, device=dev).view(torch.float32)
+
+
+def test_zero_border_stencils_against_the_device_conv2d(ops, dev):
+    """use_gpu=True in the reference runs F.avg_pool2d / F.conv2d ON THE GPU (nodes.py:171, 248-257, 325-348).  avg_pool2d
+    there is a plain raster sum: bit-equal.  conv2d is MIOpen: NOT a sum of the five (six) products in any order -- e.g. its
+    corner output -1.7550163 for the two non-zero products -1 and -0.75501657 whose only fp32 sum is -1.7550166 (tools/
+    conv_order_search.py finds no summation tree; the algorithm is Winograd-class) -- so it cannot be matched bit for bit;
+    our raster-order sum is the correctly ordered fp32 sum (== torch's CPU conv2d on the bench box) and stays within
+    4 ulp(1.0) of the device result (measured max 3.5 / 3.0)."""
+    import torch.nn.functional as F
+    x = _rand((2, 135, 240, 3), 141).to(dev)
+    nchw = x.permute(0, 3, 1, 2).contiguous()
+    blur = F.avg_pool2d(nchw, kernel_size=3, stride=1, padding=1)
+    want = (nchw + 0.7 * (nchw - blur)).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+    assert_bit_equal(ops.stencil3x3(x, "unsharp", 0.7, zero_border=True), want, "unsharp, zero border vs avg_pool2d on the device")
+    kl = torch.tensor([[0, -1, 0], [-1, 4, -1], [0, -1, 0]], dtype=torch.float32, device=dev).view(1, 1, 3, 3).repeat(3, 1, 1, 1)
+    want = (nchw + 0.7 * F.conv2d(nchw, kl, padding=1, groups=3)).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+    d = _unit_ulps(ops.stencil3x3(x, "laplacian", 0.7, zero_border=True), want)
+    _record("stencil.laplacian_zero_vs_device_conv2d", d)
+    assert d <= 8, d
+    kx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32, device=dev).view(1, 1, 3, 3).repeat(3, 1, 1, 1)
+    ky = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32, device=dev).view(1, 1, 3, 3).repeat(3, 1, 1, 1)
+    gx, gy = F.conv2d(nchw, kx, padding=1, groups=3), F.conv2d(nchw, ky, padding=1, groups=3)
+    want = (nchw + 0.7 * torch.sqrt(gx ** 2 + gy ** 2 + 1e-6)).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+    d = _unit_ulps(ops.stencil3x3(x, "sobel", 0.7, zero_border=True), want)
+    _record("stencil.sobel_zero_vs_device_conv2d", d)
+    assert d <= 8, d
+
+
+@pytest.mark.parametrize("y,lo,hi", [(2.4, 2.0 ** -12, 2.0), (1 / 2.4, 0.0031308, 4.0), (1 / 3.0, 0.008856, 4.0)])
+def test_device_math_pow_is_torch_pow_for_every_input_of_the_domain(pkg, dev, y, lo, hi):
+    """ocml powf as this hipcc links it == torch.pow on the device (ocml powf as libtorch_hip.so carries it), for EVERY fp32
+    base the Lab transforms can feed it: 7.4e7 .. 1.1e8 inputs per exponent."""
+    x = _all_floats(lo, hi, dev)
+    assert torch.equal(_dbg(pkg, x, 0, y), torch.pow(x, y))
+    sp = torch.tensor([0.0, -0.0, -0.5, -1.0, 1.0, float("inf"), float("nan"), 1e-38, 1e-45, -1e-30, 3.0e38], device=dev)
+    a, b = _dbg(pkg, sp, 0, y), torch.pow(sp, y)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
+def test_device_math_divisions_are_torch_divisions(pkg, dev):
+    """tensor / python scalar on the device is x * fl32(1 / c) with the reciprocal of the Python double (ATen
+    BinaryDivTrueKernel) -- NOT the IEEE quotient and, for 1.055, not x * (1.0f / 1.055f) either; tensor / tensor is IEEE."""
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.cat([torch.rand(1 << 22, generator=g, device=dev) * 2 - 0.5, _all_floats(2.0 ** -10, 2.0 ** -9, dev),
+                   torch.randn(1 << 20, generator=g, device=dev) * 100])
+    xn = x.cpu().numpy()
+    for c in (1.055, 12.92, 116.0, 500.0, 200.0, 7.787):
+        assert torch.equal((x / c).cpu(), torch.from_numpy(xn * np.float32(1.0 / c))), c
+    assert not torch.equal((x / 1.055).cpu(), torch.from_numpy(xn / np.float32(1.055)))
+    for c in (0.95047, 1.08883, 0.40001):
+        want = x / torch.full((1,), c, dtype=torch.float32, device=dev)
+        assert torch.equal(want.cpu(), torch.from_numpy(xn / np.float32(c))), c
+        assert torch.equal(_dbg(pkg, x, 2, c), want), c
+    assert torch.equal(torch.pow(x, 3.0).cpu(), torch.from_numpy((xn * xn) * xn))        # pow(., 3.0) is (x*x)*x
+
+
+def test_lab_transforms_bit_equal_device_oracle(pkg, dev):
+    x = _cm_image((3, 270, 480, 3), 11).to(dev)
+    want_lab = R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    assert_bit_equal(_dbg(pkg, x, 5, triples=True), want_lab, "rgb_to_lab, device policy vs torch on the device")
+    g = torch.Generator(device=dev).manual_seed(5)
+    lab = want_lab.clone()
+    lab[1:] = lab[1:] * (1.0 + 0.3 * torch.randn(lab[1:].shape, generator=g, device=dev))      # out of gamut: clamps, negative fz
+    want_rgb = R.kornia_lab_to_rgb(lab.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    assert_bit_equal(_dbg(pkg, lab, 6, triples=True), want_rgb, "lab_to_rgb, device policy vs torch on the device")
+    # the fast policy: distance to the same oracle, and to the reference on the CPU, in ulp(1.0) of the RGB output
+    fast_rgb = _dbg(pkg, lab, 8, triples=True)
+    cpu_rgb = R.kornia_lab_to_rgb(lab.permute(0, 3, 1, 2).cpu()).permute(0, 2, 3, 1).contiguous()
+    _record("lab_to_rgb.fast_vs_device_oracle", _unit_ulps(fast_rgb, want_rgb))
+    _record("lab_to_rgb.fast_vs_cpu_oracle", _unit_ulps(fast_rgb, cpu_rgb))
+    _record("lab_to_rgb.cpu_oracle_vs_device_oracle", _unit_ulps(cpu_rgb, want_rgb))
+    assert _unit_ulps(fast_rgb, want_rgb) <= 2 * 130 and _unit_ulps(fast_rgb, cpu_rgb) <= 2 * 130
+
+
+def test_lab_image_of_the_statistics_pass_bit_equal_device_oracle(ops, dev):
+    """pass 1 stores the Lab image pass 2 reads: general kernel, and LUT -> Lab, against torch on the device"""
+    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
+    x = _cm_image((2, 96, 128, 3), 12).to(dev)
+    lab = torch.empty_like(x)
+    ops.chain_stats(x, ops.ChainSpec(), lab_out=lab)
+    assert_bit_equal(lab, R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous(), "Lab image")
+    ops.chain_stats(x, ops.ChainSpec(lut=(dlut, 10.0)), lab_out=lab)
+    y = ops.lut3d(x, dlut, 10.0)
+    assert_bit_equal(lab, R.kornia_rgb_to_lab(y.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous(), "Lab image after the LUT")
+
+
+def _stats_per_frame(x_dev, batch_size=1):
+    """mean / std+1e-5 the way the reference forms them: torch reductions per batch_size chunk (their fp32 value depends on
+    the chunk shape).  Returns [F,3,2] fp32 and the NCHW Lab image."""
+    lab = R.kornia_rgb_to_lab(x_dev.permute(0, 3, 1, 2))
+    ms = []
+    for i in range(0, lab.shape[0], batch_size):
+        mu, sd = R.lab_stats(lab[i:i + batch_size])
+        ms.append(torch.stack([mu.flatten(1), sd.flatten(1)], dim=-1))
+    return torch.cat(ms, dim=0).contiguous(), lab
+
+
+@pytest.mark.parametrize("k,bs", [(1.0, 1), (0.35, 1), (0.8, 2)])
+def test_colour_match_apply_bit_equal_device_oracle_with_injected_statistics(ops, dev, k, bs):
+    """The reference's own device statistics fed to the HIP apply pass: what is left is the element-wise path
+    ((lab - mu) / sigma * sigma_ref + mu_ref, blend, Lab -> RGB, clamp) -- bit-equal to the device oracle."""
+    x = _cm_image((4, 135, 240, 3), 43).to(dev)
+    ref = (_rand((1, 64, 80, 3), 44) * 0.7 + 0.1).to(dev)
+    ims, _ = _stats_per_frame(x, bs)
+    rms, _ = _stats_per_frame(ref, 1)
+    want = R.color_match(x, ref, k, bs)                                  # device oracle end to end, same chunking
+    assert_bit_equal(ops.colormatch_apply(x, ims, rms, k, cm_math="device"), want, "apply pass with the oracle's statistics")
+    # and the other direction: OUR statistics fed to the oracle's element-wise path == our end-to-end result
+    oms, orms = ops.finalize_stats(ops.lab_stats(x)), ops.finalize_stats(ops.lab_stats(ref))
+    lab = R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2))
+    alt = R.color_match_apply(lab, oms[..., 0].view(4, 3, 1, 1), oms[..., 1].view(4, 3, 1, 1), orms[..., 0].view(1, 3, 1, 1),
+                              orms[..., 1].view(1, 3, 1, 1), k).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+    assert_bit_equal(ops.color_match(x, ref, k), alt, "whole colour match vs the oracle evaluated with our statistics")
+
+
+def test_lab_statistics_against_fp64_and_the_device_reductions(ops, dev):
+    x = _cm_image((3, 96, 128, 3), 41)
     x[2] = 0.25                                             # constant frame: sigma must be exactly 0
-    stats = ops.lab_stats(x.to(dev)).cpu().numpy()
-    lab = truth64.rgb_to_lab64(x.numpy())
-    mu, sd = truth64.lab_stats64(lab)
+    xd = x.to(dev)
+    stats = ops.lab_stats(xd)
+    lab = R.kornia_rgb_to_lab(xd.permute(0, 3, 1, 2)).double()           # the (bit-equal) Lab image, then fp64 statistics
     n = 96 * 128
-    assert np.array_equal(stats[..., 0], np.full((3, 3), float(n)))
-    assert np.max(np.abs(stats[..., 1] - mu)) < 3e-5
-    got_sd = np.sqrt(stats[..., 2] / (n - 1))
-    assert np.max(np.abs(got_sd - (sd - np.float64(np.float32(1e-5))))) < 3e-5
-    assert np.all(stats[2, :, 2] == 0.0)
-    ms = ops.finalize_stats(torch.from_numpy(stats).to(dev)).cpu().numpy()
-    assert np.array_equal(ms[..., 0], stats[..., 1].astype(np.float32))
-    assert np.array_equal(ms[..., 1], got_sd.astype(np.float32) + np.float32(1e-5))
+    mu64, var64 = lab.mean(dim=[2, 3]), lab.var(dim=[2, 3], unbiased=True)
+    s = stats.cpu().numpy()
+    assert np.array_equal(s[..., 0], np.full((3, 3), float(n)))
+    assert np.max(np.abs(s[..., 1] - mu64.cpu().numpy()) / np.maximum(np.abs(mu64.cpu().numpy()), 1e-30)) < 1e-12
+    assert np.all(s[2, :, 2] == 0.0)
+    assert np.max(np.abs(s[:2, :, 2] / (n - 1) - var64.cpu().numpy()[:2]) / var64.cpu().numpy()[:2]) < 1e-11
+    ms = ops.finalize_stats(stats)
+    got_sd = np.sqrt(s[..., 2] / (n - 1))
+    assert np.array_equal(ms.cpu().numpy()[..., 0], s[..., 1].astype(np.float32))
+    assert np.array_equal(ms.cpu().numpy()[..., 1], got_sd.astype(np.float32) + np.float32(1e-5))
+    # in ulps: ours (fp64 sums, one rounding) and torch's fp32 reductions on the device, both against the fp64 statistics
+    t_ms, _ = _stats_per_frame(xd[:2], 1)
+    sd64 = var64.sqrt() + float(np.float32(1e-5))
+
+    def eps(a, b):
+        return float(((a.double() - b).abs() / (b.abs() * ULP1)).max())
+    ours = (eps(ms[:2, :, 0], mu64[:2]), eps(ms[:2, :, 1], sd64[:2]))
+    theirs = (eps(t_ms[..., 0], mu64[:2]), eps(t_ms[..., 1], sd64[:2]))
+    _record("stats.ours_vs_fp64.mean_eps", ours[0]); _record("stats.ours_vs_fp64.std_eps", ours[1])
+    _record("stats.torch_device_vs_fp64.mean_eps", theirs[0]); _record("stats.torch_device_vs_fp64.std_eps", theirs[1])
+    assert ours[0] <= 0.5 and ours[1] <= 1.0                 # mean: one rounding; std: sqrt rounded to fp32, then + 1e-5f in fp32
     # deterministic and independent of how many frames one call covers
-    again = ops.lab_stats(x[1:2].to(dev)).cpu().numpy()
-    assert np.array_equal(again[0], stats[1])
+    again = ops.lab_stats(xd[1:2]).cpu().numpy()
+    assert np.array_equal(again[0], s[1])
+    assert torch.equal(ops.lab_stats(xd, cm_math="fast")[..., 0], stats[..., 0])
 
 
-def test_colour_match_apply_with_oracle_statistics(ops, dev):
-    x = _rand((2, 40, 40, 3), 43)
-    ref = _rand((1, 8, 8, 3), 44)
-    mu, sd = R.lab_stats(R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)))
-    rmu, rsd = R.lab_stats(R.kornia_rgb_to_lab(ref.permute(0, 3, 1, 2)))
-    ims = torch.stack([mu.flatten(1), sd.flatten(1)], dim=-1).contiguous().to(dev)      # [F,3,2]
-    rms = torch.stack([rmu.flatten(1), rsd.flatten(1)], dim=-1).contiguous().to(dev)
-    got = ops.colormatch_apply(x.to(dev), ims, rms, 0.8).cpu()
-    want = R.color_match(x, ref, 0.8, 1)
-    # same statistics on both sides: what is left is ocml powf vs Sleef powf (an ulp per call, amplified by the
-    # 500/200 Lab gains and the inverse transform); measured 7.7e-6 on MI355X
-    assert (got - want).abs().max() <= CM_ABS_TOL, (got - want).abs().max()
+@pytest.mark.parametrize("shape,ref_shape,k,bs", [((4, 135, 240, 3), (1, 64, 80, 3), 1.0, 1), ((3, 270, 480, 3), (1, 300, 400, 3), 0.35, 1),
+                                                  ((4, 96, 128, 3), (4, 50, 60, 3), 0.8, 4)])
+def test_colour_match_end_to_end_ulp_budget_vs_device_oracle(pkg, ops, dev, shape, ref_shape, k, bs):
+    """Node end to end (device policy) against the device oracle: the element-wise path is bit-equal (tests above), the
+    distance is the statistics (fp64-accumulated here, batch-shape dependent fp32 reductions there)."""
+    x, ref = _cm_image(shape, 31), _rand(ref_shape, 32) * 0.7 + 0.1
+    node = pkg.NODE_CLASS_MAPPINGS["ColorMatchToReference"]()
+    (out,) = node.match_color(x, ref, k, bs)
+    want = R.color_match(x.to(dev), ref.to(dev), k, bs).cpu()
+    d = _unit_ulps(out, want)
+    _record(f"e2e.device_vs_device_oracle.{shape[1]}p", d)
+    assert d <= CM_E2E_DEVICE_ULP, d
+    cpu = R.color_match(x, ref, k, bs)
+    _record(f"e2e.cpu_oracle_vs_device_oracle.{shape[1]}p", _unit_ulps(cpu, want))
+    _record(f"e2e.device_vs_cpu_oracle.{shape[1]}p", _unit_ulps(out, cpu))
+    fast = ops.color_match(x.to(dev), ref.to(dev), k, cm_math="fast").cpu() if ref_shape[0] == 1 else None
+    if fast is not None:
+        _record(f"e2e.fast_vs_cpu_oracle.{shape[1]}p", _unit_ulps(fast, cpu))
+        _record(f"e2e.fast_vs_device_oracle.{shape[1]}p", _unit_ulps(fast, want))
+        assert _unit_ulps(fast, cpu) <= CM_FAST_VS_CPU_ULP and _unit_ulps(fast, want) <= CM_CROSS_REF_ULP
 
 
 def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
+    """The reference-generated CPU fixtures (tests/golden/colormatch.npz: the reference's match_color control flow run on
+    the CPU with the restated kornia): both policies stay within the cross-reference band, no further from the fp64 truth
+    than the reference's own fp32 result, and keep the control flow (chunking, reference batch, errors)."""
     z = _npz("colormatch.npz")
     x, ref1, ref4 = _t(z["x"]), _t(z["ref1"]), _t(z["ref4"])
     node = pkg.NODE_CLASS_MAPPINGS["ColorMatchToReference"]()
+    tol = CM_CROSS_REF_ULP * ULP1
     for key, ref, k, bs in (("out.ref1.k1.bs1", ref1, 1.0, 1), ("out.ref1.k0.35.bs3", ref1, 0.35, 3), ("out.ref4.k0.8.bs4", ref4, 0.8, 4)):
         (out,) = node.match_color(x, ref, k, bs)
         truth = truth64.color_match64(x.numpy(), ref.numpy(), k)
@@ -322,18 +512,41 @@ def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
         err_ours = np.abs(out.numpy().astype(np.float64) - truth).reshape(4, -1).max(axis=1)
         err_ref = np.abs(gold.astype(np.float64) - truth).reshape(4, -1).max(axis=1)
         # bar: no further from the fp64 truth than the reference's own fp32 result, + tol
-        assert np.all(err_ours <= err_ref + CM_ABS_TOL), (key, err_ours, err_ref)
+        assert np.all(err_ours <= err_ref + tol), (key, err_ours, err_ref)
         # well-conditioned frames also agree with the reference output directly; frame 3 is constant
         # (sigma = 0): there the reference's fp32 mean is off by an ulp and its output is chaotic (0.6 off truth)
-        assert np.abs(out.numpy()[:3] - gold[:3]).max() <= CM_ABS_TOL, key
-        assert err_ours[3] <= CM_ABS_TOL
+        d = float(np.abs(out.numpy()[:3] - gold[:3]).max() / ULP1)
+        _record("fixtures.device_vs_cpu_fixture", d)
+        assert d <= CM_CROSS_REF_ULP, (key, d)
+        assert err_ours[3] <= tol
     with pytest.raises(RuntimeError):
         node.match_color(x, ref4[:3], 1.0, 4)                # reference batch neither 1 nor the chunk size
     from comfyui_vrgamedevgirl_amd import ops
     xd = x.to(dev)
-    a = ops.color_match(xd, ref1.to(dev), 0.35)              # Lab cached between the passes (default)
-    b = ops.color_match(xd, ref1.to(dev), 0.35, cache_lab=False)
-    assert torch.equal(a, b)
+    for mode in ("device", "fast"):
+        a = ops.color_match(xd, ref1.to(dev), 0.35, cm_math=mode)              # Lab cached between the passes (default)
+        b = ops.color_match(xd, ref1.to(dev), 0.35, cache_lab=False, cm_math=mode)
+        assert torch.equal(a, b), mode
+    fast = ops.color_match(xd, ref1.to(dev), 1.0, cm_math="fast").cpu().numpy()
+    d = float(np.abs(fast[:3] - z["out.ref1.k1.bs1"][:3]).max() / ULP1)
+    _record("fixtures.fast_vs_cpu_fixture", d)
+    assert d <= CM_CROSS_REF_ULP
+
+
+def test_colour_match_fast_policy_apply_with_cpu_oracle_statistics(ops, dev):
+    """Fast policy, statistics injected from the reference on the CPU: the element-wise distance to the CPU reference
+    (pow_pos vs Sleef powf; the divisions are IEEE on both sides)."""
+    x = _rand((2, 40, 40, 3), 43)
+    ref = _rand((1, 8, 8, 3), 44)
+    mu, sd = R.lab_stats(R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)))
+    rmu, rsd = R.lab_stats(R.kornia_rgb_to_lab(ref.permute(0, 3, 1, 2)))
+    ims = torch.stack([mu.flatten(1), sd.flatten(1)], dim=-1).contiguous().to(dev)      # [F,3,2]
+    rms = torch.stack([rmu.flatten(1), rsd.flatten(1)], dim=-1).contiguous().to(dev)
+    got = ops.colormatch_apply(x.to(dev), ims, rms, 0.8, cm_math="fast").cpu()
+    want = R.color_match(x, ref, 0.8, 2)
+    d = _unit_ulps(got, want)
+    _record("apply.fast_vs_cpu_oracle_injected_stats", d)
+    assert d <= CM_CROSS_REF_ULP, d
 
 
 # ---------------------------------------------------------------------------------------- fused chain
@@ -447,9 +660,11 @@ def test_fused_chain_with_colour_match(ops, dev, variant):
     torch.manual_seed(5)
     o = R.fast_film_grain(x, 0.04, 0.5, 2, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
     o = R.apply_lut_with_strength(o, data, 10.0)
-    o = R.color_match(o, ref, 0.9, 1)
+    o = R.color_match(o.to(dev), ref.to(dev), 0.9, 1).cpu()         # the colour match of the reference, evaluated on the device
     o = R.unsharp(o, 0.5, False)
-    assert (fused.cpu() - o).abs().max() <= 4 * CM_ABS_TOL      # unsharp at 0.5 amplifies the colour-match tolerance by <= 1.5x
+    d = _unit_ulps(fused, o)
+    _record("e2e.fused_chain4_vs_device_oracle", d)
+    assert d <= 2 * CM_E2E_DEVICE_ULP, d                            # unsharp at 0.5 amplifies a difference by <= 1 + 2*0.5*(8/9)
 
 
 @pytest.mark.parametrize("shape,bs", [((4, 48, 80, 3), 2), ((3, 96, 128, 3), 0), ((2, 540, 960, 3), 1), ((4, 270, 480, 3), 4)])
@@ -1032,8 +1247,9 @@ def test_lut_extreme_sizes(ops, dev, n):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("VRG_SWEEP_SEEDS", "16"))))
 def test_randomized_colour_match_chain_sweep(ops, pkg, dev, seed):
-    """Random shapes / reference batches / strengths for chains that contain colour match: within CM_ABS_TOL of the
-    oracle (the stage is tolerance-level: kornia unpinned, torch's own fp32 reductions), fused == stand-alone operators."""
+    """Random shapes / reference batches / strengths for chains that contain colour match, against the oracle with its
+    colour match evaluated on the device: element-wise bit-equal, so the distance is the per-frame statistics (fp64 sums
+    here, torch fp32 reductions there) -- on these thumbnails (6..80 px) an ulp of a mean moves every pixel of the frame."""
     import random
     rnd = random.Random(5000 + seed)
     H, W = rnd.randint(6, 80), rnd.randint(6, 120)
@@ -1057,12 +1273,13 @@ def test_randomized_colour_match_chain_sweep(ops, pkg, dev, seed):
         o = R.fast_film_grain(o, grain[0], grain[1], grain[2], noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
     if lut_s is not None:
         o = R.apply_lut_with_strength(o, data, lut_s)
-    o = R.color_match(o, ref, k, n_ref).contiguous()
+    o = R.color_match(o.to(dev), ref.to(dev), k, n_ref).cpu().contiguous()
     if sharpen:
         o = R.unsharp(o, sharpen[1], False).contiguous()
-    err = (got.cpu() - o).abs().max().item()
+    err = _unit_ulps(got, o)
     amp = 1.0 + (sharpen[1] * 2 if sharpen else 0.0)           # unsharp amplifies a difference by up to 1 + 2*strength*(8/9)
-    assert err <= CM_ABS_TOL * amp, (seed, err, spec)
+    _record("e2e.random_sweep_vs_device_oracle_over_amp", err / amp)
+    assert err <= CM_CROSS_REF_ULP * amp, (seed, err, spec)
 
 
 @pytest.mark.parametrize("n", [2, 5, 9, 17, 21, 22])

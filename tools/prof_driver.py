@@ -26,6 +26,7 @@ specs = {
     "chain3": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False)),
     "chain3_v1": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False), variant=1),
     "chain4": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False)),
+    "chain4fast": ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), cm_math="fast"),
     "lutsharp": ops.ChainSpec(lut=(lut, 10.0), sharpen=("unsharp", 0.5, False)),
     "grainsharp": ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)),
     "sharpen": ops.ChainSpec(sharpen=("unsharp", 0.5, False)),
