@@ -95,6 +95,12 @@ class NoisePlan:
                               grid_threads=s.grid_threads)
 
 
+def oversize_chunks(frames: int, frame_numel: int, chunk_frames: int) -> bool:
+    """Does the reference's chunk loop draw a torch.randn that ATen has to split (more than 2^29 elements)?"""
+    step = min(chunk_frames if chunk_frames > 0 else frames, frames)
+    return step * frame_numel > rng.MAX_CHUNK_NUMEL
+
+
 def plan_noise(frames: int, frame_numel: int, chunk_frames: int, device, generator=None):
     """Reserve the generator range FastFilmGrain's chunk loop would consume (nodes.py:46-51).
     Returns (plan for the full chunks or None, plan for the ragged tail chunk or None, n_full_chunks)."""
@@ -131,6 +137,35 @@ def _grain_call(x, out, f0, nf, plan: NoisePlan, I32, S32, T32):
                                        _hip.current_stream()), "vrg_grain_f32")
 
 
+def _film_grain_oversize(x, out, grain_intensity, saturation_mix, chunk_frames, generator):
+    """RNG chunks beyond 2^29 elements (batch_size 0 or >= 22 4K / >= 87 1080p frames): torch runs such a randn as several
+    kernels over 32-bit indexable sub-ranges, each with its own grid and generator offset (rng.reserve_split).  The
+    sub-ranges are not frame -- not even pixel -- aligned, so the chunk's noise is materialised leaf by leaf with the
+    stream kernel (bit-identical to torch.randn) and applied with the injected-noise grain kernel: three passes over
+    the chunk instead of one, for a case the reference handles at one tenth of the speed."""
+    F = x.shape[0]
+    fe = x[0].numel()
+    step = min(chunk_frames if chunk_frames > 0 else F, F)
+    lib = _hip.lib()
+    I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
+    noise = torch.empty((step * fe,), dtype=torch.float32, device=x.device)
+    for f0 in range(0, F, step):
+        nf = min(step, F - f0)
+        numel = nf * fe
+        if numel > rng.MAX_CHUNK_NUMEL:
+            split = rng.reserve_split(numel, x.device, generator)
+            seed, leaves = split.seed, split.leaves
+        else:           # ragged tail chunk below the limit: one ordinary randn
+            st = rng.reserve(numel, 1, x.device, generator)
+            seed, leaves = st.seed, [(0, numel, st.grid_threads, st.offset0)]
+        for start, size, G, off in leaves:
+            d = _hip.NoiseDesc(seed0=seed, seed_stride=0, offset0=off, offset_stride=0, chunk0=0, chunk_frames=1, grid_threads=G)
+            _hip.check(lib.vrg_noise_f32(C.c_void_p(noise.data_ptr() + 4 * start), 1, size, C.byref(d), _hip.current_stream()), "vrg_noise_f32")
+        _hip.check(lib.vrg_grain_injected_f32(C.c_void_p(x.data_ptr() + 4 * f0 * fe), _hip.ptr(noise), C.c_void_p(out.data_ptr() + 4 * f0 * fe),
+                                              nf * fe // 3, I32, S32, T32, _hip.current_stream()), "vrg_grain_injected_f32")
+    return out
+
+
 @_on_device
 def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: float, chunk_frames: int = 0,
                generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
@@ -142,6 +177,8 @@ def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: flo
     if F == 0:
         return out
     fe = H * W * 3
+    if plans is None and oversize_chunks(F, fe, chunk_frames):
+        return _film_grain_oversize(x, out, grain_intensity, saturation_mix, chunk_frames, generator)
     main, tail, n_full = plans if plans is not None else plan_noise(F, fe, chunk_frames, x.device, generator)
     I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
     done = 0
@@ -556,6 +593,15 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     if F == 0:
         return out
     fe = H * W * 3
+    if spec.grain is not None and plans is None and not u8 and oversize_chunks(F, fe, spec.grain[2]):
+        # RNG chunks that torch itself splits (see _film_grain_oversize): grain as its own pass, then the rest of the chain
+        import dataclasses
+        grained = film_grain(x, spec.grain[0], spec.grain[1], spec.grain[2], generator=generator)
+        rest = dataclasses.replace(spec, grain=None)
+        if rest.lut is None and rest.colormatch is None and rest.sharpen is None:
+            out.copy_(grained)
+            return out
+        return fused_chain(grained, rest, out=out, kernel_events=kernel_events, lab_workspace=lab_workspace, cache_lab=cache_lab)
     segments = [(0, F, None)]
     if spec.grain is not None:
         main, tail, n_full = plans if plans is not None else plan_noise(F, fe, spec.grain[2], x.device, generator)

@@ -16,9 +16,10 @@ import torch
 
 BLOCK = 256
 UNROLL = 4
-#: ATen splits a randn whose output cannot be 32-bit indexed (byte offsets); such chunks are not
-#: supported by the in-register path.
-MAX_CHUNK_NUMEL = (2 ** 31 - 1) // 4
+#: ATen runs a randn whose output cannot be indexed with 32-bit BYTE offsets (TensorIteratorBase::can_use_32bit_indexing:
+#: 1 + (numel - 1) * 4 <= INT32_MAX, i.e. numel <= 2^29) as several kernels over sub-ranges (`split_32bit`); the in-register
+#: noise of the fused kernels covers chunks up to this size, larger chunks go through `reserve_split`.
+MAX_CHUNK_NUMEL = 2 ** 29
 
 
 @dataclass(frozen=True)
@@ -65,6 +66,44 @@ class ChunkedStream:
     chunk_numel: int
 
 
+def split_32bit(numel: int, start: int = 0):
+    """The sub-ranges ``TensorIteratorBase::with_32bit_indexing`` (SplitUntil32Bit, TensorIterator.cpp) cuts a contiguous
+    fp32 tensor of `numel` elements into, in the order they are launched: the (single, coalesced) dimension is halved --
+    first half floor(n/2), second half the rest -- depth first, until a piece can be indexed with 32-bit byte offsets.
+    Returns [(start, size), ...] in memory order."""
+    if numel <= MAX_CHUNK_NUMEL:
+        return [(start, numel)]
+    first = numel // 2
+    return split_32bit(first, start) + split_32bit(numel - first, start + first)
+
+
+@dataclass
+class SplitStream:
+    """One oversize ``randn(numel)`` call: the leaves ATen launches, each with its own grid and generator offset."""
+    seed: int
+    leaves: list            # [(start, size, grid_threads, offset), ...]
+    chunk_numel: int
+
+
+def reserve_split(numel: int, device, generator=None, geom: DeviceGeometry | None = None) -> SplitStream:
+    """Generator bookkeeping of ONE ``torch.randn(numel)`` with numel > 2^29, exactly as ATen's
+    ``distribution_nullary_kernel`` does it (DistributionTemplates.h:118-140): the outer call takes its Philox state --
+    advancing the offset by the whole tensor's counter_offset, which is then never used -- before it notices that the
+    iterator needs splitting, and every sub-iterator call takes (and advances by) its own."""
+    geom = geom or device_geometry(device)
+    gen = _generator_for(device, generator)
+    seed = int(gen.initial_seed())
+    off = int(gen.get_offset())
+    off += counter_offset(numel, grid_threads(numel, geom))          # the outer call's unused reservation
+    leaves = []
+    for start, size in split_32bit(numel):
+        G = grid_threads(size, geom)
+        leaves.append((start, size, G, off))
+        off += counter_offset(size, G)
+    gen.set_offset(off)
+    return SplitStream(seed=seed & 0xFFFFFFFFFFFFFFFF, leaves=leaves, chunk_numel=numel)
+
+
 def _generator_for(device, generator):
     if generator is not None:
         return generator
@@ -78,9 +117,7 @@ def reserve(numel: int, n_chunks: int, device, generator=None, geom: DeviceGeome
     if numel <= 0 or n_chunks <= 0:
         raise ValueError("numel and n_chunks must be positive")
     if numel > MAX_CHUNK_NUMEL:
-        raise NotImplementedError(
-            f"a single noise chunk of {numel} elements exceeds 32-bit byte indexing ({MAX_CHUNK_NUMEL}); torch "
-            "splits such randn calls -- use a batch_size that keeps batch_size*H*W*3 below that")
+        raise ValueError(f"a noise chunk of {numel} elements is split by torch into 32-bit indexable sub-ranges: use reserve_split")
     geom = geom or device_geometry(device)
     gen = _generator_for(device, generator)
     G = grid_threads(numel, geom)

@@ -1229,6 +1229,39 @@ def test_baseline_scale_batch_crosses_32bit_element_counts(ops, dev):
         assert torch.equal(ops.adjust(x[a:b], t), whole[a:b]), (a, b)
 
 
+def test_grain_rng_chunks_beyond_32bit_byte_indexing(pkg, ops, dev):
+    """batch_size = 0 (or >= 22 4K / >= 87 1080p frames per chunk): the reference's randn_like has more than 2^29 elements and
+    ATen runs it as several kernels over 32-bit indexable sub-ranges, each with its own grid and generator offset
+    (nodes.py:46-51 works there).  Same noise, same result, same generator state afterwards as torch itself."""
+    free, _total = torch.cuda.mem_get_info(dev)
+    if free < 24 << 30:
+        pytest.skip("needs ~20 GB of free HBM")
+    F, H, W = 91, 1080, 1920                                     # 566,092,800 elements > 2^29: two leaves of 283,046,400
+    fe = H * W * 3
+    assert F * fe > 2 ** 29
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.rand((F, H, W, 3), generator=g, device=dev)
+    torch.manual_seed(2024)
+    got = ops.film_grain(x, 0.04, 0.5, chunk_frames=0)
+    state_after = torch.cuda.default_generators[dev.index].get_offset()
+    torch.manual_seed(2024)
+    noise = torch.randn_like(x)                                   # the reference's draw (nodes.py:51)
+    assert torch.cuda.default_generators[dev.index].get_offset() == state_after, "generator offset after an oversize chunk"
+    want = ops.film_grain_injected(x, noise, 0.04, 0.5)
+    assert torch.equal(got, want)
+    del noise, want
+    # the fused chain takes the same route for such chunks; and a ragged tail chunk below the limit after an oversize one
+    torch.manual_seed(2024)
+    fused = ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 0), sharpen=("unsharp", 0.5, False)))
+    assert torch.equal(fused, ops.stencil3x3(got, "unsharp", 0.5, False))
+    del fused, got
+    torch.manual_seed(11)
+    a = ops.film_grain(x, 0.1, 0.3, chunk_frames=88)              # chunks: 88 frames (oversize) + 3 frames
+    torch.manual_seed(11)
+    n1, n2 = torch.randn_like(x[:88]), torch.randn_like(x[88:])
+    assert torch.equal(a[:88], ops.film_grain_injected(x[:88], n1, 0.1, 0.3)) and torch.equal(a[88:], ops.film_grain_injected(x[88:], n2, 0.1, 0.3))
+
+
 @pytest.mark.parametrize("n", [2, 3, 5, 64])
 def test_lut_extreme_sizes(ops, dev, n):
     """Smallest legal cubes (one or two cells per axis) and a large one (64^3: 9.4 MB of records, beyond one XCD's L2)."""

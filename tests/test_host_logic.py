@@ -48,18 +48,28 @@ def test_rng_reserve_advances_generator_like_successive_randn_calls(pkg):
     step = PH.torch_counter_offset(numel, G)
     assert (s.seed, s.offset0, s.offset_stride, s.grid_threads, s.seed_stride) == (99, 12, step, G, 0)
     assert gen.offset == 12 + 5 * step
-    with pytest.raises(NotImplementedError):
-        rng.reserve(rng.MAX_CHUNK_NUMEL + 1, 1, torch.device("cpu"), generator=gen, geom=geom)
+    with pytest.raises(ValueError):
+        rng.reserve(rng.MAX_CHUNK_NUMEL + 1, 1, torch.device("cpu"), generator=gen, geom=geom)      # such chunks: reserve_split
 
 
-def test_oracle_split_plan_for_oversized_randn():
-    # documents what torch does above 32-bit indexing (the in-register path refuses these chunks)
-    n = 3 * 536870911
-    parts = PH.split_32bit(n)
-    assert sum(l for _, l in parts) == n and all(l <= 536870911 + 1 for _, l in parts)
-    assert [s for s, _ in parts] == sorted(s for s, _ in parts)
-    plan, off = PH.torch_randn_plan(n, 0, 256)
-    assert len(plan) == len(parts) and plan[0][3] > 0       # the outer call consumed an offset first
+def test_oversized_randn_is_split_like_aten(pkg):
+    """A randn beyond 2^29 elements: the same leaves, grids and generator offsets as the oracle's restatement of
+    TensorIterator::with_32bit_indexing + distribution_nullary_kernel (the outer call consumes an offset first)."""
+    from comfyui_vrgamedevgirl_amd import ops, rng
+    geom = rng.DeviceGeometry(256, 2048)
+    for n in (2 ** 29 + 1, 22 * 2160 * 3840 * 3, 3 * 536870911, 500 * 1080 * 1920 * 3, 2 ** 31 + 5):
+        parts = PH.split_32bit(n)
+        assert rng.split_32bit(n) == parts
+        assert sum(l for _, l in parts) == n and all(l <= 2 ** 29 for _, l in parts)
+        assert [s for s, _ in parts] == sorted(s for s, _ in parts)
+        plan, off = PH.torch_randn_plan(n, 40, 256)
+        gen = FakeGen(seed=7, offset=40)
+        sp = rng.reserve_split(n, torch.device("cpu"), generator=gen, geom=geom)
+        assert sp.leaves == plan and gen.offset == off and plan[0][3] > 40
+    assert rng.split_32bit(2 ** 29) == [(0, 2 ** 29)]
+    fe = 2160 * 3840 * 3
+    assert not ops.oversize_chunks(256, fe, 4) and not ops.oversize_chunks(21, fe, 0)
+    assert ops.oversize_chunks(22, fe, 0) and ops.oversize_chunks(256, fe, 22) and ops.oversize_chunks(87, 1080 * 1920 * 3, 0)
 
 
 def test_plan_noise_full_and_tail_chunks(pkg, monkeypatch):
