@@ -31,6 +31,14 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-result")
 
 
+# Per-source extra flags.  -fno-slp-vectorize: plain -O3 packs adjacent fp32 adds / multiplies of the long double-word
+# chains of the colour-match arithmetic into v_pk_*_f32 plus the v_mov_b32 that line their operands up; a packed op issues
+# at 1.8x a plain one on gfx950 (profiles/r02_valu_issue_rate_long.json), so that is a loss: the device-exact colour-match
+# passes run 11-14 % faster without it, grain -> LUT 3 % (A/B: profiles/r02_ab_slp_vectorize.log).  The wave-march kernel
+# is the opposite (grain -> sharpen 26 % slower without SLP) and keeps the default.
+EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",)}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -46,6 +54,7 @@ def _digest() -> str:
     with open(os.path.join(INCLUDE, "vrgdg_hip.h"), "rb") as fh:
         h.update(fh.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -56,7 +65,7 @@ def _object_digest(name: str) -> str:
             h.update(fh.read())
     with open(os.path.join(INCLUDE, "vrgdg_hip.h"), "rb") as fh:
         h.update(fh.read())
-    h.update(" ".join(HIPCC_FLAGS).encode())
+    h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS.get(name, ())).encode())
     return h.hexdigest()
 
 
@@ -81,7 +90,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             with open(stamp) as fh:
                 if fh.read().strip() == dig:
                     return obj
-        cmd = [hipcc, *cflags, "-I", INCLUDE, "-c", os.path.join(CSRC, name), "-o", obj]
+        cmd = [hipcc, *cflags, *EXTRA_FLAGS.get(name, ()), "-I", INCLUDE, "-c", os.path.join(CSRC, name), "-o", obj]
         if verbose:
             print("[vrgdg-amd] compiling:", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -502,9 +502,152 @@ struct DevMath {
 #if defined(__HIP_DEVICE_COMPILE__)
 extern "C" __device__ float __ocml_pow_f32(float, float);
 #define VRG_LIB_POWF(x, y) __ocml_pow_f32((x), (y))
+#define VRG_HW_FREXP_MANT(x) __builtin_amdgcn_frexp_mantf(x)     /* v_frexp_mant_f32: [0.5, 1) */
+#define VRG_HW_FREXP_EXP(x) __builtin_amdgcn_frexp_expf(x)       /* v_frexp_exp_i32_f32 */
 #else
 #define VRG_LIB_POWF(x, y) __builtin_powf((x), (y))      /* host checker only (tests/host_math) */
+#define VRG_HW_FREXP_MANT(x) __builtin_frexpf((x), &vrg_frexp_dummy_)
+#define VRG_HW_FREXP_EXP(x) ::vrg::host_frexp_exp(x)
+static int vrg_frexp_dummy_;
+VRG_HD int host_frexp_exp(float x) { int e; (void)__builtin_frexpf(x, &e); return e; }
 #endif
+
+// ------------------------------------------------------------------------------------------
+// dev_pow(x, y) for x > 0 (finite, +Inf or NaN) and finite y: ocml's powf -- the function torch.pow evaluates on the
+// device -- with its special-case scaffolding removed.  __ocml_pow_f32 is  expep(y * epln(|x|))  in fp32 double-word
+// arithmetic (ROCm device-libs ocml: powF.cl / eplnF.cl / expepF.cl, read from the LLVM IR of /opt/rocm/amdgcn/bitcode/
+// ocml.bc) wrapped in ~70 instructions of selects for x <= 0, integer / infinite y, signs and NaNs.  Below is the SAME
+// operation sequence, op for op (every add, multiply and FMA of the gfx9 "has fast FMA" path in the same order, v_rcp_f32,
+// and the backend's own lowering of exp through __builtin_expf), so the result is identical by construction wherever the
+// scaffolding is inert: 120 instead of ~195 instructions.  tests/test_gpu_parity.py sweeps EVERY fp32 base of the Lab
+// transforms' domains against torch.pow on the device (7.4e7 - 1.1e8 inputs per exponent) and against __ocml_pow_f32.
+// ------------------------------------------------------------------------------------------
+VRG_HD float dev_pow(float x, float y) {
+    // ---- epln: ln(x) = hi + lo
+    float m = VRG_HW_FREXP_MANT(x);
+    const bool low = m < f32_from_bits(0x3f2aaaabu);                 // 2/3
+    m = m * (low ? 2.0f : 1.0f);
+    const int e = VRG_HW_FREXP_EXP(x) - (low ? 1 : 0);
+    const float a12 = m + -1.0f;
+    const float a13 = m + 1.0f;
+    const float a14 = a13 + -1.0f;
+    const float a15 = m - a14;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r16 = __builtin_amdgcn_rcpf(a13);
+#else
+    const float r16 = 1.0f / a13;
+#endif
+    const float a17 = a12 * r16;
+    const float a18 = a13 * a17;
+    const float a25 = __builtin_fmaf(a17, a13, -a18);
+    const float a44 = __builtin_fmaf(a17, a15, a25);
+    const float a49 = a18 + a44;
+    const float a50 = a49 - a18;
+    const float a51 = a44 - a50;
+    const float a52 = a12 - a49;
+    const float a53 = a12 - a52;
+    const float a54 = a53 - a49;
+    const float a55 = a54 - a51;
+    const float a56 = a52 + a55;
+    const float a57 = r16 * a56;
+    const float a58 = a17 + a57;
+    const float a59 = a58 - a17;
+    const float a60 = a57 - a59;
+    const float a61 = a58 * a58;
+    const float a65 = __builtin_fmaf(a58, a58, -a61);
+    const float a80 = a60 * 2.0f;
+    const float a81 = __builtin_fmaf(a58, a80, a65);
+    const float a87 = a61 + a81;
+    const float a88 = a87 - a61;
+    const float a89 = a81 - a88;
+    const float a90 = __builtin_fmaf(a87, f32_from_bits(0x3e76c4e1u), f32_from_bits(0x3e91f4c4u));
+    const float a91 = __builtin_fmaf(a87, a90, f32_from_bits(0x3ecccdefu));
+    const float a92 = (float)e;
+    const float ln2h = f32_from_bits(0x3f317218u);
+    const float a93 = a92 * ln2h;
+    const float a97 = __builtin_fmaf(a92, ln2h, -a93);
+    const float a112 = __builtin_fmaf(a92, f32_from_bits(0xb102e308u), a97);
+    const float a117 = a58 * a87;
+    const float a121 = __builtin_fmaf(a87, a58, -a117);
+    const float a140 = __builtin_fmaf(a87, a60, a121);
+    const float a141 = __builtin_fmaf(a89, a58, a140);
+    const float a148 = a117 + a141;
+    const float a149 = a148 - a117;
+    const float a150 = a141 - a149;
+    const float a151 = a87 * a91;
+    const float a155 = __builtin_fmaf(a87, a91, -a151);
+    const float a174 = __builtin_fmaf(a89, a91, a155);
+    const float a179 = a151 + a174;
+    const float a180 = a179 - a151;
+    const float a181 = a174 - a180;
+    const float a182 = a179 + f32_from_bits(0x3f2aaaaau);
+    const float a183 = a182 + f32_from_bits(0xbf2aaaaau);
+    const float a184 = a179 - a183;
+    const float a185 = a181 + f32_from_bits(0x31739010u);
+    const float a186 = a185 + a184;
+    const float a187 = a182 + a186;
+    const float a188 = a187 - a182;
+    const float a189 = a186 - a188;
+    const float a190 = a148 * a187;
+    const float a194 = __builtin_fmaf(a148, a187, -a190);
+    const float a213 = __builtin_fmaf(a148, a189, a194);
+    const float a214 = __builtin_fmaf(a150, a187, a213);
+    const float a221 = a60 * 2.0f;                                   // ldexp(., 1): exact
+    const float a222 = a58 * 2.0f;
+    const float a223 = a93 + a112;
+    const float a224 = a223 - a93;
+    const float a225 = a112 - a224;
+    const float a226 = a190 + a214;
+    const float a227 = a226 - a190;
+    const float a228 = a214 - a227;
+    const float a229 = a222 + a226;
+    const float a230 = a229 - a222;
+    const float a231 = a226 - a230;
+    const float a232 = a221 + a228;
+    const float a233 = a232 + a231;
+    const float a234 = a229 + a233;
+    const float a235 = a234 - a229;
+    const float a236 = a233 - a235;
+    const float a237 = a223 + a234;
+    const float a238 = a237 - a223;
+    const float a239 = a237 - a238;
+    const float a240 = a223 - a239;
+    const float a241 = a234 - a238;
+    const float a242 = a241 + a240;
+    const float a243 = a225 + a236;
+    const float a244 = a243 - a225;
+    const float a245 = a243 - a244;
+    const float a246 = a225 - a245;
+    const float a247 = a236 - a244;
+    const float a248 = a247 + a246;
+    const float a249 = a243 + a242;
+    const float a250 = a237 + a249;
+    const float a251 = a250 - a237;
+    const float a252 = a249 - a251;
+    const float a253 = a248 + a252;
+    const float ln_hi = a250 + a253;
+    const float a255 = ln_hi - a250;
+    const float ln_lo = a253 - a255;
+    // ---- y * ln(x) = ph + pl
+    const float p17 = y * ln_hi;
+    const float p24 = __builtin_fmaf(y, ln_hi, -p17);
+    const float p44 = __builtin_fmaf(y, ln_lo, p24);
+    const float p50 = p17 + p44;
+    const float p51 = p50 - p17;
+    const float p52 = p44 - p51;
+    const float inf = __builtin_inff();
+    const float ph = (__builtin_fabsf(p17) == inf) ? p17 : p50;
+    const float pl = (__builtin_fabsf(ph) == inf) ? 0.0f : p52;
+    // ---- expep
+    const float c4 = (ph == f32_from_bits(0x42b17218u)) ? f32_from_bits(0x37000000u) : 0.0f;
+    const float h5 = ph - c4;
+    const float l7 = pl + c4;
+    const float e8 = __builtin_expf(h5);                              // the backend's exp lowering, as inside ocml
+    const float r9 = __builtin_fmaf(e8, l7, e8);
+    const float r = (__builtin_fabsf(e8) == inf) ? e8 : r9;
+    // ocml's scaffolding for the inputs this function admits: pow(+Inf, y) = y > 0 ? Inf : 0; NaN propagates by itself
+    return (x == inf) ? (y > 0.0f ? inf : 0.0f) : r;
+}
 
 // x / c for a Python-scalar c (written as a double literal): fast = the IEEE quotient by (float)c; device = x * (float)(1.0 / c)
 VRG_HD float cm_div_scalar(float x, float c, float rc, float, const PowTables&) { return div_const(x, c, rc); }
@@ -526,7 +669,9 @@ VRG_HD float srgb_to_linear(float v, const PowTables& T) {
 VRG_HD float srgb_to_linear(float v, const DevMath& M) {
     const float t = v + 0.055f;
     const float q = VRG_CM_DIVS(t, 1.055, M);
-    const float hi = VRG_LIB_POWF(q, M.e24);
+    // (the reference evaluates pow on every element and selects afterwards: for v <= 0.04045 the value is discarded, so the
+    //  base only has to stay in dev_pow's domain there)
+    const float hi = dev_pow(clamp_min(q, 0.0625f), M.e24);
     const float lo = VRG_CM_DIVS(v, 12.92, M);
     return v > 0.04045f ? hi : lo;
 }
@@ -542,7 +687,7 @@ VRG_HD float linear_to_srgb(float v, const PowTables& T) {
 VRG_HD float linear_to_srgb(float v, const DevMath& M) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
-    const float pw = VRG_LIB_POWF(base, M.e1_24);
+    const float pw = dev_pow(base, M.e1_24);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
@@ -570,7 +715,7 @@ VRG_HD float cbrt_pow(float x) {
 }
 
 VRG_HD float lab_cbrt(float t, const PowTables&) { return cbrt_pow(t); }
-VRG_HD float lab_cbrt(float t, const DevMath& M) { return VRG_LIB_POWF(t, M.e1_3); }
+VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow(t, M.e1_3); }
 
 template <class MATH>
 VRG_HD float lab_f(float t, const MATH& T) {

@@ -359,10 +359,20 @@ def test_device_math_pow_is_torch_pow_for_every_input_of_the_domain(pkg, dev, y,
     """ocml powf as this hipcc links it == torch.pow on the device (ocml powf as libtorch_hip.so carries it), for EVERY fp32
     base the Lab transforms can feed it: 7.4e7 .. 1.1e8 inputs per exponent."""
     x = _all_floats(lo, hi, dev)
-    assert torch.equal(_dbg(pkg, x, 0, y), torch.pow(x, y))
+    want = torch.pow(x, y)
+    assert torch.equal(_dbg(pkg, x, 0, y), want), "__ocml_pow_f32 linked by hipcc vs torch.pow"
+    assert torch.equal(_dbg(pkg, x, 9, y), want), "dev_pow (ocml powf without its special-case scaffolding) vs torch.pow"
     sp = torch.tensor([0.0, -0.0, -0.5, -1.0, 1.0, float("inf"), float("nan"), 1e-38, 1e-45, -1e-30, 3.0e38], device=dev)
     a, b = _dbg(pkg, sp, 0, y), torch.pow(sp, y)
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    # dev_pow's contract is x > 0: normal, huge, subnormal, +Inf, NaN bases; results up to overflow and down to underflow
+    sp = torch.tensor([1.0, float("inf"), float("nan"), 1e-38, 1e-45, 3.0e38, 1.17549435e-38, 2.0 ** -126, 2.0 ** 100, 1e-20, 0.99999994, 1.0000001], device=dev)
+    for yy in (y, 40.0 * y, -y):
+        a, b = _dbg(pkg, sp, 9, yy), torch.pow(sp, yy)
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (yy, a, b)
+    g = torch.Generator(device=dev).manual_seed(9)
+    wide = torch.exp(torch.rand(1 << 22, generator=g, device=dev) * 160.0 - 80.0)          # 1e-35 .. 1e35
+    assert torch.equal(_dbg(pkg, wide, 9, y), torch.pow(wide, y))
 
 
 def test_device_math_divisions_are_torch_divisions(pkg, dev):

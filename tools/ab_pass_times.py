@@ -17,8 +17,31 @@ out = torch.empty_like(x); ws = torch.empty_like(x)
 lut = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
 ref_ms = ops.finalize_stats(ops.lab_stats(x[:1]))
 gen = torch.Generator(device=dev).manual_seed(5)
-spec = ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0) if which == "chain4" else None,
-                     sharpen=("unsharp", 0.5, False))
+spec = ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0) if which.startswith("chain4") else None,
+                     sharpen=("unsharp", 0.5, False), cm_math="fast" if which == "chain4fast" else None)
+if which == "kernels":
+    # stand-alone kernels: median HIP-event ms each
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    lut25 = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_WarmFilm_25.cube")), dev)
+    t_cl = ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 40, "contrast": 12}))
+    cases = {"grain": lambda: ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen),
+             "lut33": lambda: ops.lut3d(x, lut, 10.0), "lut25": lambda: ops.lut3d(x, lut25, 10.0),
+             "unsharp": lambda: ops.stencil3x3(x, "unsharp", 0.5, False), "sobel": lambda: ops.stencil3x3(x, "sobel", 0.5, False),
+             "clarity": lambda: ops.adjust(x, t_cl, out=out),
+             "grain+lut": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0)), generator=gen, out=out),
+             "grain+sharpen": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)), generator=gen, out=out),
+             "chain3_25": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut25, 10.0), sharpen=("unsharp", 0.5, False)), generator=gen, out=out)}
+    res = {}
+    for name, fn in cases.items():
+        ts = []
+        for it in range(iters + 2):
+            a, b = ops.HipEvent(), ops.HipEvent()
+            a.record(); fn(); b.record()
+            if it >= 2:
+                ts.append(a.elapsed_ms(b))
+        res[name] = round(statistics.median(ts), 3)
+    print(os.environ.get("VRGDG_HIP_LIB", "default"), which, res)
+    sys.exit(0)
 acc = {}
 for it in range(iters + 2):
     ev = []

@@ -16,7 +16,7 @@ def field(block, key):
 rows = []
 for src in be.SOURCES:
     cflags = [f for f in be.HIPCC_FLAGS if f != "-shared"]
-    r = subprocess.run([be._hipcc(), *cflags, "-I", be.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", "/dev/null"],
+    r = subprocess.run([be._hipcc(), *cflags, *be.EXTRA_FLAGS.get(src, ()), "-I", be.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", "/dev/null"],
                        capture_output=True, text=True)
     for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
         mangled = b.split("\n")[0].split(" ")[0].strip()
