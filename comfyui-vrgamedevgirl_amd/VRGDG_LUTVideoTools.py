@@ -57,12 +57,19 @@ def _normalize_adjust_settings(settings=None):
     return normalized
 
 
+def _is_gpu_device(device) -> bool:
+    """Does the reference, called with this `device`, do its arithmetic on a GPU?  (The routes pass "cuda" when one is
+    available; all compute here is on the MI355X either way -- the argument only selects which of the reference's two
+    arithmetics, torch-CPU or torch-GPU, is reproduced bit for bit.)"""
+    return str(getattr(device, "type", device) or "cpu").strip().lower().split(":")[0] not in ("cpu", "")
+
+
 def _apply_adjust_tensor(image_tensor, settings=None, device="cpu"):
     """13-slider Adjust for one decoded batch (:307-391 of the reference): one or two HIP passes
     (csrc/vrg_adjust.hip); result stays on the GPU."""
     adjust = _normalize_adjust_settings(settings)
     src = _on_gpu(image_tensor).to(torch.float32)
-    return ops.adjust(src, ops.adjust_terms(adjust))
+    return ops.adjust(src, ops.adjust_terms(adjust, device_math=_is_gpu_device(device)))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -135,7 +142,7 @@ def _process_film_grain_batch(batch, writer, grain_intensity, saturation_mix, ta
 
 def _process_adjust_batch(batch, writer, settings, target_device):
     src = _stack_frames(batch)
-    out = ops.adjust(src, ops.adjust_terms(_normalize_adjust_settings(settings)))
+    out = ops.adjust(src, ops.adjust_terms(_normalize_adjust_settings(settings), device_math=_is_gpu_device(target_device)))
     for frame in _unstack_frames(out):
         writer.write(frame)
     return len(batch)

@@ -16,6 +16,7 @@ BORDER_REPLICATE, BORDER_ZERO = 0, 1
 STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
+ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
 ABI_VERSION = 2
 
 
@@ -48,7 +49,8 @@ class AdjustDesc(C.Structure):
                 ("has_clarity", C.c_int32), ("clarity", C.c_float),
                 ("has_sharpen", C.c_int32), ("sharpen", C.c_float),
                 ("has_fade", C.c_int32), ("fade_mul", C.c_float), ("fade_add", C.c_float),
-                ("has_vignette", C.c_int32), ("vignette", C.c_float)]
+                ("has_vignette", C.c_int32), ("vignette", C.c_float),
+                ("div_mode", C.c_int32)]
 
 
 _F3 = C.c_float * 3

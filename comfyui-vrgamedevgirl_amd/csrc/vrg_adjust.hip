@@ -196,11 +196,13 @@ static int launch_adjust(const void* in, void* out, float* tmp, int64_t frames, 
                          hipStream_t st) {
     typedef typename IO::elem elem;
     if (!in || !out || !d || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    if (d->div_mode != VRG_ADJUST_DIV_IEEE && d->div_mode != VRG_ADJUST_DIV_DEVICE) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     const int64_t ppf = (int64_t)height * width;
     if (ppf > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     AdjustK A{};
     A.enabled = d->enabled;
+    A.div_device = d->div_mode == VRG_ADJUST_DIV_DEVICE;
     for (int c = 0; c < 3; ++c) A.shift[c] = d->shift[c];
     A.exposure = d->exposure; A.contrast = d->contrast; A.saturation = d->saturation;
     A.highlights = d->highlights; A.shadows = d->shadows; A.whites = d->whites; A.blacks = d->blacks;

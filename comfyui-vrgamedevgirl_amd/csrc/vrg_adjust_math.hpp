@@ -15,6 +15,7 @@ struct AdjustK {
     float clarity, sharpen;                          // slider/100
     float fade_mul, fade_add;                        // (1 - fade*0.35), fade*0.18
     float vignette;                                  // slider/100
+    int32_t div_device;                              // tensor / python scalar as torch runs it on the GPU: x * fl32(1.0 / c)
     int32_t box;                                     // clarity box size k (odd, 3..9) or < 3: no blur
     float step_y, step_x;                            // torch.linspace steps 2/(H-1), 2/(W-1) (fp32 quotients)
 };
@@ -29,6 +30,12 @@ VRG_HD float adjust_div(float x, float c, float rc) {
     if (__builtin_expect(!((ax >= 1e-30f && ax <= 1e30f) || ax == 0.0f), 0)) return x / c;   // also NaN
     return div_const(x, c, rc);
 }
+
+// The three `tensor / python scalar` divisions of the reference that are not by a power of two (/ 0.45 twice, / 1.05).
+// The reference runs where its `device` argument says: on the CPU torch divides (IEEE quotient); on the GPU ATen multiplies
+// by the reciprocal of the Python double rounded to fp32 (BinaryDivTrueKernel; measured on the MI355X, profiles/
+// r02_cm_parity.json) -- one ulp apart now and then.  div_device selects which of the two references is reproduced.
+#define VRG_ADJ_DIVS(A, x, c) ((A).div_device ? (x) * (float)(1.0 / (double)(c)) : ::vrg::adjust_div((x), (float)(c), 1.0f / (float)(c)))
 
 VRG_HD float luma3(float r, float g, float b) {
     const float a = r * 0.2126f;
@@ -59,8 +66,8 @@ VRG_HD void adjust_point(const AdjustK& A, const float x[3], float o[3]) {
     }
     const float luma = luma3(v[0], v[1], v[2]);
     // x / 0.25 == x * 4 exactly (power of two)
-    const float hm = clamp01(VRG_ADJ_DIV(luma - 0.55f, 0.45f)) * A.highlights;
-    const float sm = clamp01(VRG_ADJ_DIV(0.45f - luma, 0.45f)) * A.shadows;
+    const float hm = clamp01(VRG_ADJ_DIVS(A, luma - 0.55f, 0.45)) * A.highlights;
+    const float sm = clamp01(VRG_ADJ_DIVS(A, 0.45f - luma, 0.45)) * A.shadows;
     const float wm = clamp01((luma - 0.75f) * 4.0f) * A.whites;
     const float bm = clamp01((0.25f - luma) * 4.0f) * A.blacks;
 #pragma unroll
@@ -97,7 +104,7 @@ VRG_HD void adjust_tail(const AdjustK& A, int y, int x, int H, int W, float v[3]
         const float b = yy * yy;
         const float dist = __builtin_sqrtf(a + b);
         const float e = dist - 0.35f;
-        const float q = clamp01(VRG_ADJ_DIV(e, 1.05f));
+        const float q = clamp01(VRG_ADJ_DIVS(A, e, 1.05));
         const float m0 = q * A.vignette;
         const float m1 = m0 * 0.75f;
         const float mask = 1.0f - m1;

@@ -77,6 +77,87 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ i
     if (p < pixels) out[p] = acc;
 }
 
+// Timing probe for the channel-split LUT: CH_LDS channels of the node table live in LDS (one float / float2 per node), the
+// other 3 - CH_LDS channels are gathered from a global record table with 4 * (3 - CH_LDS) floats per (b0, g0, r) record.
+// Persistent 1024-thread workgroups (one per CU next to the LDS table).  Values are checksums, not pixels.
+template <int CH_LDS>
+__global__ __launch_bounds__(1024) void k_dbg_lut_split(const px3* __restrict__ in, float* __restrict__ out, int64_t pixels,
+                                                          const float* __restrict__ cells, int n) {
+    extern __shared__ __attribute__((aligned(16))) float dbg_nodes[];
+    const int total = n * n * n * CH_LDS;
+    for (int i = threadIdx.x; i < total; i += 1024) dbg_nodes[i] = cells[i];
+    __syncthreads();
+    const float top = (float)(n - 1);
+    const int nc = n - 1;
+    constexpr int REC = 4 * (3 - CH_LDS);
+    for (int64_t p = (int64_t)blockIdx.x * 1024 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 1024) {
+        const px3 v = in[p];
+        const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
+        const int base = (B.cell * n + G.cell) * n + R.cell;
+        float acc = 0.0f;
+        if (CH_LDS == 1) {
+            const float* T = dbg_nodes;
+            acc += (T[base] + T[base + 1]) + (T[base + n] + T[base + n + 1]);
+            acc += (T[base + n * n] + T[base + n * n + 1]) + (T[base + n * n + n] + T[base + n * n + n + 1]);
+        } else {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2* T = reinterpret_cast<const f2*>(dbg_nodes);
+            const f2 a = T[base], b = T[base + 1], c = T[base + n], d = T[base + n + 1];
+            const f2 e = T[base + n * n], f = T[base + n * n + 1], g = T[base + n * n + n], h = T[base + n * n + n + 1];
+            acc += (a.x + a.y) + (b.x + b.y) + (c.x + c.y) + (d.x + d.y) + (e.x + e.y) + (f.x + f.y) + (g.x + g.y) + (h.x + h.y);
+        }
+        const f32x4* q = reinterpret_cast<const f32x4*>(cells + (size_t)((B.cell * nc + G.cell) * n + R.cell) * REC);
+#pragma unroll
+        for (int i = 0; i < 2 * (3 - CH_LDS); ++i) { const f32x4 t = q[i]; acc += (t.x + t.y) + (t.z + t.w); }
+        out[p] = acc;
+    }
+}
+
+// Timing probe: the whole table through LDS in three channel passes.  A persistent 1024-thread workgroup takes a batch of
+// 1024 * PX pixels, keeps their cell indices in registers and, per output channel, (re)fills the LDS with that channel's
+// node table (n^3 floats) and reads the 8 corners of each of its pixels: no global gathers at all, LDS refill traffic
+// 12 n^3 / (1024 PX) bytes per pixel.
+template <int PX>
+__global__ __launch_bounds__(1024) void k_dbg_lut_passes(const px3* __restrict__ in, float* __restrict__ out, int64_t pixels,
+                                                           const float* __restrict__ cells, int n) {
+    extern __shared__ __attribute__((aligned(16))) float dbg_nodes[];
+    const int total = n * n * n;
+    const float top = (float)(n - 1);
+    const int64_t batch = 1024 * PX;
+    for (int64_t b0 = (int64_t)blockIdx.x * batch; b0 < pixels; b0 += (int64_t)gridDim.x * batch) {
+        int base[PX];
+        float acc[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            int64_t p = b0 + j * 1024 + threadIdx.x;
+            p = p < pixels ? p : pixels - 1;
+            const px3 v = in[p];
+            const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
+            base[j] = (B.cell * n + G.cell) * n + R.cell;
+            acc[j] = 0.0f;
+        }
+        for (int pass = 0; pass < 3; ++pass) {
+            __syncthreads();
+            const f32x4* src = reinterpret_cast<const f32x4*>(cells + (size_t)pass * total);
+            f32x4* dst = reinterpret_cast<f32x4*>(dbg_nodes);
+            for (int i = threadIdx.x; i < (total + 3) / 4; i += 1024) dst[i] = src[i];
+            __syncthreads();
+            const float* T = dbg_nodes;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int bs = base[j];
+                acc[j] += (T[bs] + T[bs + 1]) + (T[bs + n] + T[bs + n + 1]);
+                acc[j] += (T[bs + n * n] + T[bs + n * n + 1]) + (T[bs + n * n + n] + T[bs + n * n + n + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int64_t p = b0 + j * 1024 + threadIdx.x;
+            if (p < pixels) out[p] = acc[j];
+        }
+    }
+}
+
 // Element-wise pieces of the colour-match arithmetic, one fp32 in -> one fp32 out, so that tests can compare each with
 // the torch op the reference executes on this GPU (tests/test_gpu_parity.py::test_device_math_pieces_equal_torch):
 //  op 0: __ocml_pow_f32(x, y) with y a kernel argument      (torch.pow(x, y))
@@ -203,9 +284,34 @@ int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float 
 }
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
-    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 4) return VRG_ERR_BAD_ARG;
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 8) return VRG_ERR_BAD_ARG;
     const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
     const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
+    if (mode >= 7) {      // three channel passes through LDS, 8 (mode 7) or 16 (mode 8) pixels per thread
+        const size_t lds = ((size_t)lut_size * lut_size * lut_size * 4 + 15) / 16 * 16;
+        if (lds > 160 * 1024) return VRG_ERR_UNSUPPORTED;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const void* fn = mode == 7 ? reinterpret_cast<const void*>(vrg::k_dbg_lut_passes<8>) : reinterpret_cast<const void*>(vrg::k_dbg_lut_passes<16>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VRG_ERR_LAUNCH;
+        if (mode == 7) hipLaunchKernelGGL(vrg::k_dbg_lut_passes<8>, dim3(cus), dim3(1024), lds, (hipStream_t)stream, src, out, pixels, cells, lut_size);
+        else hipLaunchKernelGGL(vrg::k_dbg_lut_passes<16>, dim3(cus), dim3(1024), lds, (hipStream_t)stream, src, out, pixels, cells, lut_size);
+        VRG_CHECK_LAUNCH();
+        return VRG_OK;
+    }
+    if (mode >= 5) {      // channel-split probes: mode 5 = one channel in LDS, 6 = two
+        const int ch = mode - 4;
+        const size_t lds = (size_t)lut_size * lut_size * lut_size * 4 * ch;
+        if (lds > 160 * 1024) return VRG_ERR_UNSUPPORTED;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const void* fn = ch == 1 ? reinterpret_cast<const void*>(vrg::k_dbg_lut_split<1>) : reinterpret_cast<const void*>(vrg::k_dbg_lut_split<2>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VRG_ERR_LAUNCH;
+        if (ch == 1) hipLaunchKernelGGL(vrg::k_dbg_lut_split<1>, dim3(cus), dim3(1024), lds, (hipStream_t)stream, src, out, pixels, cells, lut_size);
+        else hipLaunchKernelGGL(vrg::k_dbg_lut_split<2>, dim3(cus), dim3(1024), lds, (hipStream_t)stream, src, out, pixels, cells, lut_size);
+        VRG_CHECK_LAUNCH();
+        return VRG_OK;
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
         case 1: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
         lut_nodes = reinterpret_cast<const f32x4*>(march_lut_nodes);
     }
     if (WAVES != 4) __syncthreads();
-    const DevMath PT = D.dm;      // unused: no Lab arithmetic in this kernel
 
     constexpr int CLO = SHARPEN ? 1 : 0;     // first lane that produces output
     constexpr int CW = SHARPEN ? 61 : 63;    // output lanes per wave (lane 63 only provides noise)
@@ -170,12 +169,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
                 }
             }
         }
-        // ---------------- pre stages of the four pixels of this step
-        float Dn[4][3];
+        // ---------------- per sibling: the pixel's normals, grain
+        const int b0o = b0 - E;                                            // middle row, relative to the quarter (sharpen output)
+        float V[4][3];                                                     // the pixel after the grain stage
+        bool valid[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int li = rowbase + offm[m];
-            const bool valid = (uint32_t)li < px_limit;               // whole pixel inside the chunk
+            valid[m] = (uint32_t)li < px_limit;                            // whole pixel inside the chunk
             const float x[3] = {xin[m].r, xin[m].g, xin[m].b};
             float n[3] = {0.0f, 0.0f, 0.0f};
             if (STAGES & VRG_STAGE_GRAIN) {
@@ -187,24 +188,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
                     } else {
                         n[0] = nz[2][m]; n[1] = nx[0][m]; n[2] = nx[1][m];
                     }
-                } else if (valid) {
+                } else if (valid[m]) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) n[c] = torch_randn_element(seed, off, G, (uint64_t)(uint32_t)(li + c));
                 }
+                grain_pixel(x, n, D.I, D.S, D.T, V[m]);
+            } else {
+                V[m][0] = x[0]; V[m][1] = x[1]; V[m][2] = x[2];
             }
-            int fidx = fc[m];
-            fidx = fidx < 0 ? 0 : (fidx > M.chunk_frames - 1 ? M.chunk_frames - 1 : fidx);
-            float o[3];
-            chain_apply_stages<STAGES>(D, (int64_t)chunk * M.chunk_frames + fidx, x, n, o, PT, lut_nodes);
-            Dn[m][0] = valid ? o[0] : 0.0f; Dn[m][1] = valid ? o[1] : 0.0f; Dn[m][2] = valid ? o[2] : 0.0f;
             xin[m] = xnext[m];
         }
-        // ---------------- output
-        if (SHARPEN) {
-            if (rho >= r_first + 2) {
-                const int bo = b0 - E;                                         // middle row, relative to the quarter
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
+        // ---------------- the rest of the pre stages and the output of sibling m
+        float Dn[4][3];
+        auto set_row = [&](int m, const float o[3]) {
+            Dn[m][0] = valid[m] ? o[0] : 0.0f; Dn[m][1] = valid[m] ? o[1] : 0.0f; Dn[m][2] = valid[m] ? o[2] : 0.0f;
+        };
+        auto emit = [&](int m) {
+            if (SHARPEN) {
+                if (rho >= r_first + 2) {
                     const bool top = yM[m] == 0, bottom = yM[m] == H - 1;
                     const bool left = xm[m] == 0, right = xm[m] == W - 1;
                     const bool any_edge = __builtin_amdgcn_ballot_w64(top || bottom || left || right) != 0;   // wave-uniform
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
                         res[c] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
                     }
                     const int li = rowbase - E + offm[m];
-                    const uint32_t idx = (uint32_t)(bo + M.s[m] + 3 * lane);   // subsequence of channel 0 (wraps to huge if negative)
+                    const uint32_t idx = (uint32_t)(b0o + M.s[m] + 3 * lane);   // subsequence of channel 0 (wraps to huge if negative)
                     const bool act = lane_out && (uint32_t)li < px_limit;
                     const bool a0 = idx < G, a1 = idx + 1u < G, a2 = idx + 2u < G;
                     // wave-uniform split: in all but the rows that touch the end of the Philox quarter every active lane
@@ -243,16 +244,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
                         if (a2) cout[li + 2] = res[2];
                     }
                 }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
                 yM[m] = yc[m];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { U[m][c] = Mi[m][c]; Mi[m][c] = Dn[m][c]; }
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            } else {
                 const int li = rowbase + offm[m];
                 const uint32_t idx = (uint32_t)(b0 + M.s[m] + 3 * lane);
                 const bool act = lane_out && (uint32_t)li < px_limit;
@@ -265,6 +260,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
                     if (a2) cout[li + 2] = Dn[m][2];
                 }
             }
+        };
+        {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float o[3] = {V[m][0], V[m][1], V[m][2]};
+                if (STAGES & VRG_STAGE_LUT) {
+                    float g[3];
+                    if (lut_nodes) lut_pixel_nodes(D.lut, lut_nodes, V[m], g);      // small cube staged in LDS by the workgroup
+                    else lut_pixel(D.lut, V[m], g);
+                    o[0] = g[0]; o[1] = g[1]; o[2] = g[2];
+                }
+                set_row(m, o);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) emit(m);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {

@@ -269,24 +269,60 @@ VRG_HD float lerp2(float a, float wa, float b, float wb) {
     return pa + pb;
 }
 
-// rgb in -> graded rgb out (before the strength blend); lerp order blue, green, red (:320-333)
-VRG_HD void lut_pixel_raw(const LutParams& P, const float x[3], float y[3]) {
-    const LutAxis R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
-    const LutAxis G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
-    const LutAxis B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
+// rgb in -> graded rgb out (before the strength blend); lerp order blue, green, red (:320-333).
+// Split into "issue" (axes + the six 16-byte gathers) and "finish" (the 21 separately rounded ops per channel) so that a
+// kernel can keep the gathers of one pixel in flight while it works on another (vrg_march.hip).
+struct LutFetch { LutAxis R, G, B; f32x4 lo[3], hi[3]; };
+
+VRG_HD void lut_fetch_issue(const LutParams& P, const float x[3], LutFetch& F) {
+    F.R = lut_axis(x[0], P.dmin[0], P.span[0], P.unit_domain, P.top);
+    F.G = lut_axis(x[1], P.dmin[1], P.span[1], P.unit_domain, P.top);
+    F.B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
     const int nc = P.n - 1;
-    const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((B.cell * nc + G.cell) * P.n + R.cell) * LUT_REC_FLOATS);
+    const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((F.B.cell * nc + F.G.cell) * P.n + F.R.cell) * LUT_REC_FLOATS);
+#if defined(VRG_ABLATE_GATHER)      /* timing ablation only (tools/build_variant.py): no table reads, same arithmetic */
+    (void)q;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const f32x4 lo = q[ch];      // red node r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
-        const f32x4 hi = q[3 + ch];  // red node r0 + 1
-        const float c00 = lerp2(lo.x, B.u, lo.y, B.f);
-        const float c01 = lerp2(lo.z, B.u, lo.w, B.f);
-        const float c10 = lerp2(hi.x, B.u, hi.y, B.f);
-        const float c11 = lerp2(hi.z, B.u, hi.w, B.f);
-        const float c0 = lerp2(c00, G.u, c01, G.f);
-        const float c1 = lerp2(c10, G.u, c11, G.f);
-        y[ch] = clamp01_finite(lerp2(c0, R.u, c1, R.f));    // finite table => finite value
+        F.lo[ch] = f32x4{x[0], x[1], x[2], x[ch]};
+        F.hi[ch] = f32x4{x[2], x[1], x[0], x[ch]};
+    }
+#else
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        F.lo[ch] = q[ch];      // red node r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
+        F.hi[ch] = q[3 + ch];  // red node r0 + 1
+    }
+#endif
+}
+
+VRG_HD void lut_fetch_finish(const LutFetch& F, float y[3]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const f32x4 lo = F.lo[ch], hi = F.hi[ch];
+        const float c00 = lerp2(lo.x, F.B.u, lo.y, F.B.f);
+        const float c01 = lerp2(lo.z, F.B.u, lo.w, F.B.f);
+        const float c10 = lerp2(hi.x, F.B.u, hi.y, F.B.f);
+        const float c11 = lerp2(hi.z, F.B.u, hi.w, F.B.f);
+        const float c0 = lerp2(c00, F.G.u, c01, F.G.f);
+        const float c1 = lerp2(c10, F.G.u, c11, F.G.f);
+        y[ch] = clamp01_finite(lerp2(c0, F.R.u, c1, F.R.f));    // finite table => finite value
+    }
+}
+
+VRG_HD void lut_pixel_raw(const LutParams& P, const float x[3], float y[3]) {
+    LutFetch F;
+    lut_fetch_issue(P, x, F);
+    lut_fetch_finish(F, y);
+}
+
+VRG_HD void lut_blend(const LutParams& P, const float x[3], const float y[3], float o[3]) {
+    if (P.blend_mode == 2) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch] = lerp2(x[ch], P.one_minus_blend, y[ch], P.blend);
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o[ch] = y[ch];
     }
 }
 

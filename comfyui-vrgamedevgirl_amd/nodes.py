@@ -93,18 +93,28 @@ class ColorMatchToReference:
         ref = reference_image.to(device=dev, dtype=torch.float32)
         n_ref = int(ref.shape[0])
         frames = int(images.shape[0])
+        expand = None
         if n_ref != 1:
-            # the reference broadcasts [n_ref,3,1,1] statistics against every batch_size chunk
-            sizes = {min(batch_size, frames - i) for i in range(0, frames, batch_size)}
-            if sizes != {n_ref}:
-                bad = next(iter(sizes - {n_ref}))
+            # the reference broadcasts the [n_ref,3,1,1] reference statistics against every batch_size chunk (nodes.py:112):
+            # a chunk of n_ref frames pairs frame i with reference i; a chunk of ONE frame broadcasts the other way and
+            # yields n_ref frames (that frame matched to every reference); any other size is torch's broadcasting error
+            sizes = [min(batch_size, frames - i) for i in range(0, frames, batch_size)]
+            bad = next((b for b in sizes if b not in (1, n_ref)), None)
+            if bad is not None:
                 raise RuntimeError(f"The size of tensor a ({bad}) must match the size of tensor b ({n_ref}) at "
                                    "non-singleton dimension 0")
+            if any(b == 1 for b in sizes):
+                expand, f = [], 0
+                for b in sizes:
+                    expand += [f] * n_ref if b == 1 else list(range(f, f + b))
+                    f += b
         ref_ms = ops.finalize_stats(ops.lab_stats(ref))
 
         def run(gpu_frames, _first):
             return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms)
 
+        if expand is not None:
+            images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]
         return (_run_grouped(images, run, multiple_of=n_ref if n_ref != 1 else 1),)
 
 

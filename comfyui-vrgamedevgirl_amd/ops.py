@@ -316,10 +316,13 @@ def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool
 # 13-slider Adjust (video routes)
 # ------------------------------------------------------------------------------------------------
 
-def adjust_terms(adjust: dict) -> "_hip.AdjustDesc":
+def adjust_terms(adjust: dict, device_math: bool = False) -> "_hip.AdjustDesc":
     """Slider arithmetic of _apply_adjust_tensor (VRGDG_LUTVideoTools.py:309-315 ff.) in Python doubles, rounded
-    once to fp32 -- what torch does with a Python scalar operand.  `adjust` is a normalized settings dict."""
+    once to fp32 -- what torch does with a Python scalar operand.  `adjust` is a normalized settings dict.
+    `device_math`: reproduce the reference run with device="cuda" (its `/ 0.45`, `/ 1.05` become multiplications by the
+    fp32-rounded reciprocal, as torch evaluates tensor / scalar on a GPU) instead of with device="cpu" (IEEE quotients)."""
     d = _hip.AdjustDesc()
+    d.div_mode = _hip.ADJUST_DIV_DEVICE if device_math else _hip.ADJUST_DIV_IEEE
     d.enabled = 1 if adjust["enabled"] else 0
     t, ti = adjust["temperature"], adjust["tint"]
     d.shift[0] = _f32(t / 400.0 - ti / 900.0)

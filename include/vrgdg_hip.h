@@ -216,7 +216,11 @@ typedef struct vrg_adjust_desc {
     int32_t has_sharpen; float sharpen;      /* slider > 0;  slider/100 (:358-372) */
     int32_t has_fade; float fade_mul, fade_add;   /* 1 - fade*0.35, fade*0.18 (:374-375) */
     int32_t has_vignette; float vignette;    /* slider > 0; slider/100 (:377-389) */
+    /* `tensor / 0.45`, `/ 1.05` (:333-334, :388): the reference runs on the device its `device` argument names -- the
+     * IEEE quotient on the CPU, x * fl32(1.0 / c) on the GPU (ATen BinaryDivTrueKernel).  enum vrg_adjust_div. */
+    int32_t div_mode;
 } vrg_adjust_desc;
+enum vrg_adjust_div { VRG_ADJUST_DIV_IEEE = 0, VRG_ADJUST_DIV_DEVICE = 1 };
 
 int vrg_adjust_f32(const float* in, float* out, float* tmp, int64_t frames, int32_t height, int32_t width,
                    const vrg_adjust_desc* desc, void* stream);
@@ -266,7 +270,8 @@ int vrg_selftest_lanes(float* out128, void* stream);
  * transcription of ocml powf without its special-case scaffolding that the device policy evaluates (x > 0). */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
- * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records. */
+ * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;
+ * 5 / 6: channel split -- one / two channels of the node table in LDS (8 ds_read per pixel), the rest gathered (4 / 2 x 16 B). */
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
 /* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
  * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,

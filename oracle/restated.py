@@ -448,7 +448,7 @@ def adjust_tensor(image: torch.Tensor, settings=None, ieee_sqrt: bool = False) -
         return source
     out = source + torch.tensor(
         [adj["temperature"] / 400.0 - adj["tint"] / 900.0, adj["tint"] / 450.0, -adj["temperature"] / 400.0 - adj["tint"] / 900.0],
-        dtype=source.dtype).view(1, 1, 1, 3)
+        dtype=source.dtype, device=source.device).view(1, 1, 1, 3)
     out = out * (2.0 ** (adj["exposure"] / 100.0))
     out = (out - 0.5) * (1.0 + adj["contrast"] / 100.0) + 0.5
     gray = _luma(out, 3).repeat(1, 1, 1, 3)
@@ -479,10 +479,10 @@ def adjust_tensor(image: torch.Tensor, settings=None, ieee_sqrt: bool = False) -
     vig = adj["vignette"] / 100.0
     if vig > 0.0:
         H, W = out.shape[1], out.shape[2]
-        yy = torch.linspace(-1.0, 1.0, H, dtype=out.dtype).view(1, H, 1, 1)
-        xx = torch.linspace(-1.0, 1.0, W, dtype=out.dtype).view(1, 1, W, 1)
+        yy = torch.linspace(-1.0, 1.0, H, dtype=out.dtype, device=out.device).view(1, H, 1, 1)
+        xx = torch.linspace(-1.0, 1.0, W, dtype=out.dtype, device=out.device).view(1, 1, W, 1)
         d2 = (xx * xx) + (yy * yy)
-        dist = torch.from_numpy(np.sqrt(d2.numpy())) if ieee_sqrt else torch.sqrt(d2)
+        dist = torch.from_numpy(np.sqrt(d2.numpy())) if (ieee_sqrt and not d2.is_cuda) else torch.sqrt(d2)
         out = out * (1.0 - torch.clamp((dist - 0.35) / 1.05, 0.0, 1.0) * vig * 0.75)
     return out.clamp(0.0, 1.0)
 

@@ -231,6 +231,22 @@ def test_lut_node_and_helpers_on_shipped_cubes(pkg, dev):
         iv.VRGDG_LUTS._apply_cube_lut(x[..., :2], oracle_lut["lut"], oracle_lut["domain_min"], oracle_lut["domain_max"])
 
 
+def test_lut_rgba_partial_strength_and_non_fp32_images(pkg, ops, dev):
+    """apply_lut's strength blend runs over ALL channels (IV_Adjustments.py:355-359): alpha becomes a*(1-B) + a*B, which is
+    not always a; and the reference grades non-fp32 images in fp32 and casts back (:293, :341-342)."""
+    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
+    x = _rand((2, 17, 23, 4), 81, -0.05, 1.05)
+    for s in (3.3, 7.0, 10.0, 0.0):
+        assert_bit_equal(ops.lut3d(x.to(dev), dlut, s), R.apply_lut_with_strength(x, data, s), f"RGBA strength {s}")
+    from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
+    with pytest.raises(ValueError):                                  # the reference evaluates float64 images in fp64: not offered
+        iv.VRGDG_LUTS().apply_lut(_rand((1, 9, 11, 3), 82).to(torch.float64), "AMD_WarmFilm_25.cube", "auto", 10.0)
+    xh = _rand((1, 9, 11, 3), 83).to(torch.float16)
+    (out,) = iv.VRGDG_LUTS().apply_lut(xh, "AMD_WarmFilm_25.cube", "auto", 10.0)
+    assert out.dtype == torch.float16
+    assert_bit_equal(out, R.apply_lut_with_strength(xh, data, 10.0), "float16 image, full strength")
+
+
 def test_make_lut_node(pkg, dev, tmp_path, monkeypatch):
     from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
     monkeypatch.setattr(iv, "LUTS_DIR", str(tmp_path))
@@ -531,6 +547,15 @@ def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
         assert err_ours[3] <= tol
     with pytest.raises(RuntimeError):
         node.match_color(x, ref4[:3], 1.0, 4)                # reference batch neither 1 nor the chunk size
+    # a chunk of ONE frame against several references broadcasts the other way: n_ref output frames per input frame
+    (out,) = node.match_color(x[:2], ref4[:3], 0.7, 1)
+    want = R.color_match(x[:2].to(dev), ref4[:3].to(dev), 0.7, 1).cpu()
+    assert out.shape == want.shape == (6,) + tuple(x.shape[1:])
+    assert _unit_ulps(out, want) <= CM_CROSS_REF_ULP
+    (out,) = node.match_color(x, ref4[:3], 0.7, 3)           # chunks of 3 and 1: 3 + 3 frames
+    want = R.color_match(x.to(dev), ref4[:3].to(dev), 0.7, 3).cpu()
+    assert out.shape == want.shape == (6,) + tuple(x.shape[1:])
+    assert _unit_ulps(out[:3], want[:3]) <= CM_CROSS_REF_ULP         # frame 3 is the constant frame (chaotic in the reference)
     from comfyui_vrgamedevgirl_amd import ops
     xd = x.to(dev)
     for mode in ("device", "fast"):
@@ -810,6 +835,29 @@ def test_adjust_1080p_all_sliders(ops, pkg, dev):
     x = _rand((1, 1080, 1920, 3), seed=77, lo=-0.05, hi=1.05)
     got = ops.adjust(x.to(dev), ops.adjust_terms(LVT._normalize_adjust_settings(settings)))
     assert_bit_equal(got, _adjust_want(x, settings), "adjust 1080p")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96, 3), (1, 270, 480, 3), (2, 7, 5, 3), (1, 33, 129, 3)])
+def test_adjust_device_arithmetic_bit_equal_device_oracle(pkg, ops, dev, shape):
+    """_apply_adjust_tensor(..., device="cuda") of the reference does its arithmetic on the GPU: `/ 0.45` and `/ 1.05` are
+    multiplications by the fp32-rounded reciprocal there (ATen), avg_pool2d / linspace / sqrt are the device kernels.  Our
+    kernels with device_math reproduce THAT bit for bit (the oracle evaluated by torch on this GPU); with device="cpu" they
+    reproduce the CPU arithmetic (the committed fixtures, tests above)."""
+    from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
+    x = _rand(shape, 301, -0.1, 1.1)
+    cases = [{"highlights": 60, "shadows": -40, "whites": 30, "blacks": -25, "contrast": 15, "exposure": 12, "temperature": 20, "tint": -10},
+             {"vignette": 55, "fade": 20, "saturation": 25},
+             {"clarity": 45, "sharpen": 30, "vignette": 20, "contrast": 10, "highlights": -35},
+             {"clarity": -60, "shadows": 80}]
+    differs_from_cpu = 0
+    for settings in cases:
+        want = R.adjust_tensor(x.to(dev), settings)                      # torch ops on the device
+        got = LVT._apply_adjust_tensor(x, settings, "cuda")
+        assert_bit_equal(got, want, f"adjust device arithmetic {settings}")
+        cpu_arith = LVT._apply_adjust_tensor(x, settings, "cpu")
+        differs_from_cpu += int(not torch.equal(cpu_arith.cpu(), got.cpu()))
+    if shape[1] >= 64:
+        assert differs_from_cpu > 0, "the two arithmetics should differ somewhere on frames this large"
 
 
 def test_adjust_argument_errors(ops, pkg, dev):
