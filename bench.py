@@ -98,6 +98,16 @@ def make_frames(n, H, W, dev, seed, dist):
     return x
 
 
+def _profile_json(*names):
+    """first of the committed PMC summaries that exists (newest round first)"""
+    for n in names:
+        path = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh), n
+    raise FileNotFoundError(names[0])
+
+
 def _median_time(fn, warmup=1, reps=3):
     for _ in range(warmup):
         fn()
@@ -277,13 +287,14 @@ def main():
     # process): bytes per pixel measured there x the pixels of one launch here
     traffic, traffic_note = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_fetch_write.json")) as fh:
-            summ = json.load(fh).get("summary", {})
+        tj, tname = _profile_json("r02_pmc_traffic_fetch_write.json", "r01_pmc_traffic_fetch_write.json")
+        summ = tj.get("summary", {})
         key = dom if "colormatch" in stages else "chain3_apply"
         if summ.get(key, {}).get("total"):
             traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
-            traffic_note = (f"GB per launch = {summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
-                            "FETCH_SIZE / WRITE_SIZE, separate passes, 16x4K frames, FETCH_SIZE x2 per the gfx950 calibration) x pixels"
+            traffic_note = (f"NOT collected in this process (rocprofv3 wraps a process): profiles/{tname}, the same kernels on 16x4K frames: "
+                            f"{summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
+                            "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per the gfx950 calibration) x this launch's pixels"
                             + ("; the written bytes are the Lab image kept for pass 2 (design choice measured in DESIGN.md section 3: "
                                "40.3 vs 25.4 Gpix/s against the recomputing form), not re-reads" if key == "stats" else ""))
     except Exception:
@@ -294,10 +305,9 @@ def main():
     # against the probe's measured peak for plain fp32 / integer ops
     issue = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_valu_instr_per_px.json")) as fh:
-            recs = json.load(fh)
-        with open(os.path.join(ROOT, "profiles", "r01_valu_issue_rate.json")) as fh:
-            peak_t = max(r["tera_lane_instr_s"] for r in json.load(fh)["rows"] if r["instr"] == "v_fma_f32")
+        recs, iname = _profile_json("r02_pmc_valu_instr_per_px.json", "r01_pmc_valu_instr_per_px.json")
+        rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
+        peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
         # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
         want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
                 ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
@@ -305,7 +315,9 @@ def main():
         rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
         issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
                  "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4),
-                 "note": "unweighted; compare/select x1.5, integer multiply x1.75, transcendental x3 issue cost (profiles/r01_valu_issue_rate.json)"}
+                 "note": f"lane-instructions per pixel from profiles/{iname} (SQ_INSTS_VALU, not collected in this process) x this run's pixel rate; "
+                         f"peak = v_fma_f32 at 8 waves/SIMD over >= 17 ms launches (profiles/{rname}); unweighted: v_pk_* / fp64 / "
+                         "v_mad_u64_u32 issue at 1.8x, compare+select pairs 1.65x, transcendentals 3.45x a plain op"}
     except Exception:
         pass
 

@@ -148,6 +148,19 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
                              float k, float one_minus_k, int32_t cm_math, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: frames shard across ranks with no data-path collective; the one exchange is this --
+ * (n, mean, M2) triples of DISJOINT pixel sets (the rows of a reference frame reduced on different GPUs, vrg_lab_stats_f32 on
+ * each rank's row slice) are combined in place into the statistics of their union with two SUM all-reduces over RCCL / xGMI
+ * enqueued on `stream`: (n, n*mean) gives the global mean, then M2 + n*(mean - mean_tot)^2 gives the global M2.  72 bytes per
+ * reference frame: latency bound.  `comm` is the caller's ncclComm_t (RCCL's nccl.h), passed as void*; `stats` = `count`
+ * triples (count = frames*3), `scratch` = vrg_stats_allreduce_scratch_bytes(count) bytes of device memory.  RCCL is resolved
+ * at run time from the copy the process already loaded (the library links only the HIP runtime): VRG_ERR_UNSUPPORTED when
+ * there is none.  The Python host performs the same arithmetic through torch.distributed (sharding.allreduce_stats).
+ * ------------------------------------------------------------------------------------------- */
+int64_t vrg_stats_allreduce_scratch_bytes(int64_t count);
+int vrg_stats_allreduce(double* stats, int64_t count, void* comm, void* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused chain: grain -> LUT -> colour match -> 3x3 sharpen in one pass over HBM (12 B/px read +
  * 12 B/px written; colour match adds the 12 B/px statistics pass).  Bit-identical to running the
  * stand-alone entry points one after the other.  Stages are switched by `stages`.

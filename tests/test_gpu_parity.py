@@ -343,6 +343,50 @@ def _all_floats(lo, hi, dev):
     return torch.arange(a, b + 1, dtype=torch.int32, device=dev).view(torch.float32)
 
 
+def test_stats_allreduce_entry_point_over_rccl(pkg, ops, dev):
+    """vrg_stats_allreduce with a real RCCL communicator (one rank: all a 1-GPU box can host; the N-rank algebra is the same
+    code path and is covered on CPU by tests/test_sharding_gloo.py through the Python twin): equals sharding.allreduce_stats'
+    arithmetic -- (n, n*mean) summed, mean_tot = sum / n_tot, M2 + n*(mean - mean_tot)^2 summed."""
+    import ctypes as C
+    from comfyui_vrgamedevgirl_amd import _hip
+    import torch.distributed  # noqa: F401  (loads torch's bundled RCCL into the process)
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library to create a communicator with")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        x = _rand((3, 37, 29, 3), 77).to(dev)
+        stats = ops.lab_stats(x)                                            # [3,3,3] fp64 triples
+        want = stats.clone()
+        n, mean, m2 = want[..., 0], want[..., 1], want[..., 2]
+        mean_tot = (n * mean) / n
+        delta = mean - mean_tot
+        want = torch.stack([n, mean_tot, m2 + (n * delta) * delta], dim=-1)
+        got = stats.clone()
+        count = got.numel() // 3
+        scratch = torch.empty(int(_hip.lib().vrg_stats_allreduce_scratch_bytes(count)) // 8, dtype=torch.float64, device=dev)
+        _hip.check(_hip.lib().vrg_stats_allreduce(_hip.ptr(got), count, comm, _hip.ptr(scratch), _hip.current_stream()), "vrg_stats_allreduce")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert _hip.lib().vrg_stats_allreduce(_hip.ptr(got), count, None, _hip.ptr(scratch), _hip.current_stream()) == 1      # null communicator
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_zero_border_stencils_against_the_device_conv2d(ops, dev):
     """use_gpu=True in the reference runs F.avg_pool2d / F.conv2d ON THE GPU (nodes.py:171, 248-257, 325-348).  avg_pool2d
     there is a plain raster sum: bit-equal.  conv2d is MIOpen: NOT a sum of the five (six) products in any order -- e.g. its

@@ -59,6 +59,7 @@ if which == "issue":
     _hip.check(_hip.lib().vrg_debug_valu_rate(_hip.ptr(probe), 2048, 512, 0, _hip.current_stream()), "valu")   # 2048*4 waves * 512*64 v_fma
     lab_ws = torch.empty_like(x)
     ops.fused_chain(x, specs["chain4"], generator=gen, out=out, lab_workspace=lab_ws)
+    ops.fused_chain(x, specs["chain4fast"], generator=gen, out=out, lab_workspace=lab_ws)
     ops.fused_chain(x, specs["chain3"], generator=gen, out=out)
     ops.fused_chain(x, specs["grainsharp"], generator=gen, out=out)
     ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen)
