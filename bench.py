@@ -62,7 +62,7 @@ def self_launch(args):
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and os.environ.get("VRGDG_DIST_BACKEND", "nccl") == "nccl":
         sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {n_vis} GPU(s) are visible to PyTorch-ROCm; "
                          "refusing to print a line for fewer GPUs than asked for\n")
         raise SystemExit(2)
@@ -182,7 +182,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun --nproc-per-node {args.gpus}, or let "
                          "bench.py launch itself)")
     if world > 1:
-        if not dist.is_initialized() or dist.get_world_size() != world or dist.get_backend() != "nccl":
+        want_backend = os.environ.get("VRGDG_DIST_BACKEND", "nccl")      # gloo only for functional tests on a 1-GPU box
+        if not dist.is_initialized() or dist.get_world_size() != world or dist.get_backend() != want_backend:
             raise SystemExit("bench.py: RCCL process group did not come up with the requested world size")
     dev = torch.device("cuda", torch.cuda.current_device())
     H, W, stages = WORKLOADS[args.workload]
@@ -336,6 +337,7 @@ def main():
                        "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
                        "cm_math": "device" if "colormatch" in stages else None},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+            "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
             "per_rank_ms_per_step": per_rank_ms,
             "reference_stats_ms_per_step": ref_ms_per_step,
             "chain_hbm_frac": round(value / world * bytes_per_px_chain * 1e6 / 1e9 / HBM_PEAK_GBS, 4),

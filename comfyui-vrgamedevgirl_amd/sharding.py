@@ -87,9 +87,13 @@ def init_from_env(backend: Optional[str] = None):
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torchrun (also with a single process)
     if (world > 1 or launched) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VRGDG_DIST_BACKEND=gloo: functional runs of the N-rank flow where RCCL cannot be used (several ranks sharing the
+            # one GPU of a test box: RCCL refuses duplicate devices); the product default is RCCL ("nccl" IS RCCL on ROCm)
+            backend = os.environ.get("VRGDG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+        elif torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         kwargs = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}      # bind the RCCL communicator to this rank's GPU

@@ -247,6 +247,38 @@ def test_lut_rgba_partial_strength_and_non_fp32_images(pkg, ops, dev):
     assert_bit_equal(out, R.apply_lut_with_strength(xh, data, 10.0), "float16 image, full strength")
 
 
+@pytest.mark.parametrize("n,dmin,dmax", [(32, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), (32, (-0.25, 0.0, 0.1), (1.5, 1.0, 0.9)), (25, (0.0, -0.1, 0.0), (1.0, 1.2, 2.0))])
+def test_lut_photoshop_style_cubes_with_domain_lines(pkg, ops, dev, tmp_path, n, dmin, dmax):
+    """The reference ships 25^3 / 32^3 cubes written by Photoshop with TITLE and DOMAIN_MIN / DOMAIN_MAX lines: a synthetic
+    cube of those sizes through the parser, the record-table build and the kernels (stand-alone, fused, uint8), unit and
+    non-unit domains (the IEEE division per axis)."""
+    from comfyui_vrgamedevgirl_amd import cube
+    g = torch.Generator().manual_seed(n * 7 + int(dmax[2] * 10))
+    table = torch.rand((n, n, n, 3), generator=g)                       # [b][g][r][rgb]
+    path = tmp_path / f"synthetic_{n}.cube"
+    with open(path, "w") as fh:
+        fh.write(f'TITLE "synthetic {n}"\n# comment\nLUT_3D_SIZE {n}\n')
+        fh.write("DOMAIN_MIN " + " ".join(repr(float(v)) for v in dmin) + "\nDOMAIN_MAX " + " ".join(repr(float(v)) for v in dmax) + "\n\n")
+        for b in range(n):
+            for gg in range(n):
+                for r in range(n):
+                    v = table[b, gg, r]
+                    fh.write(f"{v[0].item():.6f} {v[1].item():.6f} {v[2].item():.6f}\n")
+    data = R.parse_cube_file(str(path))
+    ours = cube.parse_cube_file(str(path))
+    assert torch.equal(ours["lut"], data["lut"]) and torch.equal(ours["domain_min"], data["domain_min"]) and torch.equal(ours["domain_max"], data["domain_max"])
+    dlut = ops.upload_lut(ours, dev)
+    x = _rand((2, 61, 83, 3), n, -0.4, 1.7)
+    x[0, 0, :6, :] = torch.tensor([0.0, 1.0, float(dmin[0]), float(dmax[1]), 0.5, 2.5]).view(6, 1)
+    for s_ in (10.0, 4.2):
+        assert_bit_equal(ops.lut3d(x.to(dev), dlut, s_), R.apply_lut_with_strength(x, data, s_), f"{n}^3 domain {dmin}..{dmax} strength {s_}")
+    torch.manual_seed(3)
+    fused = ops.fused_chain(x.to(dev), ops.ChainSpec(grain=(0.05, 0.5, 2), lut=(dlut, 10.0), sharpen=("unsharp", 0.6, False)))
+    torch.manual_seed(3)
+    o = R.fast_film_grain(x, 0.05, 0.5, 2, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    assert_bit_equal(fused, R.unsharp(R.apply_lut_with_strength(o, data, 10.0), 0.6, False), "fused chain on the synthetic cube")
+
+
 def test_make_lut_node(pkg, dev, tmp_path, monkeypatch):
     from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
     monkeypatch.setattr(iv, "LUTS_DIR", str(tmp_path))
@@ -341,6 +373,29 @@ def _dbg(pkg, x, op, y=0.0, triples=False):
 def _all_floats(lo, hi, dev):
     a, b = int(np.float32(lo).view(np.int32)), int(np.float32(hi).view(np.int32))
     return torch.arange(a, b + 1, dtype=torch.int32, device=dev).view(torch.float32)
+
+
+def test_bench_two_rank_flow_on_one_gpu_with_gloo(dev):
+    """bench.py's N > 1 path end to end on real hardware: self-launch under torch.distributed.run, two ranks, the reference
+    frame's rows split and merged by the collective, frames sharded by absolute chunk index, max-over-ranks timing, one JSON
+    line.  A 1-GPU box cannot host two RCCL ranks (duplicate device), so the ranks share cuda:0 and talk gloo
+    (VRGDG_DIST_BACKEND): everything but the RCCL transport itself is the production code."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, VRGDG_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "8", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "gloo" and len(line["per_rank_ms_per_step"]) == 2
+    assert line["value"] > 0 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == 8
+    assert line["fast_variant"]["value"] > line["value"]
 
 
 def test_stats_allreduce_entry_point_over_rccl(pkg, ops, dev):
