@@ -525,6 +525,40 @@ def test_lab_transforms_bit_equal_device_oracle(pkg, dev):
     assert _unit_ulps(fast_rgb, want_rgb) <= 2 * 130 and _unit_ulps(fast_rgb, cpu_rgb) <= 2 * 130
 
 
+def _same_with_nans(got, want, what):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want)), f"{what}: NaN positions differ"
+    assert_bit_equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0), what)
+
+
+def test_colour_match_special_values_like_the_device_oracle(pkg, ops, dev):
+    """Out-of-range and non-finite pixels: negative, > 1, huge, +-Inf, NaN, subnormal.  kornia's where() evaluates both
+    branches on every element and the clamps propagate NaN; the device policy must give what torch gives on the GPU."""
+    vals = [0.0, -0.0, -0.3, -1e-30, 1e-40, 1.17549435e-38, 0.04045, 0.040450003, 0.5, 1.0, 1.5, 7.0, 3.0e4, 1e30, float("inf"), float("-inf"),
+            float("nan")]
+    n = len(vals)
+    grid = torch.tensor(vals, dtype=torch.float32)
+    x = torch.stack(torch.meshgrid(grid, grid, grid, indexing="ij"), dim=-1).reshape(1, n, n * n, 3).contiguous().to(dev)
+    want = R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    _same_with_nans(_dbg(pkg, x, 5, triples=True), want, "rgb_to_lab on special values")
+    lab = torch.stack(torch.meshgrid(torch.tensor([0.0, -20.0, 50.0, 100.0, 150.0, 1e6, float("inf"), float("nan")]),
+                                     torch.tensor([0.0, -200.0, 120.0, 1e5, float("-inf"), float("nan")]),
+                                     torch.tensor([0.0, -150.0, 90.0, 300.0, float("inf"), float("nan")]), indexing="ij"), dim=-1)
+    lab = lab.reshape(1, 8, 36, 3).contiguous().to(dev)
+    _same_with_nans(_dbg(pkg, lab, 6, triples=True), R.kornia_lab_to_rgb(lab.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous(),
+                    "lab_to_rgb on special values")
+    # whole colour match on finite out-of-range frames (element-wise path with the oracle's statistics), and a frame with a NaN
+    # pixel: NaN statistics -> an all-NaN frame on both sides
+    y = _rand((3, 40, 56, 3), 91, -0.5, 1.8)
+    y[2, 3, 4, 1] = float("nan")
+    yd, ref = y.to(dev), (_rand((1, 16, 16, 3), 92) * 0.7 + 0.1).to(dev)
+    ims, _ = _stats_per_frame(yd, 1)
+    rms, _ = _stats_per_frame(ref, 1)
+    _same_with_nans(ops.colormatch_apply(yd, ims, rms, 0.6, cm_math="device"), R.color_match(yd, ref, 0.6, 1), "apply on out-of-range frames")
+    got = ops.color_match(yd, ref, 0.6)
+    assert bool(torch.isnan(got[2]).all()) and not bool(torch.isnan(got[:2]).any())
+
+
 def test_lab_image_of_the_statistics_pass_bit_equal_device_oracle(ops, dev):
     """pass 1 stores the Lab image pass 2 reads: general kernel, and LUT -> Lab, against torch on the device"""
     data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
