@@ -234,7 +234,7 @@ def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensi
 
 @dataclass
 class DeviceLut:
-    table: torch.Tensor        # cell-major table on the device: [(N-1)^3 * 24] fp32 (vrg_lut_prepare_f32)
+    table: torch.Tensor        # record table on the device: (N-1)^2 * N records of 12 fp32 (vrg_lut_prepare_f32)
     size: int                  # N
     domain_min: tuple
     domain_max: tuple

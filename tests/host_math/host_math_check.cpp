@@ -114,6 +114,20 @@ void hm_stencil(const float* in, float* out, int F, int H, int W, int C, int op,
                 }
 }
 
+// device colour-match policy (DevMath) compiled for the host: v_rcp_f32 / the backend's exp lowering are replaced by IEEE 1/x and
+// libm expf, so this checks the STRUCTURE of the ocml powf transcription and of the reciprocal-multiply divisions (a wrong
+// constant, a dropped term or a swapped operand shows as an error of many ulps), not bit-equality -- that is the GPU suite's job.
+static vrg::DevMath host_dev_math_() { return vrg::DevMath{(float)2.4, (float)(1.0 / 2.4), (float)(1.0 / 3.0)}; }
+void hm_dev_pow(const float* x, float* o, int64_t n, float y) {
+    for (int64_t i = 0; i < n; ++i) o[i] = vrg::dev_pow(x[i], y);
+}
+void hm_rgb_to_lab_dev(const float* x, float* o, int64_t pixels) {
+    for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p, host_dev_math_());
+}
+void hm_lab_to_rgb_dev(const float* x, float* o, int64_t pixels) {
+    for (int64_t p = 0; p < pixels; ++p) lab_to_rgb(x + 3 * p, o + 3 * p, host_dev_math_());
+}
+
 void hm_rgb_to_lab(const float* x, float* o, int64_t pixels) {
     for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p, host_tables());
 }

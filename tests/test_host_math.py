@@ -39,6 +39,9 @@ def hm(tmp_path_factory):
     lib.hm_lab_to_rgb.argtypes = [F32P, F32P, C.c_int64]
     lib.hm_colormatch.argtypes = [F32P, F32P, C.c_int64, F32P, F32P, C.c_float, C.c_float]
     lib.hm_pow.argtypes = [F32P, F32P, C.c_int64, C.c_double]
+    lib.hm_dev_pow.argtypes = [F32P, F32P, C.c_int64, C.c_float]
+    lib.hm_rgb_to_lab_dev.argtypes = [F32P, F32P, C.c_int64]
+    lib.hm_lab_to_rgb_dev.argtypes = [F32P, F32P, C.c_int64]
     lib.hm_divc_mismatches.argtypes = [F32P, C.c_int64, C.c_int]
     lib.hm_divc_mismatches.restype = C.c_int64
     return lib
@@ -275,3 +278,37 @@ def test_cbrt_pow_is_correctly_rounded_on_its_domain(hm):
     err = np.abs(got.astype(np.float64) - truth) / ulp
     assert err.max() <= 0.5001, err.max()
     assert np.mean(got != truth.astype(np.float32)) < 1e-5
+
+
+def test_device_policy_transcription_structure_on_the_host(hm):
+    """dev_pow (ocml powf without its scaffolding) and the device-policy Lab transforms compiled for the host: with IEEE 1/x for
+    v_rcp_f32 and libm expf for the backend's exp they are not bit-equal to the device, but any transcription slip (a constant,
+    a dropped low-order term, a swapped operand) costs far more than the <= 2 ulp the double-word algorithm delivers."""
+    rng = np.random.default_rng(3)
+    for y, lo, hi in ((2.4, 0.0625, 4.0), (1 / 2.4, 0.0031308, 4.0), (1 / 3.0, 0.008856, 4.0), (2.4, 1e-30, 1e30)):
+        x = np.exp(rng.uniform(np.log(lo), np.log(hi), 200000)).astype(np.float32)
+        out = np.empty_like(x)
+        hm.hm_dev_pow(x, out, x.size, f32(y))
+        want = np.power(x.astype(np.float64), np.float64(np.float32(y)))
+        ok = np.isfinite(want) & (want > 1e-37) & (want < 3e38)
+        ulps = np.abs(out[ok].astype(np.float64) - want[ok]) / (np.abs(want[ok]) * 2.0 ** -23)
+        assert ulps.max() < 2.0, (y, ulps.max())
+    assert np.isinf(np.float32(_one(hm, np.inf, 2.4))) and np.isnan(_one(hm, np.nan, 2.4)) and _one(hm, 1.0, 2.4) == 1.0
+    from oracle import restated as R
+    import torch
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.rand(4000, 3, generator=g)
+    lab = np.empty((4000, 3), np.float32)
+    hm.hm_rgb_to_lab_dev(np.ascontiguousarray(rgb.numpy()), lab, 4000)
+    want = R.kornia_rgb_to_lab(rgb.t().reshape(1, 3, 1, 4000))[0, :, 0, :].t().numpy()
+    assert np.abs(lab - want).max() < 3e-4                      # Lab units (L up to 100): a few ulp of the powers through the 500 / 200 gains
+    back = np.empty((4000, 3), np.float32)
+    hm.hm_lab_to_rgb_dev(np.ascontiguousarray(lab), back, 4000)
+    assert np.abs(back - rgb.numpy()).max() < 2e-5              # round trip
+
+
+def _one(hm, x, y):
+    a = np.array([x], np.float32)
+    o = np.empty(1, np.float32)
+    hm.hm_dev_pow(a, o, 1, f32(y))
+    return o[0]
