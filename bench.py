@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="4K frames of the bounded CPU-baseline sample (x4 at 1080p)")
     ap.add_argument("--no-fast-variant", action="store_true", help="skip the extra timing of the fast colour-match policy")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic (use profiles/)")
     return ap.parse_args()
 
 
@@ -106,6 +107,51 @@ def _profile_json(*names):
             with open(path) as fh:
                 return json.load(fh), n
     raise FileNotFoundError(names[0])
+
+
+def live_traffic(timeout_s=150):
+    """HBM bytes per pixel of the headline kernels from the PMC counters ON THIS BOX: two extra `rocprofv3 --kernel-trace --pmc`
+    runs (FETCH_SIZE, WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes) of tools/prof_driver.py, which executes
+    the same kernels on 16 x 4K frames in its own process (rocprofv3 wraps a process, so it cannot observe this one).
+    FETCH_SIZE is doubled (the gfx950 under-count for wide coalesced reads; calibrated on k_lut3d's known 12 B/px in the same
+    run), both counters are in KB.  Returns {"stats": {...}, "apply": {...}, "chain3_apply": {...}} or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        raise RuntimeError("rocprofv3 not on PATH")
+    tmp = tempfile.mkdtemp(prefix="vrg_traffic_")
+    per_px = {}
+    px = 16 * 2160 * 3840
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                            sys.executable, os.path.join(ROOT, "tools", "prof_driver.py"), "traffic"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if "vrg" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(counter, []).append(float(r["Counter_Value"]) * 1024.0 / px)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def bpp(match):
+        rd = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 2.0 for k, v in per_px.items() if match(k) and "FETCH_SIZE" in v)
+        wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
+        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2)}
+    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k),
+           "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
+    if not res["calibration_k_lut3d"]["total"]:
+        raise RuntimeError("no counters collected")
+    return res
 
 
 def _median_time(fn, warmup=1, reps=3):
@@ -287,13 +333,29 @@ def main():
     # HBM traffic of the dominant pass from the PMC run committed under profiles/ (rocprofv3 cannot run inside this
     # process): bytes per pixel measured there x the pixels of one launch here
     traffic, traffic_note = None, None
+    key = dom if "colormatch" in stages else "chain3_apply"
+    if rank == 0 and world == 1 and not args.no_live_traffic and args.workload in ("chain4_4k", "chain3_4k"):
+        try:
+            del out, lab_ws                                   # the profiled side process needs ~5 GB of the HBM
+            torch.cuda.empty_cache()
+            summ = live_traffic()
+            if summ.get(key, {}).get("total"):
+                traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
+                traffic_note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on this box right after the timed region (separate "
+                                f"passes, own process, the same kernels on 16x4K frames): {summ[key]['read']} B/px read + "
+                                f"{summ[key]['written']} B/px written (FETCH_SIZE x2 per the gfx950 calibration; k_lut3d in the same run: "
+                                f"{summ['calibration_k_lut3d']['read']} + {summ['calibration_k_lut3d']['written']} for its known 12 + 12) x this "
+                                "launch's pixels" + ("; the written bytes are the Lab image kept for pass 2, not re-reads" if key == "stats" else ""))
+        except Exception as exc:
+            traffic_note = f"live PMC passes failed ({type(exc).__name__}: {exc}); "
     try:
+        if traffic is not None:
+            raise StopIteration
         tj, tname = _profile_json("r02_pmc_traffic_fetch_write.json", "r01_pmc_traffic_fetch_write.json")
         summ = tj.get("summary", {})
-        key = dom if "colormatch" in stages else "chain3_apply"
         if summ.get(key, {}).get("total"):
             traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
-            traffic_note = (f"NOT collected in this process (rocprofv3 wraps a process): profiles/{tname}, the same kernels on 16x4K frames: "
+            traffic_note = (traffic_note or "") + (f"NOT collected in this process (rocprofv3 wraps a process): profiles/{tname}, the same kernels on 16x4K frames: "
                             f"{summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
                             "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per the gfx950 calibration) x this launch's pixels"
                             + ("; the written bytes are the Lab image kept for pass 2 (design choice measured in DESIGN.md section 3: "

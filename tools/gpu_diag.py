@@ -305,6 +305,10 @@ def kernel_bench(ops, frames_4k, iters, match=""):
                     cases.append((f"probe lut fetch mode {mode} {src_name}", 16, (lambda m=mode, t=tab, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
                         _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), lut33.size, m, _hip.current_stream()), "probe"))))
                 # channel split: one (33^3, 32^3) / two (25^3) channels of the node table in LDS, the rest gathered
+                for nsz in (25, 28, 30, 32):      # cell-major 128-byte records (mode 4) against the 48-byte record runs (mode 0), by cube size
+                    for mode, tab in ((0, lut33.table), (4, cellmajor)):
+                        cases.append((f"probe lut cellmajor-vs-records n={nsz} mode {mode} {src_name}", 16, (lambda m=mode, n_=nsz, t=tab, s_=src: _hip.check(
+                            _hip.lib().vrg_debug_lut_fetch(_hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), n_, m, _hip.current_stream()), "probe"))))
                 for nsz, mode in ((33, 5), (32, 5), (25, 6), (25, 5), (25, 0), (17, 6), (33, 7), (33, 8), (25, 7), (25, 8), (17, 7)):
                     cases.append((f"probe lut split n={nsz} mode {mode} {src_name}", 16, (lambda m=mode, n_=nsz, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
                         _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(lut33.table), n_, m, _hip.current_stream()), "probe"))))
