@@ -64,6 +64,7 @@ _SIGNATURES = {
     "vrg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "vrg_event_destroy": (C.c_int, [_P]),
     "vrg_selftest_divconst": (C.c_int, [_P, _P]),
+    "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
     "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),

@@ -29,6 +29,15 @@ __global__ __launch_bounds__(256) void k_selftest_divconst(unsigned long long* c
     }
 }
 
+// Exhaustive device check of the trimmed square root of the Box-Muller radius: one thread per 32-bit Philox word.
+// counts[0] = inputs where bm_radius (sqrt_normal_range) != the backend's IEEE sqrt of the same argument (must be 0).
+__global__ __launch_bounds__(256) void k_selftest_bm_radius(unsigned long long* counts, uint32_t first) {
+    const uint32_t a = first + blockIdx.x * 256u + threadIdx.x;
+    const float x = bm_radius_arg(a);
+    const float got = bm_radius(a), want = __builtin_sqrtf(x);
+    if (!(got == want) || !(x >= 0.0f)) atomicAdd(&counts[0], 1ull);
+}
+
 // ---- micro-benchmark of LUT record fetch patterns (timing only; results are checksums, not pixels) ----------
 //  mode 0: every lane reads its own 96-B record as 6 x 16 B                       (what k_lut3d does)
 //  mode 1: every lane reads half of its record (3 x 16 B)                          (is the L1 request rate the bound?)
@@ -320,6 +329,16 @@ int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float
         default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
     }
     VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream) {
+    if (!counts1) return VRG_ERR_BAD_ARG;
+    if (hipMemsetAsync(counts1, 0, sizeof(unsigned long long), (hipStream_t)stream) != hipSuccess) return VRG_ERR_LAUNCH;
+    for (uint32_t part = 0; part < 4; ++part) {
+        hipLaunchKernelGGL(vrg::k_selftest_bm_radius, dim3(1u << 22), dim3(256), 0, (hipStream_t)stream, counts1, part << 30);
+        VRG_CHECK_LAUNCH();
+    }
     return VRG_OK;
 }
 

@@ -274,6 +274,9 @@ int vrg_device_info(int32_t* cu_count, int32_t* max_threads_per_cu);
  * counts18 (device, 18 x u64): [0..8] mismatches for 1e-30 <= |x| <= 1e30 (expected 0 for all nine
  * constants), [9..17] mismatches outside that range. */
 int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
+/* Device self-test: the trimmed correctly-rounded square root of the Box-Muller radius (csrc/vrg_pixel_math.hpp
+ * sqrt_normal_range) against the backend's IEEE sqrt for all 2^32 Philox words; counts1[0] = mismatches (expected 0). */
+int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
 /* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);

@@ -83,6 +83,13 @@ def test_constant_divisions_equal_ieee_division_for_every_fp32_input(pkg, dev):
     assert c[17] == 0, c            # c = 9: exact everywhere (+-0 compare equal, Inf handled)
 
 
+def test_box_muller_radius_sqrt_equals_ieee_sqrt_for_every_philox_word(pkg, dev):
+    from comfyui_vrgamedevgirl_amd import _hip
+    counts = torch.zeros(1, dtype=torch.int64, device=dev)
+    _hip.check(_hip.lib().vrg_selftest_bm_radius(_hip.ptr(counts), _hip.current_stream()), "vrg_selftest_bm_radius")
+    assert int(counts.item()) == 0
+
+
 def test_dpp_lane_shifts(pkg, dev):
     """The wave-march kernel takes 3x3 taps and misaligned normals from neighbouring lanes with DPP wave shifts."""
     from comfyui_vrgamedevgirl_amd import _hip
