@@ -1,9 +1,9 @@
-// vrg_march.hip -- the fused chain as a register-resident "wave march" (default kernel of
-// vrg_fused_chain_f32).  gfx950 only.
+// vrg_march.hip -- the fused grain -> LUT -> 3x3 sharpen chain (any subset, no colour-match stage) as a
+// register-resident "wave march": the kernel vrg_fused_chain_f32 picks for grain -> (LUT) -> sharpen.  gfx950 only.
 //
 // One wave64 owns a vertical strip 64 pixels wide and walks down it one frame row per step: every lane
 // keeps the last three processed rows of its column in VGPRs, the 3x3 taps of the left/right columns come
-// from the neighbouring lanes with DPP wave shifts, so the grain->LUT->colour-match result of a pixel is
+// from the neighbouring lanes with DPP wave shifts, so the grain -> LUT result of a pixel is
 // computed once (no LDS tile, no barrier, no halo rows recomputed per tile; 61 of 64 lanes produce
 // output, 2 rows of ~49 are priming).
 //
