@@ -316,6 +316,8 @@ static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) 
 
 int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st);
 bool produce_applicable(int stages, int64_t frame_elems);
+int launch_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
+                    float one_minus_sat, const vrg_noise_desc* nd, void* stream);      // vrg_pointwise.hip
 bool lut_lds_applicable(int lut_size, int64_t pixels);
 int launch_lut_lds(const void* in, void* out, int64_t pixels, const LutParams& P, bool u8, hipStream_t st);
 int64_t produce_scratch_bytes(const ChainK& D, int64_t frames, int64_t fe);
@@ -479,6 +481,8 @@ int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t 
     if (rc) return rc;
     const bool sharpen = (desc->stages & VRG_STAGE_SHARPEN) != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (desc->stages == VRG_STAGE_GRAIN && (desc->variant & 0xff) == 0)      // grain alone: the shared-Philox grain kernel on uint8 frames
+        return launch_grain_u8(in, out, frames, height, width, desc->intensity, desc->sat, desc->one_minus_sat, &desc->noise, stream);
     if (desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
         return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, true, st);                      // small cube: table in LDS
     switch (desc->stages & 3) {

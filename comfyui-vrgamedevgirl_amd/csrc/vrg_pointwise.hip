@@ -46,9 +46,13 @@ __global__ __launch_bounds__(256) void k_noise(float* __restrict__ out, NoiseK n
 constexpr int GRAIN_IPT = 4;                    // subsequences per thread
 constexpr int GRAIN_N = 256 * GRAIN_IPT;        // subsequences per block
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_grain(const float* __restrict__ in, float* __restrict__ out, NoiseK nk,
+// U8: decoded video frames, uint8 B,G,R per pixel (element li = 3 p + c of the reference's fp32 R,G,B tensor lives in byte
+// 3 p + 2 - c); the / 255 and the * 255-clip-truncate of the frame converters happen at the load and the store.
+template <bool VEC, bool U8 = false>
+__global__ __launch_bounds__(256) void k_grain(const void* __restrict__ in_, void* __restrict__ out_, NoiseK nk,
                                                 int64_t chunk_numel, uint32_t groups_per_chunk, float I, float S, float T) {
+    const float* in = reinterpret_cast<const float*>(in_);
+    float* out = reinterpret_cast<float*>(out_);
     __shared__ float sn[4][GRAIN_N + 8];
     const uint32_t G = nk.G;
     const uint32_t blocks_per_group = (G + GRAIN_N - 1) / GRAIN_N;
@@ -98,21 +102,38 @@ __global__ __launch_bounds__(256) void k_grain(const float* __restrict__ in, flo
         if (li0 >= chunk_numel) continue;
         float x[4], o[4];
         const bool full = li0 + 3 < chunk_numel;
-        if (VEC && full) {
+        int c = (int)((uint32_t)li0 % 3u);   // chunk_numel < 2^31 (checked by the entry point)
+        const uint8_t* cin8 = reinterpret_cast<const uint8_t*>(in_) + chunk * chunk_numel;
+        uint8_t* cout8 = reinterpret_cast<uint8_t*>(out_) + chunk * chunk_numel;
+        if (U8) {
+            int cc = c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                x[j] = (li0 + j < chunk_numel) ? unit_from_u8(cin8[li0 + j + 2 - 2 * cc]) : 0.0f;      // byte 3p + 2 - c = li + 2 - 2c
+                cc = (cc == 2) ? 0 : cc + 1;
+            }
+        } else if (VEC && full) {
             const float4 v = *reinterpret_cast<const float4*>(cin + li0);
             x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = (li0 + j < chunk_numel) ? cin[li0 + j] : 0.0f;
         }
-        int c = (int)((uint32_t)li0 % 3u);   // chunk_numel < 2^31 (checked by the entry point)
+        const int c_first = c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float ng = sn[ii][4 + t4 + j + 1 - c];   // c==1: itself
             o[j] = grain_element(x[j], nz[j][ii], ng, c, I, S, T);
             c = (c == 2) ? 0 : c + 1;
         }
-        if (VEC && full) {
+        if (U8) {
+            int cc = c_first;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (li0 + j < chunk_numel) cout8[li0 + j + 2 - 2 * cc] = u8_from_unit(o[j]);
+                cc = (cc == 2) ? 0 : cc + 1;
+            }
+        } else if (VEC && full) {
             *reinterpret_cast<float4*>(cout + li0) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
 #pragma unroll
@@ -269,8 +290,8 @@ int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems, const vrg_noi
     return VRG_OK;
 }
 
-int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
-                  float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+static int launch_grain_any(const void* in, void* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
+                            float one_minus_sat, const vrg_noise_desc* nd, bool u8, void* stream) {
     if (!in || !out || !nd || frames < 0 || height <= 0 || width <= 0 || nd->chunk_frames < 1 || nd->grid_threads == 0 ||
         (nd->grid_threads % 256u) != 0)
         return VRG_ERR_BAD_ARG;
@@ -286,15 +307,34 @@ int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, i
     if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
     // float4 path needs every chunk base and G*ii offsets 16-byte aligned
     const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) && (numel % 4 == 0);
-    if (vec)
-        hipLaunchKernelGGL(k_grain<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
+    if (u8)
+        hipLaunchKernelGGL((k_grain<false, true>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
+                           (uint32_t)groups, intensity, sat, one_minus_sat);
+    else if (vec)
+        hipLaunchKernelGGL((k_grain<true, false>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
                            (uint32_t)groups, intensity, sat, one_minus_sat);
     else
-        hipLaunchKernelGGL(k_grain<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
+        hipLaunchKernelGGL((k_grain<false, false>), dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, nk, numel,
                            (uint32_t)groups, intensity, sat, one_minus_sat);
     VRG_CHECK_LAUNCH();
     return VRG_OK;
 }
+
+int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
+                  float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+    return launch_grain_any(in, out, frames, height, width, intensity, sat, one_minus_sat, nd, false, stream);
+}
+
+// uint8 B,G,R frames, grain only: the shared-Philox kernel (one Philox call per four elements instead of the point-wise
+// chain kernel's one per element).  Used by vrg_fused_chain_u8 for a chain that is just the grain stage.
+}  // extern "C"
+namespace vrg {
+int launch_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
+                    float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+    return launch_grain_any(in, out, frames, height, width, intensity, sat, one_minus_sat, nd, true, stream);
+}
+}  // namespace vrg
+extern "C" {
 
 int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels, float intensity, float sat,
                            float one_minus_sat, void* stream) {

@@ -1091,12 +1091,13 @@ U8_CHAINS = [
 
 @pytest.mark.parametrize("shape", [(4, 45, 70, 3), (2, 64, 129, 3), (3, 1, 5, 3), (2, 270, 480, 3)])
 @pytest.mark.parametrize("case", U8_CHAINS)
-def test_fused_chain_u8_equals_convert_chain_convert(ops, dev, case, shape):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fused_chain_u8_equals_convert_chain_convert(ops, dev, case, shape, variant):
     data, dlut = _lut_pair(ops, dev)
     g = torch.Generator().manual_seed(sum(shape))
     frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
     spec = ops.ChainSpec(grain=case["grain"], lut=(dlut, case["lut"]) if case["lut"] is not None else None, sharpen=case["sharpen"],
-                         variant=1)
+                         variant=variant)       # 0: the library's choice (grain alone: the shared-Philox grain kernel on uint8 frames)
     torch.manual_seed(5)
     got = ops.fused_chain(frames.to(dev), spec)
     assert got.dtype == torch.uint8 and got.shape == frames.shape
