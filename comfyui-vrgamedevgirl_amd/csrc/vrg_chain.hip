@@ -423,6 +423,8 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     // bound and the march wins (Philox shared across four strips, no LDS); point-wise chains, chains without
     // grain and the colour-match apply pass run faster on the higher-occupancy tile / point-wise kernels.
     int variant = desc->variant & 0xff;
+    if (variant == 0 && desc->stages == VRG_STAGE_GRAIN)      // grain alone: the shared-Philox grain kernel (one Philox call per four elements)
+        return vrg_grain_f32(in, out, frames, height, width, desc->intensity, desc->sat, desc->one_minus_sat, &desc->noise, stream);
     if (variant == 0) {
         variant = ((desc->stages & VRG_STAGE_GRAIN) && (desc->stages & VRG_STAGE_SHARPEN) && !(desc->stages & VRG_STAGE_COLORMATCH)) ? 2 : 1;
         // a cube of at most 21^3 lives in LDS inside the march kernel: no gather path, so it also wins for LUT -> sharpen
