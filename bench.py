@@ -349,7 +349,7 @@ def main():
         except Exception as exc:
             traffic_note = f"live PMC passes failed ({type(exc).__name__}: {exc}); "
     try:
-        if traffic is not None:
+        if traffic is not None or args.workload not in ("chain4_4k", "chain3_4k"):      # the PMC passes cover these two workloads' kernels
             raise StopIteration
         tj, tname = _profile_json("r02_pmc_traffic_fetch_write.json", "r01_pmc_traffic_fetch_write.json")
         summ = tj.get("summary", {})
