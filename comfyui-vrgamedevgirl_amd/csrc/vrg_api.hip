@@ -173,15 +173,16 @@ __global__ __launch_bounds__(1024) void k_dbg_lut_passes(const px3* __restrict__
 //  op 1: x * fl(1/y)                                         (x / python_scalar on the GPU)
 //  op 2: x / y, IEEE                                         (x / tensor)
 //  op 3: pow_pos(x, y)      op 4: cbrt_pow(x)                (the fast policy's powers)
-//  op 9: dev_pow(x, y), the scaffolding-free transcription of ocml powf the device policy uses
+//  op 9 / 10 / 11: dev_pow_t<DEV_POW_ANY / _OVF / _UNIT>(x, y), the scaffolding-free transcription of ocml powf the device
+//        policy uses (_OVF in srgb -> linear, _UNIT in linear -> srgb and the Lab cube root)
 //  op 5: Lab of an RGB triple / op 6: RGB of a Lab triple, device policy; op 7 / 8: the same with the fast policy
 __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ in, float* __restrict__ out, int64_t n, int op, float y,
                                                       DevMath dm) {
     VRG_CM_MATH(PT, true, true, dm);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (op == 9) {
-        out[i] = dev_pow(in[i], y);
+    if (op >= 9) {
+        out[i] = op == 9 ? dev_pow_t<DEV_POW_ANY>(in[i], y) : (op == 10 ? dev_pow_t<DEV_POW_OVF>(in[i], y) : dev_pow_t<DEV_POW_UNIT>(in[i], y));
     } else if (op <= 4) {
         const float x = in[i];
         float r;
@@ -284,7 +285,7 @@ int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode,
 }
 
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream) {
-    if (!in || !out || n <= 0 || op < 0 || op > 9) return VRG_ERR_BAD_ARG;
+    if (!in || !out || n <= 0 || op < 0 || op > 11) return VRG_ERR_BAD_ARG;
     const uint64_t blocks = (uint64_t)(n + 255) / 256;
     if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vrg::k_dbg_cm_math, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n, op, y, vrg::host_dev_math());

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k_chain_pointwise(const typename IO::elem
     const px3 v = IO::load_stream(in + f * ppf + p);
     const float x[3] = {v.r, v.g, v.b};
     float o[3];
-    chain_pre<STAGES>(D, f, p, x, o, PT);
+    chain_pre<STAGES>(D, frame_ctx<STAGES>(D, f), p, x, o, PT);
     IO::store_stream(out + f * ppf + p, px3{o[0], o[1], o[2]});
 }
 
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
     const int32_t ppf = H * W;
     const typename IO::elem* fin = in + f * ppf;
     const bool zero = D.zero_border != 0;
+    const FrameCtx FC = frame_ctx<STAGES>(D, f);
 
     for (int i = threadIdx.x; i < HALO_H * HALO_W; i += 256) {
         const int hy = i / HALO_W, hx = i - hy * HALO_W;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
             const int32_t p = y * W + x;
             const px3 v = IO::load(fin + p);   // plain load: halo pixels are re-read by the neighbouring tiles (L2 hits)
             const float xi[3] = {v.r, v.g, v.b};
-            chain_pre<STAGES>(D, f, p, xi, o, PT);
+            chain_pre<STAGES>(D, FC, p, xi, o, PT);
         }
         tile[0][hy][hx] = o[0];
         tile[1][hy][hx] = o[1];
@@ -141,12 +142,13 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
     VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int64_t f = blockIdx.y;
     const px3* fin = in + f * ppf;
+    const FrameCtx FC = frame_ctx<STAGES>(D, f);
     float pivot[3];
     {
         const px3 v0 = fin[0];
         const float x0[3] = {v0.r, v0.g, v0.b};
         float pre[3];
-        chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+        chain_pre<STAGES>(D, FC, 0, x0, pre, PT);
         rgb_to_lab(pre, pivot, PT);
     }
     const int32_t per = (ppf + bpf - 1) / bpf;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
         const px3 v = load_px_stream(fin + p);
         const float x[3] = {v.r, v.g, v.b};
         float pre[3], lab[3];
-        chain_pre<STAGES>(D, f, p, x, pre, PT);
+        chain_pre<STAGES>(D, FC, p, x, pre, PT);
         rgb_to_lab(pre, lab, PT);
         if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[0], lab[1], lab[2]});
 #pragma unroll
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64) void k_lab_merge(const px3* __restrict__ in, in
         const px3 v0 = in[f * ppf];
         const float x0[3] = {v0.r, v0.g, v0.b};
         float pre[3];
-        chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+        chain_pre<STAGES>(D, frame_ctx<STAGES>(D, f), 0, x0, pre, PT);
         rgb_to_lab(pre, pivot, PT);
     }
     if (threadIdx.x < 3) {

@@ -41,6 +41,11 @@ VRG_HD float f32_from_bits(uint32_t b) {
     c.u = b;
     return c.f;
 }
+VRG_HD uint32_t f32_bits(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    return c.u;
+}
 
 // clamp(v, 0, 1) with torch.clamp / np.clip NaN behaviour (NaN stays NaN).
 // Device: one v_med3_f32 plus a NaN pass-through (v_cmp_u + v_cndmask) -- 4 issue units instead of the 6 of two
@@ -580,12 +585,46 @@ VRG_HD int host_frexp_exp(float x) { int e; (void)__builtin_frexpf(x, &e); retur
 // scaffolding is inert: 120 instead of ~195 instructions.  tests/test_gpu_parity.py sweeps EVERY fp32 base of the Lab
 // transforms' domains against torch.pow on the device (7.4e7 - 1.1e8 inputs per exponent) and against __ocml_pow_f32.
 // ------------------------------------------------------------------------------------------
-VRG_HD float dev_pow(float x, float y) {
+// GUARD selects how much of the scaffolding that is still left below is kept -- every flavour executes the SAME arithmetic,
+// a lower GUARD only drops selects that a range argument proves inert for the stated inputs (so the results are identical
+// there by construction, and the exhaustive sweeps in tests/test_gpu_parity.py run every flavour the kernels use):
+//   DEV_POW_ANY   x > 0 down to subnormals, +Inf, NaN; any finite y          (everything kept)
+//   DEV_POW_OVF   x >= 2^-20, +Inf or NaN; 0 < y <= 4: y ln x >= -56, so exp cannot underflow and no intermediate is
+//                 infinite for finite x; overflow of the result (x^2.4 for x > 1.1e16) keeps its guards
+//   DEV_POW_UNIT  x >= 2^-20, +Inf or NaN; 0 < y <= 0.5: |y ln x| <= 44.4, far from ln 2^128 = 88.72: nothing can overflow either
+// The exp of the high word is the backend's own expansion of exp(x) for fp32 (AMDGPU lowerFEXP, the one ocml's expep gets
+// inlined): exp2(x * log2e) with the product in double-word form, v_rndne / v_exp_f32 / v_ldexp_f32, then its two range
+// selects (x < -103.28 -> 0, x > 88.72 -> Inf); written out here so that the selects can be dropped where they are inert.
+// ------------------------------------------------------------------------------------------
+constexpr int DEV_POW_ANY = 0, DEV_POW_OVF = 1, DEV_POW_UNIT = 2;
+
+VRG_HD float dev_exp_core(float x) {
+    const float c = f32_from_bits(0x3fb8aa3bu);                      // log2(e), high word
+    const float ph = x * c;
+    const float f0 = __builtin_fmaf(x, c, -ph);
+    const float pl = __builtin_fmaf(x, f32_from_bits(0x32a5705fu), f0);       // + x * (log2(e) - c)
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(VRG_HW_EXP2(a), (int)e);
+}
+
+template <int GUARD>
+VRG_HD float dev_pow_t(float x, float y) {
     // ---- epln: ln(x) = hi + lo
-    float m = VRG_HW_FREXP_MANT(x);
-    const bool low = m < f32_from_bits(0x3f2aaaabu);                 // 2/3
-    m = m * (low ? 2.0f : 1.0f);
-    const int e = VRG_HW_FREXP_EXP(x) - (low ? 1 : 0);
+    // x = m * 2^e with m in [2/3, 4/3)
+    float m;
+    int e;
+    if (GUARD == DEV_POW_ANY) {
+        m = VRG_HW_FREXP_MANT(x);
+        const bool low = m < f32_from_bits(0x3f2aaaabu);             // 2/3
+        m = m * (low ? 2.0f : 1.0f);
+        e = VRG_HW_FREXP_EXP(x) - (low ? 1 : 0);
+    } else {
+        // the same (m, e) for a normal x, from its bit pattern: 4 integer ops instead of frexp x 2, compare, select, multiply, borrow
+        const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
+        e = d >> 23;
+        m = f32_from_bits((uint32_t)(d & 0x007fffff) + 0x3f2aaaabu);
+    }
     const float a12 = m + -1.0f;
     const float a13 = m + 1.0f;
     const float a14 = a13 + -1.0f;
@@ -694,18 +733,30 @@ VRG_HD float dev_pow(float x, float y) {
     const float p51 = p50 - p17;
     const float p52 = p44 - p51;
     const float inf = __builtin_inff();
-    const float ph = (__builtin_fabsf(p17) == inf) ? p17 : p50;
-    const float pl = (__builtin_fabsf(ph) == inf) ? 0.0f : p52;
+    const float ovf = f32_from_bits(0x42b17218u);                    // ln 2^128
+    float ph = p50, pl = p52;
+    if (GUARD == DEV_POW_ANY) {                                      // y * ln_hi overflowed
+        ph = (__builtin_fabsf(p17) == inf) ? p17 : p50;
+        pl = (__builtin_fabsf(ph) == inf) ? 0.0f : p52;
+    }
     // ---- expep
-    const float c4 = (ph == f32_from_bits(0x42b17218u)) ? f32_from_bits(0x37000000u) : 0.0f;
-    const float h5 = ph - c4;
-    const float l7 = pl + c4;
-    const float e8 = __builtin_expf(h5);                              // the backend's exp lowering, as inside ocml
+    float h5 = ph, l7 = pl;
+    if (GUARD != DEV_POW_UNIT) {
+        const float c4 = (ph == ovf) ? f32_from_bits(0x37000000u) : 0.0f;
+        h5 = ph - c4;
+        l7 = pl + c4;
+    }
+    float e8 = dev_exp_core(h5);
+    if (GUARD == DEV_POW_ANY) e8 = (h5 < f32_from_bits(0xc2ce8ed0u)) ? 0.0f : e8;       // -103.279: the backend's underflow select
+    if (GUARD != DEV_POW_UNIT) e8 = (h5 > ovf) ? inf : e8;
     const float r9 = __builtin_fmaf(e8, l7, e8);
-    const float r = (__builtin_fabsf(e8) == inf) ? e8 : r9;
+    const float r = (GUARD != DEV_POW_UNIT && __builtin_fabsf(e8) == inf) ? e8 : r9;
     // ocml's scaffolding for the inputs this function admits: pow(+Inf, y) = y > 0 ? Inf : 0; NaN propagates by itself
-    return (x == inf) ? (y > 0.0f ? inf : 0.0f) : r;
+    // through the frexp form, and is passed on explicitly by the bit-pattern form
+    if (GUARD == DEV_POW_ANY) return (x == inf) ? (y > 0.0f ? inf : 0.0f) : r;
+    return (x < inf) ? r : ((x == inf) ? (y > 0.0f ? inf : 0.0f) : x);
 }
+VRG_HD float dev_pow(float x, float y) { return dev_pow_t<DEV_POW_ANY>(x, y); }
 
 // x / c for a Python-scalar c (written as a double literal): fast = the IEEE quotient by (float)c; device = x * (float)(1.0 / c)
 VRG_HD float cm_div_scalar(float x, float c, float rc, float, const PowTables&) { return div_const(x, c, rc); }
@@ -729,7 +780,7 @@ VRG_HD float srgb_to_linear(float v, const DevMath& M) {
     const float q = VRG_CM_DIVS(t, 1.055, M);
     // (the reference evaluates pow on every element and selects afterwards: for v <= 0.04045 the value is discarded, so the
     //  base only has to stay in dev_pow's domain there)
-    const float hi = dev_pow(clamp_min(q, 0.0625f), M.e24);
+    const float hi = dev_pow_t<DEV_POW_OVF>(clamp_min(q, 0.0625f), M.e24);
     const float lo = VRG_CM_DIVS(v, 12.92, M);
     return v > 0.04045f ? hi : lo;
 }
@@ -745,7 +796,7 @@ VRG_HD float linear_to_srgb(float v, const PowTables& T) {
 VRG_HD float linear_to_srgb(float v, const DevMath& M) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
-    const float pw = dev_pow(base, M.e1_24);
+    const float pw = dev_pow_t<DEV_POW_UNIT>(base, M.e1_24);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
@@ -773,7 +824,7 @@ VRG_HD float cbrt_pow(float x) {
 }
 
 VRG_HD float lab_cbrt(float t, const PowTables&) { return cbrt_pow(t); }
-VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow(t, M.e1_3); }
+VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow_t<DEV_POW_UNIT>(t, M.e1_3); }
 
 template <class MATH>
 VRG_HD float lab_f(float t, const MATH& T) {

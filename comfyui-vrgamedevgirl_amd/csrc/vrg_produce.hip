@@ -37,12 +37,13 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// does sibling m of block (k, ib) own pixels of two different frames?
+// does sibling m of block (k, ib) own pixels of two different frames?  (element indices of a chunk fit 31 bits: numel is
+// an int32 -- 32-bit divisions, a dozen of them per workgroup)
 __device__ __forceinline__ bool run_crosses_frame(const ProduceK& P, int64_t A) {
     if (A >= P.numel) return false;
     int64_t last = A + PR_RUN - 1;
     if (last > P.numel - 1) last = P.numel - 1;
-    return (A / P.fe) != (last / P.fe);
+    return ((uint32_t)A / (uint32_t)P.fe) != ((uint32_t)last / (uint32_t)P.fe);
 }
 
 #ifndef VRG_PRODUCE_WAVES
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int64_t A = q0 + (int64_t)G * m + run0;
-        fr[m] = A < P.numel ? (int)(A / P.fe) : -1;
+        fr[m] = A < P.numel ? (int)((uint32_t)A / (uint32_t)P.fe) : -1;
         fb[m] = ((int64_t)fr[m] + 1) * P.fe;
 #pragma unroll
         for (int part = 0; part < (TWO_PART ? 2 : 1); ++part) {
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
             pv[m][part][0] = pp[0]; pv[m][part][1] = pp[1]; pv[m][part][2] = pp[2];
         }
     }
+    const FrameCtx FC0{};            // no colour-match stage in front of the Lab transform, and the normals come from the shared draws
     double s1[4][TWO_PART ? 2 : 1][3], s2[4][TWO_PART ? 2 : 1][3];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
                 const float x[3] = {v.r, v.g, v.b};
                 const float n[3] = {sn[m][p0], sn[m][p0 + 1], sn[m][p0 + 2]};
                 float pre[3], lab[3];
-                chain_apply_stages<STAGES>(D, 0, x, n, pre, PT);
+                chain_apply_stages<STAGES>(D, FC0, x, n, pre, PT);
                 rgb_to_lab(pre, lab, PT);
                 if (clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
                 const int part = TWO_PART ? (e0 >= fb[m] ? 1 : 0) : 0;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64) void k_frame_pivots(const px3* __restrict__ in,
     const px3 v0 = in[f * ppf];
     const float x0[3] = {v0.r, v0.g, v0.b};
     float pre[3], lab[3];
-    chain_pre<STAGES>(D, f, 0, x0, pre, PT);
+    chain_pre<STAGES>(D, frame_ctx<STAGES>(D, f), 0, x0, pre, PT);
     rgb_to_lab(pre, lab, PT);
     pivots[f * 3] = lab[0]; pivots[f * 3 + 1] = lab[1]; pivots[f * 3 + 2] = lab[2];
 }

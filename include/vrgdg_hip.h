@@ -280,10 +280,12 @@ int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
 /* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);
-/* Element-wise pieces of the colour-match arithmetic for the parity tests (n values, or n triples for op >= 5):
+/* Element-wise pieces of the colour-match arithmetic for the parity tests (n values, or n triples for op 5..8):
  * op 0 ocml powf(x, y); 1 x * fl(1/y); 2 x / y; 3 fast-policy pow_pos(x, y); 4 fast-policy cube root;
- * 5 / 6 rgb->Lab / Lab->rgb with the device policy; 7 / 8 the same with the fast policy; 9 dev_pow(x, y), the
- * transcription of ocml powf without its special-case scaffolding that the device policy evaluates (x > 0). */
+ * 5 / 6 rgb->Lab / Lab->rgb with the device policy; 7 / 8 the same with the fast policy; 9 / 10 / 11 dev_pow(x, y), the
+ * transcription of ocml powf without its special-case scaffolding that the device policy evaluates: 9 any x > 0 and finite y,
+ * 10 the flavour of sRGB -> linear (x >= 2^-20, 0 < y <= 4), 11 the flavour of linear -> sRGB and the Lab cube root
+ * (x >= 2^-20, 0 < y <= 0.5). */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;

@@ -484,6 +484,14 @@ def test_device_math_pow_is_torch_pow_for_every_input_of_the_domain(pkg, dev, y,
     want = torch.pow(x, y)
     assert torch.equal(_dbg(pkg, x, 0, y), want), "__ocml_pow_f32 linked by hipcc vs torch.pow"
     assert torch.equal(_dbg(pkg, x, 9, y), want), "dev_pow (ocml powf without its special-case scaffolding) vs torch.pow"
+    # the flavour the Lab transforms instantiate for this exponent (selects dropped where a range argument proves them inert):
+    # the whole domain again, then every 7th fp32 from 2^-20 up to FLT_MAX (1.8e8 bases), +Inf and NaN
+    flavour = 10 if y > 1 else 11
+    assert torch.equal(_dbg(pkg, x, flavour, y), want), "dev_pow flavour of the Lab transforms vs torch.pow"
+    bits = torch.arange(int(np.float32(2.0 ** -20).view(np.uint32)), 0x7f800000 + 1, 7, dtype=torch.int64, device=dev).to(torch.int32)
+    span = torch.cat([bits.view(torch.float32), torch.tensor([float("inf"), float("nan"), 3.4028235e38, 1.14e16, 1.15e16], device=dev)])
+    a, b = _dbg(pkg, span, flavour, y), torch.pow(span, y)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
     sp = torch.tensor([0.0, -0.0, -0.5, -1.0, 1.0, float("inf"), float("nan"), 1e-38, 1e-45, -1e-30, 3.0e38], device=dev)
     a, b = _dbg(pkg, sp, 0, y), torch.pow(sp, y)
     assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
