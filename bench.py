@@ -110,8 +110,9 @@ def _profile_json(*names):
 
 
 def live_traffic(timeout_s=150):
-    """HBM bytes per pixel of the headline kernels from the PMC counters ON THIS BOX: two extra `rocprofv3 --kernel-trace --pmc`
-    runs (FETCH_SIZE, WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes) of tools/prof_driver.py, which executes
+    """HBM bytes and VALU lane-instructions per pixel of the headline kernels from the PMC counters ON THIS BOX: three extra
+    `rocprofv3 --kernel-trace --pmc` runs (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: separate passes, as MI355X_MICROARCH.md
+    prescribes) of tools/prof_driver.py, which executes
     the same kernels on 16 x 4K frames in its own process (rocprofv3 wraps a process, so it cannot observe this one).
     FETCH_SIZE is doubled (the gfx950 under-count for wide coalesced reads; calibrated on k_lut3d's known 12 B/px in the same
     run), both counters are in KB.  Returns {"stats": {...}, "apply": {...}, "chain3_apply": {...}} or raises."""
@@ -127,7 +128,7 @@ def live_traffic(timeout_s=150):
     per_px = {}
     px = 16 * 2160 * 3840
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             out = os.path.join(tmp, counter)
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -139,14 +140,17 @@ def live_traffic(timeout_s=150):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
                         if "vrg" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(counter, []).append(float(r["Counter_Value"]) * 1024.0 / px)
+                            # FETCH_SIZE / WRITE_SIZE count KB; SQ_INSTS_VALU counts wave64 instructions (x64 lanes)
+                            scale = 64.0 if counter == "SQ_INSTS_VALU" else 1024.0
+                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(counter, []).append(float(r["Counter_Value"]) * scale / px)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
     def bpp(match):
         rd = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 2.0 for k, v in per_px.items() if match(k) and "FETCH_SIZE" in v)
         wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
-        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2)}
+        vi = sum(sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) for k, v in per_px.items() if match(k) and "SQ_INSTS_VALU" in v)
+        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1)}
     res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k),
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
     if not res["calibration_k_lut3d"]["total"]:
@@ -332,13 +336,14 @@ def main():
     bytes_per_px_chain = 36 if "colormatch" in stages else 24
     # HBM traffic of the dominant pass from the PMC run committed under profiles/ (rocprofv3 cannot run inside this
     # process): bytes per pixel measured there x the pixels of one launch here
-    traffic, traffic_note = None, None
+    traffic, traffic_note, live_ipp = None, None, None
     key = dom if "colormatch" in stages else "chain3_apply"
     if rank == 0 and world == 1 and not args.no_live_traffic and args.workload in ("chain4_4k", "chain3_4k"):
         try:
             del out, lab_ws                                   # the profiled side process needs ~5 GB of the HBM
             torch.cuda.empty_cache()
             summ = live_traffic()
+            live_ipp = summ.get(key, {}).get("valu_lane_instr") or None
             if summ.get(key, {}).get("total"):
                 traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
                 traffic_note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on this box right after the timed region (separate "
@@ -374,11 +379,13 @@ def main():
         # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
         want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
                 ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
-        ipp = next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
+        ipp = live_ipp if live_ipp else next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
+        src = ("a rocprofv3 --pmc SQ_INSTS_VALU pass on this box right after the timed region (own process, 16x4K frames)" if live_ipp
+               else f"profiles/{iname} (SQ_INSTS_VALU, not collected in this process)")
         rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
         issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
                  "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4),
-                 "note": f"lane-instructions per pixel from profiles/{iname} (SQ_INSTS_VALU, not collected in this process) x this run's pixel rate; "
+                 "note": f"lane-instructions per pixel from {src} x this run's pixel rate; "
                          f"peak = v_fma_f32 at 8 waves/SIMD over >= 17 ms launches (profiles/{rname}); unweighted: v_pk_* / fp64 / "
                          "v_mad_u64_u32 issue at 1.8x, compare+select pairs 1.65x, transcendentals 3.45x a plain op"}
     except Exception:

@@ -77,6 +77,18 @@ def _check_frames(t: torch.Tensor, name="images", channels: Optional[int] = None
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _check_side(t: torch.Tensor, name: str, like: torch.Tensor, shape_tail=None, dtype=torch.float32):
+    """A small device-resident operand of a kernel (statistics rows, LUT record table): the kernels read it through a raw
+    pointer, so it must be contiguous, of the stated type and on the frames' GPU."""
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous {str(dtype).replace('torch.', '')} tensor")
+    if t.device != like.device:
+        raise RuntimeError(f"{name} lives on {t.device}, the frames on {like.device}")
+    if shape_tail is not None and tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"{name} must be shaped [n, {', '.join(str(v) for v in shape_tail)}], got {tuple(t.shape)}")
+    return t
+
+
 # ------------------------------------------------------------------------------------------------
 # noise descriptors
 # ------------------------------------------------------------------------------------------------
@@ -280,6 +292,7 @@ def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.
     mode, B, omB = blend_terms(strength)
     if mode == 0:
         return x
+    _check_side(lut.table, "LUT record table", x)
     out = torch.empty_like(x)
     px = x.numel() // x.shape[-1]
     if px == 0:
@@ -462,6 +475,10 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
     out = torch.empty_like(x)
     if F == 0:
         return out
+    _check_side(ref_ms, "ref_ms", x, (3, 2))
+    _check_side(img_ms, "img_ms", x, (3, 2))
+    if int(img_ms.shape[0]) != F:
+        raise ValueError(f"img_ms holds {int(img_ms.shape[0])} frames of statistics for {F} frames")
     R = int(ref_ms.shape[0])
     if R != 1 and F % R != 0:
         raise RuntimeError(f"The size of tensor a ({F}) must match the size of tensor b ({R}) at non-singleton dimension 0")
@@ -502,7 +519,7 @@ class ChainSpec:
     cm_math: object = None                 # None = default_cm_math(); "device" / "fast" (colour-match arithmetic policy)
 
 
-def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
+def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep, like: Optional[torch.Tensor] = None):
     d = _hip.ChainDesc()
     stages = 0
     if spec.grain is not None:
@@ -514,6 +531,8 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
         lut, strength = spec.lut
         mode, B, omB = blend_terms(strength)
         if mode != 0:
+            if like is not None:
+                _check_side(lut.table, "LUT record table", like)
             stages |= _hip.STAGE_LUT
             d.lut = lut.table.data_ptr(); d.lut_size = lut.size
             d.domain_min = _F3(*lut.domain_min); d.domain_max = _F3(*lut.domain_max)
@@ -521,6 +540,8 @@ def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep):
             keep.append(lut.table)
     if spec.colormatch is not None:
         ref_ms, k = spec.colormatch
+        if like is not None:
+            _check_side(ref_ms, "colormatch reference statistics", like, (3, 2))
         stages |= _hip.STAGE_COLORMATCH
         d.ref_ms = ref_ms.data_ptr(); d.ref_frames = int(ref_ms.shape[0])
         d.k, d.one_minus_k = _f32(k), _f32(1.0 - k)
@@ -557,7 +578,7 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     lib = _hip.lib()
     for f0, nf, plan in segments:
         keep = []
-        d = _chain_desc(ChainSpec(grain=spec.grain, lut=spec.lut, variant=spec.variant, cm_math=spec.cm_math), plan, keep)
+        d = _chain_desc(ChainSpec(grain=spec.grain, lut=spec.lut, variant=spec.variant, cm_math=spec.cm_math), plan, keep, x)
         nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
         scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
         src = C.c_void_p(x.data_ptr() + f0 * fe * 4)
@@ -617,7 +638,7 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     st = _hip.current_stream()
     for f0, nf, plan in segments:
         keep = []
-        d = _chain_desc(spec, plan, keep)
+        d = _chain_desc(spec, plan, keep, x)
         if d.stages == 0:
             out[f0:f0 + nf] = x[f0:f0 + nf]
             continue

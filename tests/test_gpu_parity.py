@@ -1020,6 +1020,27 @@ def test_adjust_argument_errors(ops, pkg, dev):
     assert ops.adjust(torch.zeros(0, 4, 4, 3, device=dev), terms).shape == (0, 4, 4, 3)
 
 
+def test_side_operands_are_validated(ops, pkg, dev):
+    """Statistics rows and LUT record tables reach the kernels as raw pointers: wrong device / type / layout must raise."""
+    x = _rand((2, 8, 8, 3), 5).to(dev)
+    ms = ops.finalize_stats(ops.lab_stats(x))
+    with pytest.raises(RuntimeError):
+        ops.colormatch_apply(x, ms, ms[:1].cpu(), 1.0)
+    with pytest.raises(ValueError):
+        ops.colormatch_apply(x, ms[:1], ms[:1], 1.0)                     # statistics of one frame for two
+    with pytest.raises(ValueError):
+        ops.colormatch_apply(x, ms.double(), ms[:1], 1.0)
+    with pytest.raises(ValueError):
+        ops.fused_chain(x, ops.ChainSpec(colormatch=(ms.permute(0, 2, 1)[:1], 1.0)))      # [n, 2, 3] view
+    lut = ops.upload_lut({"size": 5, "lut": _rand((5, 5, 5, 3), 9), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}, dev)
+    bad = ops.DeviceLut(lut.table.cpu(), lut.size, lut.domain_min, lut.domain_max)
+    with pytest.raises(RuntimeError):
+        ops.lut3d(x, bad, 10.0)
+    with pytest.raises(RuntimeError):
+        ops.fused_chain(x, ops.ChainSpec(lut=(bad, 10.0)))
+    assert_bit_equal(ops.colormatch_apply(x, ms, ms[:1], 1.0), ops.color_match(x, None, 1.0, ref_ms=ms[:1], cache_lab=False), "apply forms")
+
+
 # ---------------------------------------------------------------------------------------- uint8 codec edge (8f-3)
 def _frames_eq(got, want, what):
     got = np.stack([np.asarray(f) for f in got], axis=0) if isinstance(got, list) else np.asarray(got)
