@@ -6,9 +6,13 @@ The reference drives ffmpeg for everything around the numbers (frame extraction 
 graph, re-encode).  What is *its own arithmetic* -- the channel statistics (PIL.ImageStat), scales / offsets, the 17^3
 ``.cube`` it writes and the blend-weight expression -- is reproduced here exactly, with the statistics as one exact
 integer reduction on the GPU (``vrg_u8_channel_sums``).  The per-pixel part that ffmpeg performs (LUT lookup + fade
-blend) runs on the decoded uint8 frames through this package's LUT kernel; ffmpeg's own filter arithmetic (tetrahedral
-``lut3d`` on its internal pixel format, 8-bit blend) is a third-party implementation and is not bit-reproduced -- the
-LUT is affine per channel below the clamp, so trilinear and tetrahedral interpolation agree there.
+blend) runs on the decoded uint8 frames, with either arithmetic (``filter_arithmetic``):
+  "nodes"   this package's LUT stage (trilinear, fp32 blend ``x*(1-w) + y*w``, one quantisation at the end): bit-exact
+            against the oracle composition of the reference's own LUT node arithmetic;
+  "ffmpeg"  ffmpeg's filters as published (tetrahedral ``lut3d`` with its 8-bit truncation, then the ``blend`` expression in
+            double, truncated): a restatement of a third-party implementation that is absent here -- parity unpinned, and
+            the yuv420p <-> RGB conversions ffmpeg inserts around the filters are not part of it.
+The LUT is affine per channel below the clamp, so the two interpolations agree up to the 8-bit rounding rule.
 The media plumbing (paths, ffmpeg, thumbnails) is out of scope."""
 from __future__ import annotations
 
@@ -92,11 +96,13 @@ def _opening_color_match_weight(frame_index, fps, strength, fade_seconds) -> flo
 
 
 def _apply_scene_start_color_match_frames(frames, reference_frame, fps, fade_seconds=1.0, strength=0.85, target_frame=None,
-                                          first_frame_index=0):
+                                          first_frame_index=0, filter_arithmetic="nodes"):
     """Frame-level form of the reference routine: `frames` = decoded B,G,R uint8 frames of the new clip starting at
     `first_frame_index`, `reference_frame` = last frame of the previous clip, `target_frame` = first frame of the new
     clip (default: ``frames[0]``).  Returns ``(frames_out, info)`` with the same clamps as the reference
     (fade 0.05..30 s, strength 0..1; strength 0 -> unchanged, ``applied: False``)."""
+    if filter_arithmetic not in ("nodes", "ffmpeg"):
+        raise ValueError("filter_arithmetic must be 'nodes' or 'ffmpeg'")
     fade_seconds = max(0.05, min(30.0, float(fade_seconds or 1.0)))
     strength = max(0.0, min(1.0, float(strength or 0.85)))
     batch = _as_gpu_u8(frames)
@@ -112,13 +118,14 @@ def _apply_scene_start_color_match_frames(frames, reference_frame, fps, fade_sec
             handle.write(text)
         lut_data = cube.parse_cube_file(path)
     dev_lut = ops.upload_lut(lut_data, batch.device)
-    out = batch.clone()
-    weights = []
-    for i in range(batch.shape[0]):
-        w = _opening_color_match_weight(first_frame_index + i, fps, strength, fade_seconds)
-        weights.append(w)
-        if w > 0.0:
-            ops.fused_chain(batch[i:i + 1], ops.ChainSpec(lut=(dev_lut, 10.0 * w)), out=out[i:i + 1])
+    weights = [_opening_color_match_weight(first_frame_index + i, fps, strength, fade_seconds) for i in range(batch.shape[0])]
+    if filter_arithmetic == "ffmpeg":
+        out = ops.lut3d_ffmpeg_u8(batch, dev_lut, weights)        # w = 0 leaves a frame unchanged: A*1 + B*0
+    else:
+        out = batch.clone()
+        for i, w in enumerate(weights):
+            if w > 0.0:
+                ops.fused_chain(batch[i:i + 1], ops.ChainSpec(lut=(dev_lut, 10.0 * w)), out=out[i:i + 1])
     info = {"applied": True, "scales": scales, "offsets": offsets, "weights": weights, "cube_text": text,
             "reference_mean": ref_stats[0], "reference_std": ref_stats[1], "target_mean": tgt_stats[0], "target_std": tgt_stats[1]}
     return [f for f in out.cpu().numpy()], info

@@ -84,6 +84,7 @@ _SIGNATURES = {
     "vrg_u8_channel_sums": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "vrg_u8bgr_to_f32rgb": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_f32rgb_to_u8bgr": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "vrg_lut3d_tetra_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int32, _F3, _F3, _P, _P]),
     "vrg_fused_chain_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_lab_stats_scratch_bytes": (C.c_int64, [C.c_int64]),
     "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),

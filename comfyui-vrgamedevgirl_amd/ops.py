@@ -250,6 +250,7 @@ class DeviceLut:
     size: int                  # N
     domain_min: tuple
     domain_max: tuple
+    nodes: Optional[torch.Tensor] = None   # the parsed [N,N,N,3] table itself on the device (ffmpeg-style lookup only)
 
 
 def upload_lut(lut_data: dict, device) -> DeviceLut:
@@ -270,7 +271,7 @@ def upload_lut(lut_data: dict, device) -> DeviceLut:
     _hip.check(_hip.lib().vrg_lut_prepare_f32(_hip.ptr(raw), n, _hip.ptr(cells), _hip.current_stream()), "vrg_lut_prepare_f32")
     dmin = tuple(float(v) for v in lut_data["domain_min"].to(torch.float32).cpu().tolist())
     dmax = tuple(float(v) for v in lut_data["domain_max"].to(torch.float32).cpu().tolist())
-    return DeviceLut(cells, n, dmin, dmax)
+    return DeviceLut(cells, n, dmin, dmax, raw)
 
 
 def blend_terms(strength: float):
@@ -300,6 +301,30 @@ def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.
     _hip.check(_hip.lib().vrg_lut3d_f32(_hip.ptr(x), _hip.ptr(out), px, x.shape[-1], _hip.ptr(lut.table), lut.size,
                                        _F3(*lut.domain_min), _F3(*lut.domain_max), mode, B, omB, _hip.current_stream()),
                "vrg_lut3d_f32")
+    return out
+
+
+@_on_device
+def lut3d_ffmpeg_u8(frames_bgr: torch.Tensor, lut: DeviceLut, weights=None) -> torch.Tensor:
+    """ffmpeg's ``lut3d`` (tetrahedral) and, with `weights` (one blend weight per frame), its ``blend`` expression
+    ``A*(1-w)+B*w`` on decoded uint8 B,G,R frames: the per-pixel step of the reference's opening colour match as ffmpeg
+    performs it.  Restated from ffmpeg's published sources, parity unpinned (csrc/vrg_lut_tetra.hip)."""
+    x = _check_frames(frames_bgr, "frames", channels=3, dtype=torch.uint8)
+    if lut.nodes is None:
+        raise ValueError("this DeviceLut carries no node table (use ops.upload_lut)")
+    _check_side(lut.nodes, "LUT node table", x)
+    F, H, W, _ = x.shape
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    wt = None
+    if weights is not None:
+        wt = torch.tensor([float(w) for w in weights], dtype=torch.float64, device=x.device)
+        if wt.numel() != F:
+            raise ValueError(f"{wt.numel()} blend weights for {F} frames")
+    _hip.check(_hip.lib().vrg_lut3d_tetra_u8(_hip.ptr(x), _hip.ptr(out), F, H * W, _hip.ptr(lut.nodes), lut.size,
+                                            _F3(*lut.domain_min), _F3(*lut.domain_max), _hip.ptr(wt) if wt is not None else None,
+                                            _hip.current_stream()), "vrg_lut3d_tetra_u8")
     return out
 
 

@@ -254,6 +254,14 @@ int vrg_f32rgb_to_u8bgr(const float* in, uint8_t* out, int64_t pixels, void* str
  * (VRGDG_WorkflowRunnerNodes.py:4385-4392); mean / stddev follow on the host in double exactly as ImageStat does. */
 int vrg_u8_channel_sums(const uint8_t* frames, int64_t frames_n, int32_t height, int32_t width, unsigned long long* sums,
                         void* stream);
+/* The per-pixel step of the opening colour match with ffmpeg's filter arithmetic instead of this library's LUT stage
+ * (reference filter graph lut3d + blend, VRGDG_WorkflowRunnerNodes.py:4407-4412): tetrahedral interpolation of the cube on
+ * 8-bit B,G,R frames, truncation to 8 bits, then `A*(1-w)+B*w` in double per byte with the per-frame weight `weights[f]`
+ * (device pointer, NULL = no blend), truncated.  `table` = the parsed .cube [N][N][N][3] fp32 (index [blue][green][red]) on
+ * the device, `domain_min/max` = host float[3].  Restated from ffmpeg's published sources (libavfilter/vf_lut3d.c,
+ * vf_blend.c); ffmpeg is absent here, so this entry point's parity is unpinned. */
+int vrg_lut3d_tetra_u8(const uint8_t* in, uint8_t* out, int64_t frames, int64_t pixels_per_frame, const float* table,
+                       int32_t lut_size, const float* domain_min, const float* domain_max, const double* weights, void* stream);
 /* grain / LUT / 3x3 sharpen in any combination (no colour match: VRG_ERR_UNSUPPORTED); desc as for vrg_fused_chain_f32 */
 int vrg_fused_chain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width,
                        const vrg_chain_desc* desc, void* stream);

@@ -1283,6 +1283,26 @@ def test_u8_channel_sums_are_exact(pkg, dev):
         assert np.array_equal(sums.cpu().numpy(), want), shape
 
 
+@pytest.mark.parametrize("n,dmin,dmax", [(17, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), (33, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)),
+                                         (2, (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), (9, (0.0, 0.0, 0.0), (2.0, 4.0, 0.5))])
+def test_ffmpeg_style_lut3d_and_blend_equal_their_restatement(ops, dev, n, dmin, dmax):
+    """vrg_lut3d_tetra_u8 vs oracle.restated.ffmpeg_lut3d_blend_u8 (ffmpeg's published lut3d / blend arithmetic restated;
+    ffmpeg itself is absent: parity unpinned): every byte value on every axis, random frames, per-frame weights."""
+    g = torch.Generator().manual_seed(100 + n)
+    data = {"size": n, "lut": torch.rand((n, n, n, 3), generator=g) * 1.2 - 0.1, "domain_min": torch.tensor(dmin), "domain_max": torch.tensor(dmax)}
+    lut = ops.upload_lut(data, dev)
+    ramp = torch.arange(256, dtype=torch.uint8)
+    axes = torch.stack([torch.stack([ramp, ramp.flip(0), ramp * 7], -1), torch.stack([ramp, ramp, ramp], -1),
+                        torch.stack([ramp * 3, ramp, ramp.flip(0)], -1)], 0).reshape(3, 16, 16, 3)
+    frames = torch.cat([axes, torch.randint(0, 256, (3, 16, 16, 3), generator=g, dtype=torch.uint8)], 0).contiguous()
+    for weights in (None, [1.0, 0.85, 0.5, 0.3333333333333333, 0.0, 0.07]):
+        got = ops.lut3d_ffmpeg_u8(frames.to(dev), lut, weights)
+        _frames_eq(got.cpu().numpy(), R.ffmpeg_lut3d_blend_u8(frames.numpy(), data, weights), f"ffmpeg-style lut3d {n}^3 weights={weights}")
+    assert ops.lut3d_ffmpeg_u8(frames[:0].to(dev), lut).shape == (0, 16, 16, 3)
+    with pytest.raises(ValueError):
+        ops.lut3d_ffmpeg_u8(frames.to(dev), lut, [1.0])
+
+
 def test_opening_colour_match_statistics_and_frames(pkg, ops, dev):
     import json
     from comfyui_vrgamedevgirl_amd import VRGDG_WorkflowRunnerNodes as WR
@@ -1314,6 +1334,16 @@ def test_opening_colour_match_statistics_and_frames(pkg, ops, dev):
             assert info["weights"][i] == w
             want = frame if w <= 0.0 else R.tensor_to_frames(R.apply_lut_with_strength(R.frames_to_tensor([frame]), lut, 10.0 * w))[0]
             _frames_eq(out[i], want, f"opening match {name} frame {i}")
+        # the same clip with ffmpeg's filter arithmetic (restated): equal to its oracle, and -- the cube being affine per
+        # channel below the clamp -- within ONE 8-bit step of the node arithmetic (ffmpeg truncates twice, the nodes once)
+        out_ff, info_ff = WR._apply_scene_start_color_match_frames(clip, ref_bgr, fps=4.0, fade_seconds=m["fade_seconds"],
+                                                                   strength=m["strength"], filter_arithmetic="ffmpeg")
+        assert info_ff["weights"] == info["weights"] and info_ff["cube_text"] == info["cube_text"]
+        want_ff = R.ffmpeg_lut3d_blend_u8(np.stack(clip, 0), lut, info["weights"])
+        _frames_eq(np.stack(out_ff, 0), want_ff, f"opening match {name}, ffmpeg arithmetic")
+        step = np.abs(np.stack(out_ff, 0).astype(np.int32) - np.stack(out, 0).astype(np.int32)).max()
+        _record(f"opening_match.{name}.ffmpeg_vs_nodes_max_8bit_steps", int(step))
+        assert step <= 2, step
     # the reference's `float(payload.get("strength", 0.85) or 0.85)`: 0 is falsy -> 0.85; only a negative value clamps to 0
     _, info = WR._apply_scene_start_color_match_frames(clip, ref_bgr, fps=4.0, strength=0.0)
     assert info["applied"] and info["weights"][0] == 0.85

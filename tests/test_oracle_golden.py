@@ -272,3 +272,28 @@ def test_baseline_config_1_oracle_equals_reference_node_on_cpu():
     torch.manual_seed(1)
     got = R.fast_film_grain(x, 0.04, 0.5, 4)
     assert torch.equal(got, want)
+
+
+def test_ffmpeg_style_lut3d_restatement_properties():
+    """oracle.restated.ffmpeg_lut3d_blend_u8 is restated from ffmpeg's published sources with nothing here to pin it to
+    (parity unpinned).  What can be checked without ffmpeg: grid nodes return the node value (truncated to 8 bits), an affine
+    cube interpolates exactly like the trilinear node arithmetic up to the 8-bit rule, weights 0 / 1 select source / result."""
+    n = 17
+    ax = torch.linspace(0, 1, n, dtype=torch.float64)
+    b, g, r = torch.meshgrid(ax, ax, ax, indexing="ij")
+    affine = torch.stack([(0.9 * r + 0.02), (0.5 * g + 0.1), (1.0 * b)], -1).to(torch.float32).clamp(0, 1)
+    data = {"size": n, "lut": affine, "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}
+    gen = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (2, 32, 32, 3), generator=gen, dtype=torch.uint8).numpy()
+    out = R.ffmpeg_lut3d_blend_u8(frames, data)
+    tri = R.tensor_to_frames(R.apply_lut_with_strength(R.frames_to_tensor(list(frames)), data, 10.0))
+    assert np.abs(out.astype(np.int32) - np.stack(tri, 0).astype(np.int32)).max() <= 1
+    # byte 255 * k / 16 is a grid node only for k = 0, 16 at 8 bits: check the two ends and the clamp of an out-of-range table
+    ends = np.array([[[[0, 0, 0], [255, 255, 255]]]], dtype=np.uint8)
+    rnd = {"size": n, "lut": torch.rand((n, n, n, 3), generator=gen) * 1.4 - 0.2, "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}
+    got = R.ffmpeg_lut3d_blend_u8(ends, rnd)
+    for px, node in ((got[0, 0, 0], rnd["lut"][0, 0, 0]), (got[0, 0, 1], rnd["lut"][n - 1, n - 1, n - 1])):
+        want = np.clip((node.numpy() * np.float32(255.0)).astype(np.int32), 0, 255)[::-1]          # B, G, R bytes
+        assert np.array_equal(px, want.astype(np.uint8))
+    assert np.array_equal(R.ffmpeg_lut3d_blend_u8(frames, rnd, [0.0, 0.0]), frames)
+    assert np.array_equal(R.ffmpeg_lut3d_blend_u8(frames, rnd, [1.0, 1.0]), R.ffmpeg_lut3d_blend_u8(frames, rnd))
