@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void k_chain_pointwise(const typename IO::elem
 // tile plus a one-pixel halo is staged in LDS as three planes (conflict-free row reads), then every
 // thread produces 8 output pixels.  Halo recompute: (34*66)/(32*64) = 1.096x.
 // ----------------------------------------------------------------------------------------------
-constexpr int TILE_H = 32, TILE_W = 64;
+#ifndef VRG_TILE_H
+#define VRG_TILE_H 32
+#endif
+constexpr int TILE_H = VRG_TILE_H, TILE_W = 64;
+constexpr int TILE_ROWS = TILE_H / 4;      // rows per thread: 4 row groups of 64 columns in a 256-thread block
 constexpr int HALO_H = TILE_H + 2, HALO_W = TILE_W + 2;
 constexpr int LDS_PITCH = HALO_W + 1;
 
@@ -92,10 +96,10 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
     // streaming stores, conflict-free LDS rows), the 3x3 window slides down in registers (30 LDS reads per channel for
     // 8 pixels instead of 72) and the index arithmetic is paid once per thread.
     typename IO::elem* fout = out + f * ppf;
-    const int lx = threadIdx.x & (TILE_W - 1), ly0 = (threadIdx.x / TILE_W) * 8;
+    const int lx = threadIdx.x & (TILE_W - 1), ly0 = (threadIdx.x / TILE_W) * TILE_ROWS;
     const int x = tx0 + lx;
     if (x >= W) return;
-    float res[8][3];
+    float res[TILE_ROWS][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float p[3][3];
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) p[dy + 1][dx] = tile[c][ly0 + dy][lx + dx];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < TILE_ROWS; ++k) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 p[0][dx] = p[1][dx];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
         }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < TILE_ROWS; ++k) {
         const int y = ty0 + ly0 + k;
         if (y < H) IO::store_stream(fout + (y * W + x), px3{res[k][0], res[k][1], res[k][2]});
     }

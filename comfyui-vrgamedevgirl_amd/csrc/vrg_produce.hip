@@ -20,7 +20,10 @@
 namespace vrg {
 
 constexpr int PR_SUB = 768;      // subsequences per sub-range = 256 pixels per sibling
-constexpr int PR_SUBS = 8;       // sub-ranges per block
+#ifndef VRG_PR_SUBS
+#define VRG_PR_SUBS 8
+#endif
+constexpr int PR_SUBS = VRG_PR_SUBS;       // sub-ranges per block
 constexpr int PR_RUN = PR_SUB * PR_SUBS;
 
 struct ProduceK {
