@@ -6,7 +6,7 @@ TAG=${1:-r02}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out/ev_${TAG}; mkdir -p $O
 {
-  echo "=== $(date) pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4
+  echo "=== $(date) pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E " passed| failed| error" | tail -3
   echo "=== $(date) smoke"; timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v amdgpu.ids
   echo "=== $(date) bench (default = driver's call)"; timeout 900 python bench.py 2>$O/bench.err | tee $O/bench.json | cut -c1-400
   for W in chain3_4k grain_lut_1080p colormatch_4k; do
