@@ -641,11 +641,11 @@ VRG_HD float dev_pow_t(float x, float y) {
     const float a49 = a18 + a44;
     const float a50 = a49 - a18;
     const float a51 = a44 - a50;
+    // ocml forms the rounding error of a12 - a49 as well ((a12 - a52) - a49, two more subtractions and a negated add).  a49 is
+    // a12 * (1 + eps) with |eps| < 2^-21 (v_rcp_f32's ulp plus the roundings of a17, a18, a44, a49), so the difference of the two
+    // is exact (Sterbenz) and that error term is +0 for every input: a56 = a52 + (0 - a51) = a52 - a51, same rounding.
     const float a52 = a12 - a49;
-    const float a53 = a12 - a52;
-    const float a54 = a53 - a49;
-    const float a55 = a54 - a51;
-    const float a56 = a52 + a55;
+    const float a56 = a52 - a51;
     const float a57 = r16 * a56;
     const float a58 = a17 + a57;
     const float a59 = a58 - a17;
@@ -705,12 +705,12 @@ VRG_HD float dev_pow_t(float x, float y) {
     const float a234 = a229 + a233;
     const float a235 = a234 - a229;
     const float a236 = a233 - a235;
+    // (a237, a242) = two-sum(a223, a234).  ocml spends the six-operation form here; a223 is the head of e * ln2 -- zero, or
+    // at least 0.693 in magnitude -- and a234 the head of ln(m), |ln(m)| <= 0.405 for m in [2/3, 4/3): the three-operation
+    // form is error-free under exactly that ordering (or a zero first operand) and returns the same pair.
     const float a237 = a223 + a234;
     const float a238 = a237 - a223;
-    const float a239 = a237 - a238;
-    const float a240 = a223 - a239;
-    const float a241 = a234 - a238;
-    const float a242 = a241 + a240;
+    const float a242 = a234 - a238;
     const float a243 = a225 + a236;
     const float a244 = a243 - a225;
     const float a245 = a243 - a244;
