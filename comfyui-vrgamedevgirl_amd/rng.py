@@ -10,9 +10,14 @@ generator offset by ((numel - 1) // (4 G) + 1) * 4.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass
 
 import torch
+
+#: torch takes the generator's mutex around "read the Philox state, advance the offset" of every randn; the reservations
+#: below do the same read-modify-write from Python (nodes and routes may enter from different host threads)
+_RESERVE_LOCK = threading.Lock()
 
 BLOCK = 256
 UNROLL = 4
@@ -92,15 +97,16 @@ def reserve_split(numel: int, device, generator=None, geom: DeviceGeometry | Non
     iterator needs splitting, and every sub-iterator call takes (and advances by) its own."""
     geom = geom or device_geometry(device)
     gen = _generator_for(device, generator)
-    seed = int(gen.initial_seed())
-    off = int(gen.get_offset())
-    off += counter_offset(numel, grid_threads(numel, geom))          # the outer call's unused reservation
-    leaves = []
-    for start, size in split_32bit(numel):
-        G = grid_threads(size, geom)
-        leaves.append((start, size, G, off))
-        off += counter_offset(size, G)
-    gen.set_offset(off)
+    with _RESERVE_LOCK:
+        seed = int(gen.initial_seed())
+        off = int(gen.get_offset())
+        off += counter_offset(numel, grid_threads(numel, geom))          # the outer call's unused reservation
+        leaves = []
+        for start, size in split_32bit(numel):
+            G = grid_threads(size, geom)
+            leaves.append((start, size, G, off))
+            off += counter_offset(size, G)
+        gen.set_offset(off)
     return SplitStream(seed=seed & 0xFFFFFFFFFFFFFFFF, leaves=leaves, chunk_numel=numel)
 
 
@@ -122,9 +128,10 @@ def reserve(numel: int, n_chunks: int, device, generator=None, geom: DeviceGeome
     gen = _generator_for(device, generator)
     G = grid_threads(numel, geom)
     stride = counter_offset(numel, G)
-    seed = int(gen.initial_seed())
-    off = int(gen.get_offset())
-    gen.set_offset(off + stride * n_chunks)
+    with _RESERVE_LOCK:
+        seed = int(gen.initial_seed())
+        off = int(gen.get_offset())
+        gen.set_offset(off + stride * n_chunks)
     return ChunkedStream(seed=seed & 0xFFFFFFFFFFFFFFFF, offset0=off, offset_stride=stride, seed_stride=0,
                          grid_threads=G, chunk_numel=numel)
 
