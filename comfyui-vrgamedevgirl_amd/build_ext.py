@@ -22,7 +22,8 @@ STAMP = LIB_PATH + ".stamp"
 
 SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_adjust.hip",
            "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_api.hip")
-HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc")
+HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
+           "vrg_ziv_log_table.inc")
 
 # -ffp-contract=off : the reference performs one rounding per op; FMAs are written explicitly where
 #                     torch's own device code has them (Box-Muller).

@@ -179,9 +179,36 @@ __global__ __launch_bounds__(1024) void k_dbg_lut_passes(const px3* __restrict__
 __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ in, float* __restrict__ out, int64_t n, int op, float y,
                                                       DevMath dm) {
     VRG_CM_MATH(PT, true, true, dm);
+    __shared__ __attribute__((aligned(16))) float zivt[ZIV_TABLE_WORDS];
+    ziv_table_fill(zivt, (int)threadIdx.x, 256);
+    __syncthreads();
+    dm.logt = zivt;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (op >= 9) {
+    if (op >= 16) {          // 16 / 17: ocml's ln x = hi + lo (epln, as transcribed); 18 / 19: dev_pow_ziv's table log
+        float a, b;
+        float eh;
+        if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh);
+        out[i] = (op & 1) ? b : a;
+    } else if (op >= 12) {
+        // the Lab transforms' powers as they are called there (dev_pow_ziv with each call site's domain): op 12 sRGB -> linear
+        // (y = 2.4), 13 linear -> sRGB (1/2.4), 14 Lab cube root (1/3); 15: 1.0 where the Ziv test sends op 13's lane to the
+        // transcription, else 0.0 (statistics of the fallback rate)
+        const float x = in[i];
+        if (op == 12) out[i] = dev_pow_ziv<DEV_POW_OVF>(x, y, zivt, 0x3d800000u, 0x40000000u);
+        else if (op == 13) out[i] = dev_pow_ziv<DEV_POW_UNIT>(x, y, zivt, 0x3b4d2e1cu, 0x40800000u);
+        else if (op == 14) out[i] = dev_pow_ziv<DEV_POW_UNIT>(x, y, zivt, 0x3c1118c2u, 0x40800000u);
+        else {
+            float Lh, Ll, Eh;
+            ziv_log(x, zivt, Lh, Ll, Eh);
+            const float p17 = y * Lh, p24 = __builtin_fmaf(y, Lh, -p17), p44 = __builtin_fmaf(y, Ll, p24);
+            const float delta = ziv_delta(y, Lh, Eh);
+            const float php = p17 + (p44 + delta), phm = p17 + (p44 - delta);
+            const float pl = p44 - (php - p17);
+            const float e8 = dev_exp_core(php);
+            out[i] = (php == phm && __builtin_fmaf(e8, pl + delta, e8) == __builtin_fmaf(e8, pl - delta, e8)) ? 0.0f : 1.0f;
+        }
+    } else if (op >= 9) {
         out[i] = op == 9 ? dev_pow_t<DEV_POW_ANY>(in[i], y) : (op == 10 ? dev_pow_t<DEV_POW_OVF>(in[i], y) : dev_pow_t<DEV_POW_UNIT>(in[i], y));
     } else if (op <= 4) {
         const float x = in[i];
@@ -285,7 +312,7 @@ int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode,
 }
 
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream) {
-    if (!in || !out || n <= 0 || op < 0 || op > 11) return VRG_ERR_BAD_ARG;
+    if (!in || !out || n <= 0 || op < 0 || op > 19) return VRG_ERR_BAD_ARG;
     const uint64_t blocks = (uint64_t)(n + 255) / 256;
     if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vrg::k_dbg_cm_math, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n, op, y, vrg::host_dev_math());

@@ -109,12 +109,16 @@ struct ChainK {
 // (PowTables) instead of the default device policy (DevMath).  Never part of vrg_chain_desc::stages; set from cm_math.
 constexpr int VRG_STAGE_FASTMATH = 32;
 
-inline DevMath host_dev_math() { return DevMath{(float)2.4, (float)(1.0 / 2.4), (float)(1.0 / 3.0)}; }
+inline DevMath host_dev_math() { return DevMath{(float)2.4, (float)(1.0 / 2.4), (float)(1.0 / 3.0), nullptr}; }
 
 template <bool FAST> struct CmMathSel { typedef DevMath type; };
 template <> struct CmMathSel<true> { typedef PowTables type; };
 __device__ __forceinline__ PowTables cm_make_math(const float* lds, const DevMath&, const PowTables*) { return PowTables{lds, lds + 512}; }
-__device__ __forceinline__ DevMath cm_make_math(const float*, const DevMath& dm, const DevMath*) { return dm; }
+__device__ __forceinline__ DevMath cm_make_math(const float* lds, const DevMath& dm, const DevMath*) {
+    DevMath m = dm;
+    m.logt = lds;            // dev_pow_ziv's log table, staged by VRG_CM_MATH
+    return m;
+}
 
 inline NoiseK make_noise(const vrg_noise_desc* d, int64_t frame_elems) {
     NoiseK n;
@@ -139,12 +143,13 @@ inline LutParams make_lut(const float* cells, int n, const float dmin[3], const 
 }
 
 // The colour-match arithmetic object of a kernel: NEED = does the kernel evaluate Lab at all, FAST = policy.  The fast
-// policy stages its pow tables in LDS (2.5 KB); the device policy only carries the three exponents.  Every thread of the
+// policy stages its pow tables in LDS (2.5 KB), the device policy the log table of dev_pow_ziv (2 KB).  Every thread of the
 // block must execute it (barrier).
 #define VRG_CM_MATH(PT, NEED, FAST, DM)                                                                       \
-    __shared__ __attribute__((aligned(16))) float vrg_pow_lds_[((NEED) && (FAST)) ? ::vrg::POW_TABLE_WORDS : 4]; \
-    if ((NEED) && (FAST)) {                                                                                    \
-        ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);                              \
+    __shared__ __attribute__((aligned(16))) float vrg_pow_lds_[(NEED) ? ((FAST) ? ::vrg::POW_TABLE_WORDS : ::vrg::ZIV_TABLE_WORDS) : 4]; \
+    if (NEED) {                                                                                                \
+        if (FAST) ::vrg::pow_tables_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);                    \
+        else ::vrg::ziv_table_fill(vrg_pow_lds_, (int)threadIdx.x, (int)blockDim.x);                          \
         __syncthreads();                                                                                       \
     }                                                                                                          \
     typedef typename ::vrg::CmMathSel<(FAST)>::type PT##_t;                                                    \

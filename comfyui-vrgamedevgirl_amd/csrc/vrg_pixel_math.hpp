@@ -560,6 +560,7 @@ VRG_HD float pow_pos(float x, float y, const PowTables& T) {
 // ------------------------------------------------------------------------------------------
 struct DevMath {
     float e24, e1_24, e1_3;     // 2.4f, (float)(1/2.4), (float)(1/3.0): kernel arguments, not literals
+    const float* logt;          // dev_pow_ziv's log table in LDS ([128][4], filled by the kernel), or nullptr: transcription only
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -608,9 +609,9 @@ VRG_HD float dev_exp_core(float x) {
     return __builtin_ldexpf(VRG_HW_EXP2(a), (int)e);
 }
 
+// ocml's epln: ln(x) = ln_hi + ln_lo
 template <int GUARD>
-VRG_HD float dev_pow_t(float x, float y) {
-    // ---- epln: ln(x) = hi + lo
+VRG_HD void dev_epln(float x, float& ln_hi_out, float& ln_lo_out) {
     // x = m * 2^e with m in [2/3, 4/3)
     float m;
     int e;
@@ -724,7 +725,14 @@ VRG_HD float dev_pow_t(float x, float y) {
     const float a253 = a248 + a252;
     const float ln_hi = a250 + a253;
     const float a255 = ln_hi - a250;
-    const float ln_lo = a253 - a255;
+    ln_hi_out = ln_hi;
+    ln_lo_out = a253 - a255;
+}
+
+template <int GUARD>
+VRG_HD float dev_pow_t(float x, float y) {
+    float ln_hi, ln_lo;
+    dev_epln<GUARD>(x, ln_hi, ln_lo);
     // ---- y * ln(x) = ph + pl
     const float p17 = y * ln_hi;
     const float p24 = __builtin_fmaf(y, ln_hi, -p17);
@@ -758,6 +766,102 @@ VRG_HD float dev_pow_t(float x, float y) {
 }
 VRG_HD float dev_pow(float x, float y) { return dev_pow_t<DEV_POW_ANY>(x, y); }
 
+// ------------------------------------------------------------------------------------------
+// dev_pow_ziv: the SAME value as dev_pow_t -- ocml's powf -- through a cheaper route wherever that route provably cannot
+// differ, and through the transcription itself everywhere else (a Ziv-style rounding test, per lane).
+//
+// ocml's result is  RN(e8 * (1 + pl))  with  e8 = exp(ph),  (ph, pl) = the double-word y * ln x:  it depends on the double-word
+// logarithm only through (a) the fp32 head ph = RN(y ln x) and (b) the last rounding; everything ocml spends on carrying ln x to
+// ~2^-45 matters only for the rare arguments where one of those two roundings sits within the logarithm's error of a tie.
+// So: ln x from a 128-entry table (tools/make_ziv_log_table.py: ln x = e ln2 + T_j + log1p(r), r = m c_j - 1 EXACT in one FMA,
+// r^2 kept as a double word, the r^3.. tail in fp32; |error| <= 2^-37.2 |ln x| and <= 2^-39 absolute on the domains below, measured
+// over every fp32 argument against a float64 log by tools/ziv_log_accuracy.py -- ocml's own epln: 2^-34.7 / 2^-36), then ocml's own
+// y * ln x product, backend exp and final FMA, with the two roundings evaluated at BOTH ends of the interval
+// [y ln x - delta, y ln x + delta], delta = the measured maximum distance between ocml's logarithm and this one (ziv_delta):
+// if the heads agree and the results agree, ocml's head and result lie between equal numbers.  Otherwise -- 0.1-0.3 % of the
+// lanes -- and for arguments outside [lo, hi] (the ranges the tests sweep exhaustively, per exponent), the lane runs
+// dev_pow_t.  tests/test_gpu_parity.py compares this function with torch.pow for EVERY fp32 base of [lo, hi] for each of the
+// three exponents, so inside the fast path's domain equality is established by enumeration, outside it by construction.
+// ------------------------------------------------------------------------------------------
+#include "vrg_ziv_log_table.inc"
+
+constexpr int ZIV_TABLE_WORDS = 128 * 4;
+
+VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
+    for (int i = first; i < ZIV_TABLE_WORDS; i += stride) dst[i] = f32_from_bits(VRG_ZIV_LOGT[i >> 2][i & 3]);
+}
+
+// (Lh, Ll) = ln x for a normal positive x; T = the table in LDS
+VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out) {
+    const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
+    const float ef = (float)(d >> 23);
+    const uint32_t off = (uint32_t)d & 0x007fffffu;
+    const float m = f32_from_bits(off + 0x3f2aaaabu);                // [2/3, 4/3)
+    const float* t = T + ((off >> 16) << 2);
+    const float c = t[0], th = t[1], tl = t[2];
+    const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (7-bit c)
+    const float Eh = ef * f32_from_bits(0x3f317200u);                // e * ln2 head (15 bits: exact product)
+    const float h = r * r;
+    const float l = __builtin_fmaf(r, r, -h);                        // r^2 = h + l
+    const float nh = -0.5f * h;
+    float P = __builtin_fmaf(r, (float)(-1.0 / 6.0), 0.2f);
+    P = __builtin_fmaf(r, P, -0.25f);
+    P = __builtin_fmaf(r, P, (float)(1.0 / 3.0));
+    const float tail = __builtin_fmaf(-0.5f, l, (h * r) * P);        // -l/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
+    const float s1 = Eh + th;                                        // |Eh| >= 0.69 > |th|, or Eh = 0: fast two-sum
+    const float e1 = th - (s1 - Eh);
+    const float s2 = r + nh;                                         // |r| >= |r^2 / 2|
+    const float e2 = nh - (s2 - r);
+    const float s3 = s1 + s2;                                        // no ordering: two-sum
+    const float bb = s3 - s1;
+    const float e3 = (s1 - (s3 - bb)) + (s2 - bb);
+    float low = __builtin_fmaf(ef, f32_from_bits(0x35bfbe8eu), tl);  // e * (ln2 - head) + T_lo
+    low = low + e1;
+    low = low + e3;
+    low = low + e2;
+    low = low + tail;
+    Lh = s3 + low;
+    Ll = low - (Lh - s3);
+    Eh_out = Eh;
+}
+
+// Half-width of the interval that contains ocml's y ln x around this function's: y * |ln x (ocml) - ln x (table)|.  The two
+// logarithms are deterministic functions of x, so their distance has an exact maximum over a finite domain; measured over
+// EVERY fp32 of [0.0031308, 4] (tools/ziv_log_accuracy.py, profiles/): 2^-34.73 max(|e ln2|, |ln x|) and 2^-36.00 absolute --
+// almost all of it ocml's own error (its epln is good to 2^-34.7, the table log to 2^-37.3).  The bounds below are those
+// maxima times 1.25 (the +-delta additions and ocml's own last roundings are five orders of magnitude smaller).
+VRG_HD float ziv_delta(float y, float Lh, float Eh) {
+    const float a = __builtin_fabsf(Lh), b = __builtin_fabsf(Eh);
+    const float rel = (a > b ? a : b) * (y * f32_from_bits(0x2e420300u));          // 2^-34.4
+    const float ab = y * f32_from_bits(0x2d9d9624u);                                // 2^-35.7
+    return rel < ab ? rel : ab;
+}
+
+template <int GUARD>
+VRG_HD float dev_pow_ziv(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (T) {
+        float Lh, Ll, Eh;
+        ziv_log(x, T, Lh, Ll, Eh);
+        const float p17 = y * Lh;
+        const float p24 = __builtin_fmaf(y, Lh, -p17);
+        const float p44 = __builtin_fmaf(y, Ll, p24);
+        const float delta = ziv_delta(y, Lh, Eh);
+        const float php = p17 + (p44 + delta);
+        const float phm = p17 + (p44 - delta);
+        const float pl = p44 - (php - p17);
+        const float e8 = dev_exp_core(php);
+        const float rp = __builtin_fmaf(e8, pl + delta, e8);
+        const float rm = __builtin_fmaf(e8, pl - delta, e8);
+        const bool safe = ((f32_bits(x) - lo_bits) <= (hi_bits - lo_bits)) && (php == phm) && (rp == rm);
+        if (safe) return rp;
+    }
+#else
+    (void)T; (void)lo_bits; (void)hi_bits;
+#endif
+    return dev_pow_t<GUARD>(x, y);
+}
+
 // x / c for a Python-scalar c (written as a double literal): fast = the IEEE quotient by (float)c; device = x * (float)(1.0 / c)
 VRG_HD float cm_div_scalar(float x, float c, float rc, float, const PowTables&) { return div_const(x, c, rc); }
 VRG_HD float cm_div_scalar(float x, float, float, float rc_dev, const DevMath&) { return x * rc_dev; }
@@ -780,7 +884,7 @@ VRG_HD float srgb_to_linear(float v, const DevMath& M) {
     const float q = VRG_CM_DIVS(t, 1.055, M);
     // (the reference evaluates pow on every element and selects afterwards: for v <= 0.04045 the value is discarded, so the
     //  base only has to stay in dev_pow's domain there)
-    const float hi = dev_pow_t<DEV_POW_OVF>(clamp_min(q, 0.0625f), M.e24);
+    const float hi = dev_pow_ziv<DEV_POW_OVF>(clamp_min(q, 0.0625f), M.e24, M.logt, 0x3d800000u, 0x40000000u);        // fast path on [0.0625, 2]
     const float lo = VRG_CM_DIVS(v, 12.92, M);
     return v > 0.04045f ? hi : lo;
 }
@@ -796,7 +900,7 @@ VRG_HD float linear_to_srgb(float v, const PowTables& T) {
 VRG_HD float linear_to_srgb(float v, const DevMath& M) {
     const float thr = 0.0031308f;
     const float base = clamp_min(v, thr);
-    const float pw = dev_pow_t<DEV_POW_UNIT>(base, M.e1_24);
+    const float pw = dev_pow_ziv<DEV_POW_UNIT>(base, M.e1_24, M.logt, 0x3b4d2e1cu, 0x40800000u);                      // [0.0031308, 4]
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
     return v > thr ? hi : lo;
@@ -824,7 +928,7 @@ VRG_HD float cbrt_pow(float x) {
 }
 
 VRG_HD float lab_cbrt(float t, const PowTables&) { return cbrt_pow(t); }
-VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow_t<DEV_POW_UNIT>(t, M.e1_3); }
+VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow_ziv<DEV_POW_UNIT>(t, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u); }   // [0.008856, 4]
 
 template <class MATH>
 VRG_HD float lab_f(float t, const MATH& T) {

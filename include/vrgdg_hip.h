@@ -293,7 +293,10 @@ int vrg_selftest_lanes(float* out128, void* stream);
  * 5 / 6 rgb->Lab / Lab->rgb with the device policy; 7 / 8 the same with the fast policy; 9 / 10 / 11 dev_pow(x, y), the
  * transcription of ocml powf without its special-case scaffolding that the device policy evaluates: 9 any x > 0 and finite y,
  * 10 the flavour of sRGB -> linear (x >= 2^-20, 0 < y <= 4), 11 the flavour of linear -> sRGB and the Lab cube root
- * (x >= 2^-20, 0 < y <= 0.5). */
+ * (x >= 2^-20, 0 < y <= 0.5); 12 / 13 / 14 dev_pow_ziv(x, y) as sRGB -> linear / linear -> sRGB / the Lab cube root call it
+ * (table logarithm + rounding test, the transcription where the test fails or x is outside the call site's domain);
+ * 15: 1.0 where op 13's rounding test fails, else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
+ * 18 / 19 dev_pow_ziv's table ln x, head / tail. */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;

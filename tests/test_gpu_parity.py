@@ -10,6 +10,7 @@ therefore torch.randn itself on this GPU -- our in-register Philox/Box-Muller mu
 and leave the generator exactly where torch would have left it.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -503,6 +504,38 @@ def test_device_math_pow_is_torch_pow_for_every_input_of_the_domain(pkg, dev, y,
     g = torch.Generator(device=dev).manual_seed(9)
     wide = torch.exp(torch.rand(1 << 22, generator=g, device=dev) * 160.0 - 80.0)          # 1e-35 .. 1e35
     assert torch.equal(_dbg(pkg, wide, 9, y), torch.pow(wide, y))
+
+
+@pytest.mark.parametrize("op,y,lo,hi", [(12, 2.4, 0.0625, 2.0), (13, 1 / 2.4, 0.0031308, 4.0), (14, 1 / 3.0, 0.008856, 4.0)])
+def test_ziv_tested_power_is_torch_pow_for_every_input_of_its_domain(pkg, dev, op, y, lo, hi):
+    """dev_pow_ziv as the Lab transforms call it (table log + ocml's own product / exp / final FMA, with a rounding test that sends
+    a lane to the transcription of ocml powf whenever the cheaper logarithm could change a rounding): equal to torch.pow on the
+    device for EVERY fp32 base of the call site's fast-path domain -- equality by enumeration there -- and, outside it, on every
+    7th fp32 from 2^-20 to FLT_MAX and the specials, where every lane takes the transcription."""
+    yf = float(np.float32(y))
+    x = _all_floats(lo, hi, dev)
+    assert torch.equal(_dbg(pkg, x, op, y), torch.pow(x, yf)), "dev_pow_ziv vs torch.pow inside the fast-path domain"
+    slow = float(_dbg(pkg, x, 15, y).mean())
+    _record(f"ziv.fallback_fraction_op{op}", slow)
+    assert slow < 0.004, slow            # measured 0.05-0.15 %: the test is the cheap path, not the exception
+    bits = torch.arange(int(np.float32(2.0 ** -20).view(np.uint32)), 0x7f800000 + 1, 7, dtype=torch.int64, device=dev).to(torch.int32)
+    # (the callers clamp the base from below, and the flavours behind the test take x >= 2^-20, +Inf or NaN)
+    span = torch.cat([bits.view(torch.float32), torch.tensor([float("inf"), float("nan"), 3.4028235e38, lo, hi], device=dev)])
+    a, b = _dbg(pkg, span, op, y), torch.pow(span, yf)
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
+def test_ziv_interval_covers_the_distance_between_the_two_logarithms(pkg, dev):
+    """ziv_delta()'s two constants are the exhaustively measured maxima of |ln x (ocml's epln) - ln x (table)| times 1.25:
+    re-measure them over every fp32 of [0.0031308, 4] and hold the margin."""
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    import importlib
+    acc = importlib.import_module("ziv_log_accuracy").measure(0.0031308, 4.0, dev)
+    for k in ("ocml_rel", "table_rel", "distance_rel_to_max_eln2_lnx", "distance_abs"):
+        _record("ziv.log_" + k, acc[k])
+    assert acc["distance_rel_to_max_eln2_lnx"] * 1.2 <= 2.0 ** -34.4, acc
+    assert acc["distance_abs"] * 1.2 <= 2.0 ** -35.7, acc
+    assert acc["table_rel"] < acc["ocml_rel"]                   # the table log is the more accurate of the two
 
 
 def test_device_math_divisions_are_torch_divisions(pkg, dev):
