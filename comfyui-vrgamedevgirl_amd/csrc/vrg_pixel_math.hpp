@@ -837,29 +837,59 @@ VRG_HD float ziv_delta(float y, float Lh, float Eh) {
     return rel < ab ? rel : ab;
 }
 
+// The fast route alone: returns the candidate and whether the rounding test (and the domain test) passed.
+VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float& out) {
+    float Lh, Ll, Eh;
+    ziv_log(x, T, Lh, Ll, Eh);
+    const float p17 = y * Lh;
+    const float p24 = __builtin_fmaf(y, Lh, -p17);
+    const float p44 = __builtin_fmaf(y, Ll, p24);
+    const float delta = ziv_delta(y, Lh, Eh);
+    const float php = p17 + (p44 + delta);
+    const float phm = p17 + (p44 - delta);
+    const float pl = p44 - (php - p17);
+    const float e8 = dev_exp_core(php);
+    const float rp = __builtin_fmaf(e8, pl + delta, e8);
+    const float rm = __builtin_fmaf(e8, pl - delta, e8);
+    out = rp;
+    return ((f32_bits(x) - lo_bits) <= (hi_bits - lo_bits)) & (php == phm) & (rp == rm);      // bitwise: no control flow here
+}
+
 template <int GUARD>
 VRG_HD float dev_pow_ziv(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (T) {
-        float Lh, Ll, Eh;
-        ziv_log(x, T, Lh, Ll, Eh);
-        const float p17 = y * Lh;
-        const float p24 = __builtin_fmaf(y, Lh, -p17);
-        const float p44 = __builtin_fmaf(y, Ll, p24);
-        const float delta = ziv_delta(y, Lh, Eh);
-        const float php = p17 + (p44 + delta);
-        const float phm = p17 + (p44 - delta);
-        const float pl = p44 - (php - p17);
-        const float e8 = dev_exp_core(php);
-        const float rp = __builtin_fmaf(e8, pl + delta, e8);
-        const float rm = __builtin_fmaf(e8, pl - delta, e8);
-        const bool safe = ((f32_bits(x) - lo_bits) <= (hi_bits - lo_bits)) && (php == phm) && (rp == rm);
-        if (safe) return rp;
+        float r;
+        if (ziv_try(x, y, T, lo_bits, hi_bits, r)) return r;
     }
 #else
     (void)T; (void)lo_bits; (void)hi_bits;
 #endif
     return dev_pow_t<GUARD>(x, y);
+}
+
+// Three powers with one exponent (the three channels of a Lab transform): the three fast routes first, as straight-line code --
+// three independent chains for the scheduler to interleave, the three table reads in flight together -- then the (rare)
+// transcription per channel.  Same values as three dev_pow_ziv calls.
+template <int GUARD>
+VRG_HD void dev_pow_ziv3(const float x[3], float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float o[3]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (T) {
+        float r0, r1, r2;
+        const bool s0 = ziv_try(x[0], y, T, lo_bits, hi_bits, r0);
+        const bool s1 = ziv_try(x[1], y, T, lo_bits, hi_bits, r1);
+        const bool s2 = ziv_try(x[2], y, T, lo_bits, hi_bits, r2);
+        o[0] = r0; o[1] = r1; o[2] = r2;
+        if (!s0) o[0] = dev_pow_t<GUARD>(x[0], y);
+        if (!s1) o[1] = dev_pow_t<GUARD>(x[1], y);
+        if (!s2) o[2] = dev_pow_t<GUARD>(x[2], y);
+        return;
+    }
+#else
+    (void)T; (void)lo_bits; (void)hi_bits;
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = dev_pow_t<GUARD>(x[c], y);
 }
 
 // x / c for a Python-scalar c (written as a double literal): fast = the IEEE quotient by (float)c; device = x * (float)(1.0 / c)
@@ -887,6 +917,20 @@ VRG_HD float srgb_to_linear(float v, const DevMath& M) {
     const float hi = dev_pow_ziv<DEV_POW_OVF>(clamp_min(q, 0.0625f), M.e24, M.logt, 0x3d800000u, 0x40000000u);        // fast path on [0.0625, 2]
     const float lo = VRG_CM_DIVS(v, 12.92, M);
     return v > 0.04045f ? hi : lo;
+}
+
+// the three channels at once (same values as three calls; the device policy phases its powers, see dev_pow_ziv3)
+VRG_HD void srgb_to_linear3(const float v[3], float o[3], const PowTables& T) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = srgb_to_linear(v[c], T);
+}
+VRG_HD void srgb_to_linear3(const float v[3], float o[3], const DevMath& M) {
+    float q[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = clamp_min(VRG_CM_DIVS(v[c] + 0.055f, 1.055, M), 0.0625f);
+    dev_pow_ziv3<DEV_POW_OVF>(q, M.e24, M.logt, 0x3d800000u, 0x40000000u, hi);                                        // fast path on [0.0625, 2]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = v[c] > 0.04045f ? hi[c] : VRG_CM_DIVS(v[c], 12.92, M);
 }
 
 VRG_HD float linear_to_srgb(float v, const PowTables& T) {
@@ -927,6 +971,20 @@ VRG_HD float cbrt_pow(float x) {
     return __builtin_fmaf(t0, d, t0);
 }
 
+VRG_HD void linear_to_srgb3(const float v[3], float o[3], const PowTables& T) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = linear_to_srgb(v[c], T);
+}
+VRG_HD void linear_to_srgb3(const float v[3], float o[3], const DevMath& M) {
+    const float thr = 0.0031308f;
+    float base[3], pw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) base[c] = clamp_min(v[c], thr);
+    dev_pow_ziv3<DEV_POW_UNIT>(base, M.e1_24, M.logt, 0x3b4d2e1cu, 0x40800000u, pw);                                  // [0.0031308, 4]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = v[c] > thr ? 1.055f * pw[c] - 0.055f : 12.92f * v[c];
+}
+
 VRG_HD float lab_cbrt(float t, const PowTables&) { return cbrt_pow(t); }
 VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow_ziv<DEV_POW_UNIT>(t, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u); }   // [0.008856, 4]
 
@@ -936,6 +994,20 @@ VRG_HD float lab_f(float t, const MATH& T) {
     const float pw = lab_cbrt(clamp_min(t, thr), T);
     const float sc = 7.787f * t + (float)(4.0 / 29.0);
     return t > thr ? pw : sc;
+}
+
+VRG_HD void lab_f3(const float t[3], float o[3], const PowTables& T) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = lab_f(t[c], T);
+}
+VRG_HD void lab_f3(const float t[3], float o[3], const DevMath& M) {
+    const float thr = 0.008856f;
+    float base[3], pw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) base[c] = clamp_min(t[c], thr);
+    dev_pow_ziv3<DEV_POW_UNIT>(base, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u, pw);                                   // [0.008856, 4]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = t[c] > thr ? pw[c] : 7.787f * t[c] + (float)(4.0 / 29.0);
 }
 
 VRG_HD float dot3(float a, float x, float b, float y, float c, float z) {
@@ -948,13 +1020,16 @@ VRG_HD float dot3(float a, float x, float b, float y, float c, float z) {
 
 template <class MATH>
 VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const MATH& T) {
-    const float r = srgb_to_linear(rgb[0], T);
-    const float g = srgb_to_linear(rgb[1], T);
-    const float b = srgb_to_linear(rgb[2], T);
+    float lin[3];
+    srgb_to_linear3(rgb, lin, T);
+    const float r = lin[0], g = lin[1], b = lin[2];
     const float X = VRG_CM_DIVT(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f, T);
     const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b);   // / 1.0
     const float Z = VRG_CM_DIVT(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f, T);
-    const float fx = lab_f(X, T), fy = lab_f(Y, T), fz = lab_f(Z, T);
+    const float xyz[3] = {X, Y, Z};
+    float f[3];
+    lab_f3(xyz, f, T);
+    const float fx = f[0], fy = f[1], fz = f[2];
     lab[0] = 116.0f * fy - 16.0f;
     const float dxy = fx - fy;
     const float dyz = fy - fz;
@@ -985,9 +1060,12 @@ VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const MATH& T) {
     const float lr = dot3((float)3.2404813432005266, X, (float)-1.5371515162713185, Y, (float)-0.4985363261688878, Z);
     const float lg = dot3((float)-0.9692549499965682, X, (float)1.8759900014898907, Y, (float)0.0415559265582928, Z);
     const float lb = dot3((float)0.0556466391351772, X, (float)-0.2040413383665112, Y, (float)1.0573110696453443, Z);
-    rgb[0] = clamp01(linear_to_srgb(lr, T));
-    rgb[1] = clamp01(linear_to_srgb(lg, T));
-    rgb[2] = clamp01(linear_to_srgb(lb, T));
+    const float lin[3] = {lr, lg, lb};
+    float s3[3];
+    linear_to_srgb3(lin, s3, T);
+    rgb[0] = clamp01(s3[0]);
+    rgb[1] = clamp01(s3[1]);
+    rgb[2] = clamp01(s3[2]);
 }
 
 // matched = (lab-mu)/sigma*sigma_ref + mu_ref ; blended = K*matched + T*lab (nodes.py:112-113)
