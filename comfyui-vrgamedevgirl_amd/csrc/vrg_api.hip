@@ -192,21 +192,15 @@ __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ i
         out[i] = (op & 1) ? b : a;
     } else if (op >= 12) {
         // the Lab transforms' powers as they are called there (dev_pow_ziv with each call site's domain): op 12 sRGB -> linear
-        // (y = 2.4), 13 linear -> sRGB (1/2.4), 14 Lab cube root (1/3); 15: 1.0 where the Ziv test sends op 13's lane to the
-        // transcription, else 0.0 (statistics of the fallback rate)
+        // (y = 2.4), 13 linear -> sRGB (1/2.4), 14 Lab cube root (1/3); 15: 1.0 where the rounding test fails (the lane would run
+        // the transcription), else 0.0 (statistics of the fallback rate)
         const float x = in[i];
         if (op == 12) out[i] = dev_pow_ziv<DEV_POW_OVF>(x, y, zivt, 0x3d800000u, 0x40000000u);
         else if (op == 13) out[i] = dev_pow_ziv<DEV_POW_UNIT>(x, y, zivt, 0x3b4d2e1cu, 0x40800000u);
         else if (op == 14) out[i] = dev_pow_ziv<DEV_POW_UNIT>(x, y, zivt, 0x3c1118c2u, 0x40800000u);
         else {
-            float Lh, Ll, Eh;
-            ziv_log(x, zivt, Lh, Ll, Eh);
-            const float p17 = y * Lh, p24 = __builtin_fmaf(y, Lh, -p17), p44 = __builtin_fmaf(y, Ll, p24);
-            const float delta = ziv_delta(y, Lh, Eh);
-            const float php = p17 + (p44 + delta), phm = p17 + (p44 - delta);
-            const float pl = p44 - (php - p17);
-            const float e8 = dev_exp_core(php);
-            out[i] = (php == phm && __builtin_fmaf(e8, pl + delta, e8) == __builtin_fmaf(e8, pl - delta, e8)) ? 0.0f : 1.0f;
+            float r;
+            out[i] = ziv_try(x, y, zivt, 0x00800000u, 0x7f7fffffu, r) ? 0.0f : 1.0f;       // any normal positive x: the rounding test alone
         }
     } else if (op >= 9) {
         out[i] = op == 9 ? dev_pow_t<DEV_POW_ANY>(in[i], y) : (op == 10 ? dev_pow_t<DEV_POW_OVF>(in[i], y) : dev_pow_t<DEV_POW_UNIT>(in[i], y));

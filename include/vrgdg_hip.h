@@ -295,7 +295,7 @@ int vrg_selftest_lanes(float* out128, void* stream);
  * 10 the flavour of sRGB -> linear (x >= 2^-20, 0 < y <= 4), 11 the flavour of linear -> sRGB and the Lab cube root
  * (x >= 2^-20, 0 < y <= 0.5); 12 / 13 / 14 dev_pow_ziv(x, y) as sRGB -> linear / linear -> sRGB / the Lab cube root call it
  * (table logarithm + rounding test, the transcription where the test fails or x is outside the call site's domain);
- * 15: 1.0 where op 13's rounding test fails, else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
+ * 15: 1.0 where the rounding test of dev_pow_ziv fails for (x, y), else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
  * 18 / 19 dev_pow_ziv's table ln x, head / tail. */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
