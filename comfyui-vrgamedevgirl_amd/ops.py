@@ -25,7 +25,7 @@ _F3 = C.c_float * 3
 
 #: Arithmetic policy of the Lab transforms / statistics transfer (include/vrgdg_hip.h, enum vrg_cm_math).
 #: "device" (default): each element-wise op is the one torch-ROCm runs for it on this GPU (bit-equal to the reference's
-#: colour match executed on the MI355X, given the same statistics); "fast": table-driven powers, a few ulp away, ~2.3x faster.
+#: colour match executed on the MI355X, given the same statistics); "fast": table-driven powers, a few ulp away, 1.2-1.4x faster.
 CM_MATH = {"device": _hip.CM_MATH_DEVICE, "fast": _hip.CM_MATH_FAST}
 
 

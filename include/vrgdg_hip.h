@@ -127,7 +127,8 @@ int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, int32_t heig
  *       scalar` = x * fl(1/c), torch.pow = ocml powf, tensor / tensor = IEEE quotient.  Bit-equal to the restated kornia
  *       formulas evaluated by torch on the device (tests/test_gpu_parity.py), given the same statistics.
  *   VRG_CM_MATH_FAST: IEEE quotients (torch-CPU behaviour) and table-driven powers with <= 0.534 ulp error instead of
- *       ocml powf (~190 instructions): a few ulp from either reference, about 2.3x faster. */
+ *       ocml powf: a few ulp from either reference, 1.2-1.4x faster than the device policy (which reaches ocml's value through
+ *       a cheaper logarithm plus a rounding test, and through ocml's own operation sequence where the test fails). */
 enum vrg_cm_math { VRG_CM_MATH_DEVICE = 0, VRG_CM_MATH_FAST = 1 };
 
 /* ---------------------------------------------------------------------------------------------
