@@ -17,7 +17,7 @@ STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
 ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NoiseDesc(C.Structure):
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
     "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
     "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "vrg_lab_stats_scratch_bytes": (C.c_int64, [C.c_int64]),
     "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "vrg_lab_stats_torch_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P]),
     "vrg_stats_allreduce_scratch_bytes": (C.c_int64, [C.c_int64]),
     "vrg_stats_allreduce": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "vrg_colormatch_apply_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float,

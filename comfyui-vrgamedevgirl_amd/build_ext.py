@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
 STAMP = LIB_PATH + ".stamp"
 
 SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_adjust.hip",
-           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_api.hip")
+           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip")
 HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
            "vrg_ziv_log_table.inc")
 

@@ -1,0 +1,372 @@
+// vrg_torch_stats.hip -- per-frame Lab mean / std with the BITS torch-ROCm's reductions return on the MI355X.
+//
+// The reference takes its colour statistics with `lab.mean(dim=[2,3], keepdim=True)` and `lab.std(dim=[2,3], keepdim=True)` on a
+// contiguous [b,3,H,W] fp32 tensor, once per batch_size chunk (/root/reference nodes.py:99-100,109-110).  On this GPU those are
+// ATen's reduce_kernel<512,1,ReduceOp<float, MeanOps<float,float,float,float>, uint32, float, 4, 4>> and
+// <..., WelfordOps<float,float,int,pair<float,float>>, ..., 2, 2> (torch/include/ATen/native/cuda/Reduce.cuh and
+// ATen/native/SharedReduceOps.h of the installed torch 2.10.0+rocm7.0).  fp32 sums depend on their order, so "the reference's
+// statistics" are a function of the launch geometry torch picks (setReduceConfig, Reduce.cuh:1012-1180) and of how it combines
+// per-thread accumulators, lanes and warps -- and, for the Welford update, of which multiply-adds hipcc contracted when it built
+// libtorch_hip.so.  The kernels below replay exactly that computation on our interleaved [F][H*W][3] Lab image:
+//
+//   * geometry (ts_config): per output one row of `bw` lanes, x `bh` rows when the reduction is split across warps; for a 2-dim
+//     iterator (H*W contiguous reduced, b*3 kept) ROCm caps max_threads_per_mp at 256, so blocks_per_sm = 256 / 512 = 0 and the
+//     input is never split across workgroups: one workgroup per output, b = 1 -> (256,2), b = 2 -> (128,4), b >= 3 -> (64,8) on
+//     video-sized frames (confirmed by rocprofv3 grid / workgroup sizes);
+//   * thread loop: input_vectorized_thread_reduce_impl (Reduce.cuh:498-556: unaligned head, `vec` accumulators over aligned vectors,
+//     tail) from 128 elements up, thread_reduce_impl (:558-624) below;
+//   * block_x_reduce (:626-661: LDS tree down to 64 lanes, then shfl_down with INCREASING offsets, the USE_ROCM branch),
+//     block_y_reduce (:663-680), project;
+//   * contraction, read from the disassembly of libtorch_hip.so's gfx950 code object: every `a + b * c` of WelfordOps is one FMA
+//     EXCEPT accumulator 0's `m2 + delta * new_delta` inside the vectorised main loop -- the SLP vectoriser paired that add with
+//     accumulator 1's `mean + delta / n` into a v_pk_add_f32, so its product is rounded first (v_mul_f32).  Division and sqrt
+//     are IEEE (hipcc's default), as here.
+//
+// oracle/torch_device_reduce.py restates the same algorithm in numpy; both are held bit-equal to torch on the device
+// (tests/golden/torch_reduce_truth.npz collected on the MI355X; tests/test_gpu_parity.py compares with torch directly).
+#include "vrg_common.hpp"
+
+namespace vrg {
+
+struct TsCfg { int bw, bh, split, vectorize; };
+
+static int ts_last_pow2(int n) {
+    n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8; n |= n >> 16;
+    const int r = n - (n >> 1);
+    return r > 1 ? r : 1;
+}
+static int64_t ts_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// setReduceConfig for iter.ndim() == 2, reduction over the contiguous fastest dimension, 256 CUs, warp 64, 512 threads max.
+// false: a geometry with ctas_per_output > 1 (not reachable for >= 2 outputs; kept as a guard).
+static bool ts_config(int64_t num_outputs, int64_t n, int vec, TsCfg& c) {
+    int64_t dim0 = n;
+    c.vectorize = dim0 >= 128;
+    if (c.vectorize) dim0 /= vec;
+    const int d0 = dim0 < 512 ? ts_last_pow2((int)dim0) : 512;
+    const int d1 = num_outputs < 512 ? ts_last_pow2((int)num_outputs) : 512;
+    int bw = d0 < 64 ? d0 : 64;
+    const int bh = d1 < 512 / bw ? d1 : 512 / bw;
+    bw = d0 < 512 / bh ? d0 : 512 / bh;
+    int64_t vpt = ts_div_up(n, bw);
+    const int thr = bh * 16 < 256 ? bh * 16 : 256;
+    c.split = vpt >= thr;
+    c.bw = bw; c.bh = bh;
+    const int64_t step_in = (int64_t)bw * (c.split ? bh : 1), step_out = c.split ? 1 : bh;
+    const int64_t grid_x = ts_div_up(num_outputs, step_out);
+    const int max_tpm = grid_x == 1 ? 2048 : 256;          // `grid.x == grid.y == grid.z == 1` as C evaluates it
+    const int64_t target = 256 * (int64_t)(max_tpm / (bw * bh));
+    vpt = ts_div_up(n, step_in);
+    if (c.split && vpt >= 256 && grid_x <= target) {
+        const int64_t c1 = ts_div_up(target, grid_x), c2 = ts_div_up(vpt, 16), c3 = ts_div_up(vpt, 256);
+        int64_t ctas = (c1 < c2 ? c1 : c2) > c3 ? (c1 < c2 ? c1 : c2) : c3;
+        if (ctas > 256) ctas = 256; else if (ctas > 128) ctas = 128; else if (ctas < 16) ctas = 1;
+        if (ctas != 1) return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ops
+// ---------------------------------------------------------------------------------------------------------------------
+struct Welf { float mean, m2; int n; float nf; };
+
+struct MeanOp {
+    typedef float acc_t;
+    static constexpr int VEC = 4;
+    static __device__ __forceinline__ acc_t ident() { return 0.0f; }
+    template <bool FUSED> static __device__ __forceinline__ acc_t reduce(acc_t a, float x) { return a + x; }
+    static __device__ __forceinline__ acc_t combine(acc_t a, acc_t b) { return a + b; }
+    static __device__ __forceinline__ acc_t shfl_down(acc_t a, int off) { return __shfl_down(a, off, 64); }
+};
+
+struct WelfOp {
+    typedef Welf acc_t;
+    static constexpr int VEC = 2;
+    static __device__ __forceinline__ acc_t ident() { return Welf{0.0f, 0.0f, 0, 0.0f}; }
+    // WelfordOps::reduce (SharedReduceOps.h:100-113)
+    template <bool FUSED> static __device__ __forceinline__ acc_t reduce(acc_t a, float x) {
+        const int n1 = a.n + 1;
+        const float nf1 = (float)n1;
+        const float delta = x - a.mean;
+        const float mean1 = a.mean + delta / nf1;
+        const float d2 = x - mean1;
+        const float m2 = FUSED ? __builtin_fmaf(delta, d2, a.m2) : a.m2 + delta * d2;
+        return Welf{mean1, m2, n1, nf1};
+    }
+    // WelfordOps::combine (:114-131); both multiply-adds are FMAs in libtorch_hip.so at every call site
+    static __device__ __forceinline__ acc_t combine(acc_t a, acc_t b) {
+        if (a.nf == 0.0f) return b;
+        if (b.nf == 0.0f) return a;
+        const float delta = b.mean - a.mean;
+        const float cnt = a.nf + b.nf;
+        const float nb = b.nf / cnt;
+        const float mean = __builtin_fmaf(delta, nb, a.mean);
+        const float m2 = __builtin_fmaf((delta * delta) * a.nf, nb, a.m2 + b.m2);
+        return Welf{mean, m2, -1, cnt};
+    }
+    static __device__ __forceinline__ acc_t shfl_down(acc_t a, int off) {
+        return Welf{__shfl_down(a.mean, off, 64), __shfl_down(a.m2, off, 64), __shfl_down(a.n, off, 64), __shfl_down(a.nf, off, 64)};
+    }
+};
+
+// WelfordOps::project with correction 1, take_sqrt
+static __device__ __forceinline__ float welf_std(const Welf& a) {
+    const float divisor = a.nf > 1.0f ? a.nf - 1.0f : 0.0f;
+    return __builtin_sqrtf(a.m2 / divisor);
+}
+
+// block_x_reduce, then block_y_reduce when the rows share one output.  Every thread of the workgroup calls it (`live`: the thread is
+// one of the bw * rows threads of the geometry); the result is valid in thread 0.  `lds` holds blockDim.x accumulators.
+template <class OP>
+static __device__ typename OP::acc_t ts_block_reduce(typename OP::acc_t v, int bw, int bh, bool split, int t, bool live,
+                                                     typename OP::acc_t* lds) {
+    const int tx = t % bw, ty = t / bw;
+    int dim_x = bw;
+    __syncthreads();                                   // lds may still be read by a previous call
+    if (dim_x > 64) {
+        if (live) lds[t] = v;
+        for (int off = dim_x / 2; off >= 64; off >>= 1) {
+            __syncthreads();
+            if (live && tx < off && tx + off < bw) {
+                v = OP::combine(v, lds[t + off]);
+                lds[t] = v;
+            }
+        }
+        dim_x = 64;
+    }
+    __syncthreads();
+    for (int off = 1; off < dim_x; off <<= 1) {
+        const typename OP::acc_t other = OP::shfl_down(v, off);
+        v = OP::combine(v, other);
+    }
+    if (split) {
+        if (live) lds[t] = v;
+        for (int off = bh / 2; off > 0; off >>= 1) {
+            __syncthreads();
+            if (live && ty < off && ty + off < bh) {
+                v = OP::combine(v, lds[t + off * bw]);
+                lds[t] = v;
+            }
+        }
+    }
+    return v;
+}
+
+// One thread's share of one output: `X(p)` = element p of the output's reduction range, `shift` = elements by which that range
+// starts past a VEC-aligned address in the reference's planar tensor.
+template <class OP, class LOAD>
+static __device__ __forceinline__ typename OP::acc_t ts_thread_reduce(LOAD X, int64_t n, int shift, bool vectorize, int T, int t, int tx,
+                                                                      bool tail_ok) {
+    constexpr int VEC = OP::VEC;
+    typename OP::acc_t acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = OP::ident();
+    if (vectorize) {
+        int64_t start = 0, end = n;
+        if (shift > 0) {
+            if (tx >= shift && tx < VEC && tail_ok) acc[0] = OP::template reduce<true>(acc[0], X((int64_t)(tx - shift)));
+            start = VEC - shift;
+            end = n + shift - VEC;
+        }
+        for (int64_t idx = t; idx * VEC + VEC - 1 < end; idx += T) {
+            const int64_t p = start + idx * VEC;
+            acc[0] = OP::template reduce<false>(acc[0], X(p));        // accumulator 0: unfused in libtorch_hip.so's main loop
+#pragma unroll
+            for (int i = 1; i < VEC; ++i) acc[i] = OP::template reduce<true>(acc[i], X(p + i));
+        }
+        const int64_t tail_start = end - end % VEC;
+        if (tail_ok && tail_start + tx < end) acc[0] = OP::template reduce<true>(acc[0], X(start + tail_start + tx));
+    } else {
+        int64_t idx = t;
+        while (idx + (int64_t)(VEC - 1) * T < n) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = OP::template reduce<true>(acc[i], X(idx + (int64_t)i * T));
+            idx += (int64_t)T * VEC;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            if (idx < n) acc[i] = OP::template reduce<true>(acc[i], X(idx));
+            idx += T;
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < VEC; ++i) acc[0] = OP::combine(acc[0], acc[i]);
+    return acc[0];
+}
+
+// General form: one workgroup per output plane (frame, channel); any geometry, any size, any alignment.  `lab` = first frame of
+// the group; plane = plane0 + blockIdx.x; frames are `chunk_frames` per reference call (the plane's position in ITS call fixes
+// the alignment of its first element in the reference's tensor).  out[frame][channel][WHICH].
+template <class OP, int WHICH>
+__global__ void __launch_bounds__(512) k_tstats_plane(const float* __restrict__ lab, int64_t n, int64_t plane0, int chunk_frames, TsCfg cfg,
+                                                      float factor, float eps, float* __restrict__ out) {
+    __shared__ typename OP::acc_t lds[512];
+    const int64_t plane = plane0 + blockIdx.x;
+    const int64_t f = plane / 3;
+    const int c = (int)(plane % 3);
+    const int64_t o_in_call = (f % chunk_frames) * 3 + c;
+    const int shift = cfg.vectorize ? (int)((o_in_call * n) % OP::VEC) : 0;
+    const int rows = cfg.split ? cfg.bh : 1;
+    const int T = cfg.bw * rows;
+    const int t = threadIdx.x;
+    const bool live = t < T;
+    const float* base = lab + (size_t)f * (size_t)n * 3 + c;
+    auto X = [base](int64_t p) { return base[(size_t)p * 3]; };
+    typename OP::acc_t v = OP::ident();
+    if (live) v = ts_thread_reduce<OP>(X, n, shift, cfg.vectorize != 0, T, t, t % cfg.bw, cfg.split ? (t / cfg.bw == 0) : true);
+    v = ts_block_reduce<OP>(v, cfg.bw, cfg.bh, cfg.split != 0, t, live, lds);
+    if (t == 0) {
+        if constexpr (WHICH == 0) out[(size_t)f * 6 + c * 2] = v * factor;
+        else out[(size_t)f * 6 + c * 2 + 1] = welf_std(v) + eps;
+    }
+}
+
+// Video-sized frames (H*W % 4 == 0, 512 cooperating threads for both reductions): one workgroup per frame walks the frame ONCE and
+// feeds the three channels' mean accumulators (vectors of 4 pixels, 512 vectors apart) and Welford accumulators (vectors of 2
+// pixels) of torch's thread of the same index -- 12 B/px of HBM traffic for both statistics of all three channels.
+struct Px2 { float v[6]; };
+
+__global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ lab, int64_t n, int bw, int bh, float factor, float eps,
+                                                      float* __restrict__ out) {
+    __shared__ Welf lds_w[512];
+    float* lds_m = reinterpret_cast<float*>(lds_w);
+    const int64_t f = blockIdx.x;
+    const int t = threadIdx.x;
+    const float* base = lab + (size_t)f * (size_t)n * 3;
+    const int64_t nvm = n / 4, nvw = n / 2;
+    float ma[3][4];
+    Welf wa[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ma[c][i] = 0.0f;
+        wa[c][0] = WelfOp::ident();
+        wa[c][1] = WelfOp::ident();
+    }
+    auto mean_step = [&](int64_t idx) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)idx * 12);
+        const f32x4 a0 = q[0], a1 = q[1], a2 = q[2];
+        const float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ma[c][i] = ma[c][i] + e[i * 3 + c];
+    };
+    auto welf_step = [&](int64_t idx) {
+        const float2* q = reinterpret_cast<const float2*>(base + (size_t)idx * 6);
+        const float2 b0 = q[0], b1 = q[1], b2 = q[2];
+        const float e[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wa[c][0] = WelfOp::reduce<false>(wa[c][0], e[c]);
+            wa[c][1] = WelfOp::reduce<true>(wa[c][1], e[3 + c]);
+        }
+    };
+    // full rounds: every thread has a mean vector and two Welford vectors
+    const int64_t rounds = nvm / 512;
+    for (int64_t r = 0; r < rounds; ++r) {
+        mean_step(r * 512 + t);
+        welf_step(r * 1024 + t);
+        welf_step(r * 1024 + 512 + t);
+    }
+    for (int64_t idx = rounds * 512 + t; idx < nvm; idx += 512) mean_step(idx);
+    for (int64_t idx = rounds * 1024 + t; idx < nvw; idx += 512) welf_step(idx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float m = ma[c][0];
+        m = m + ma[c][1];
+        m = m + ma[c][2];
+        m = m + ma[c][3];
+        m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
+        Welf w = WelfOp::combine(wa[c][0], wa[c][1]);
+        w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
+        if (t == 0) {
+            out[(size_t)f * 6 + c * 2] = m * factor;
+            out[(size_t)f * 6 + c * 2 + 1] = welf_std(w) + eps;
+        }
+    }
+}
+
+// planes [o0, o1) of one reference call: the sub-iterators TensorIterator::with_32bit_indexing would produce (depth first, first half =
+// floor(size / 2)) when the call's tensor has more than 2^29 elements; each has its own geometry and mean factor
+static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_t o1, int chunk_frames, float eps, float* out_call,
+                            hipStream_t st) {
+    const int64_t O = o1 - o0;
+    if (O * n > ((int64_t)1 << 29) && O > 1) {
+        const int64_t half = O / 2;
+        int rc = ts_launch_planes(lab_call, n, o0, o0 + half, chunk_frames, eps, out_call, st);
+        if (rc != VRG_OK) return rc;
+        return ts_launch_planes(lab_call, n, o0 + half, o1, chunk_frames, eps, out_call, st);
+    }
+    if (O * n > ((int64_t)1 << 29)) return VRG_ERR_UNSUPPORTED;      // a single plane beyond 32-bit indexing: torch splits the reduction itself
+    TsCfg cm, cw;
+    if (!ts_config(O, n, 4, cm) || !ts_config(O, n, 2, cw)) return VRG_ERR_UNSUPPORTED;
+    const float factor = (float)O / (float)(O * n);                  // static_cast<float>(num_output_elements) / numel
+    hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)O), dim3(512), 0, st, lab_call, n, o0, chunk_frames, cm, factor, eps, out_call);
+    hipLaunchKernelGGL((k_tstats_plane<WelfOp, 1>), dim3((unsigned)O), dim3(512), 0, st, lab_call, n, o0, chunk_frames, cw, factor, eps, out_call);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+// `count` reference calls of `b` frames each, starting at `lab` / `out`
+static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, hipStream_t st) {
+    if (count <= 0 || b <= 0) return VRG_OK;
+    const int64_t O = (int64_t)b * 3;
+    if (O * n > ((int64_t)1 << 29)) {
+        for (int64_t k = 0; k < count; ++k) {
+            const int rc = ts_launch_planes(lab + (size_t)k * b * n * 3, n, 0, O, b, eps, out + (size_t)k * b * 6, st);
+            if (rc != VRG_OK) return rc;
+        }
+        return VRG_OK;
+    }
+    TsCfg cm, cw;
+    if (!ts_config(O, n, 4, cm) || !ts_config(O, n, 2, cw)) return VRG_ERR_UNSUPPORTED;
+    const float factor = (float)O / (float)(O * n);
+    const int64_t frames = count * b;
+    const bool whole = (n % 4 == 0) && cm.vectorize && cw.vectorize && cm.split && cw.split && cm.bw * cm.bh == 512 && cw.bw * cw.bh == 512 &&
+                       cm.bw == cw.bw;
+    if (whole) {
+        hipLaunchKernelGGL(k_tstats_frame, dim3((unsigned)frames), dim3(512), 0, st, lab, n, cm.bw, cm.bh, factor, eps, out);
+    } else {
+        // all planes of all calls in one launch: plane -> (frame, channel), position in its call from frame % b
+        hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)(frames * 3)), dim3(512), 0, st, lab, n, (int64_t)0, b, cm, factor, eps, out);
+        hipLaunchKernelGGL((k_tstats_plane<WelfOp, 1>), dim3((unsigned)(frames * 3)), dim3(512), 0, st, lab, n, (int64_t)0, b, cw, factor, eps, out);
+    }
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+}  // namespace vrg
+
+extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
+                                       float* mean_std, float eps, void* stream) {
+    using namespace vrg;
+    if (frames < 0 || height <= 0 || width <= 0 || chunk_frames <= 0) return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    if (!lab || !mean_std) return VRG_ERR_BAD_ARG;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VRG_ERR_NO_DEVICE;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return VRG_ERR_NO_DEVICE;
+    if (cus != 256) return VRG_ERR_UNSUPPORTED;        // the geometry above is the MI355X's (256 CUs); other parts pick other grids
+    const int64_t n = (int64_t)height * width;
+    if (frames * 3 > 0x7fffffff / 2) return VRG_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t full = frames / chunk_frames;
+    const int tail = (int)(frames % chunk_frames);
+    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, st);
+    if (rc != VRG_OK) return rc;
+    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, st);
+    return rc;
+}
+
+// Host-only: the geometry ts_config derives for (num_outputs, reduction length, vector width): cfg4 = {block_width, block_height,
+// split across warps, vectorised}; VRG_ERR_UNSUPPORTED where torch would split the reduction across workgroups.  No GPU needed
+// (tests/test_torch_reduce_oracle.py compares it with what rocprofv3 recorded for torch's own launches).
+extern "C" int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32_t vec, int32_t* cfg4) {
+    if (!cfg4 || num_outputs < 1 || reduce_len < 1 || (vec != 2 && vec != 4)) return VRG_ERR_BAD_ARG;
+    vrg::TsCfg c;
+    if (!vrg::ts_config(num_outputs, reduce_len, vec, c)) return VRG_ERR_UNSUPPORTED;
+    cfg4[0] = c.bw; cfg4[1] = c.bh; cfg4[2] = c.split; cfg4[3] = c.vectorize;
+    return VRG_OK;
+}

@@ -108,14 +108,33 @@ class ColorMatchToReference:
                 for b in sizes:
                     expand += [f] * n_ref if b == 1 else list(range(f, f + b))
                     f += b
-        ref_ms = ops.finalize_stats(ops.lab_stats(ref))
+        ref_ms = ops.reference_stats(ref)
+        # The statistics of a chunk are ONE torch reduction call over its frames (nodes.py:109-110): the call sizes shape the
+        # device statistics (ops.CM_STATS), so every piece streamed through the GPU is made of whole calls.
+        if n_ref == 1:
+            calls_of = lambda first, n: batch_size          # pieces start on multiples of batch_size; the last holds the remainder
+            group = batch_size
+        else:
+            sizes = [min(batch_size, frames - i) for i in range(0, frames, batch_size)]
+            calls = [c for b in sizes for c in ([1] * n_ref if b == 1 else [b])]       # a broadcast single frame: n_ref calls of one frame
+            starts = [0]
+            for c in calls:
+                starts.append(starts[-1] + c)
+            first_call = {f: i for i, f in enumerate(starts)}
 
-        def run(gpu_frames, _first):
-            return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms)
+            def calls_of(first, n):
+                i, got, out = first_call[first], 0, []
+                while got < n:
+                    out.append(calls[i]); got += calls[i]; i += 1
+                return out
+            group = n_ref
+
+        def run(gpu_frames, first):
+            return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])))
 
         if expand is not None:
             images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]
-        return (_run_grouped(images, run, multiple_of=n_ref if n_ref != 1 else 1),)
+        return (_run_grouped(images, run, multiple_of=group),)
 
 
 class _Sharpen:

@@ -44,6 +44,21 @@ def _cm_math(value) -> int:
     return int(value)
 
 
+#: Where the colour statistics come from.  "device" (default with the device arithmetic): torch-ROCm's own fp32 reductions replayed
+#: bit for bit (csrc/vrg_torch_stats.hip) -- with it the whole colour match equals the reference run on this GPU; the value depends on
+#: the node's batch_size like the reference's does.  "fp64": fp64-accumulated (n, mean, M2), rounded once -- closer to the exact
+#: statistics than either reference, independent of batch_size, mergeable across GPUs (sharding.py), and what the fast policy uses.
+CM_STATS = ("device", "fp64")
+
+
+def _cm_stats(value, cm_math) -> str:
+    if value is None:
+        value = os.environ.get("VRGDG_CM_STATS", "").strip().lower() or ("device" if _cm_math(cm_math) == _hip.CM_MATH_DEVICE else "fp64")
+    if value not in CM_STATS:
+        raise ValueError(f"cm_stats must be one of {CM_STATS}, got {value!r}")
+    return value
+
+
 def _on_device(fn):
     """Run `fn` with the device of its first tensor argument current: the kernels are enqueued on torch's current
     stream of the current device and the C side asks hipGetDevice(), so a tensor on cuda:1 while cuda:0 is current
@@ -477,6 +492,53 @@ def finalize_stats(stats: torch.Tensor) -> torch.Tensor:
     return ms
 
 
+def _chunk_runs(frames: int, chunks) -> list:
+    """`chunks`: frames per reference call (an int: the node's batch_size, last call = remainder) or the explicit list of call
+    sizes.  Returns [(first_frame, frames, call_size)] runs of equally sized calls."""
+    if isinstance(chunks, int):
+        if chunks < 1:
+            raise ValueError("colour-match chunk must be >= 1")
+        return [(0, frames, chunks)] if frames else []
+    sizes = [int(c) for c in chunks]
+    if any(c < 1 for c in sizes) or sum(sizes) != frames:
+        raise ValueError("colour-match chunk sizes must be positive and add up to the number of frames")
+    runs, f = [], 0
+    for c in sizes:
+        if runs and runs[-1][2] == c and runs[-1][1] % c == 0:
+            runs[-1] = (runs[-1][0], runs[-1][1] + c, c)
+        else:
+            runs.append((f, c, c))
+        f += c
+    return runs
+
+
+@_on_device
+def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5) -> torch.Tensor:
+    """fp32 ``[F, 3, 2]`` = (mean, unbiased std + eps) of an interleaved Lab image ``[F,H,W,3]`` with the BITS
+    ``lab.mean(dim=[2,3])`` / ``lab.std(dim=[2,3]) + 1e-5`` have when torch evaluates them on this GPU for ``chunks`` frames per
+    call (nodes.py:99-100, 109-110).  include/vrgdg_hip.h: vrg_lab_stats_torch_f32."""
+    x = _check_frames(lab, "lab", channels=3)
+    F, H, W, _ = x.shape
+    ms = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
+    fe = H * W * 3
+    for f0, nf, c in _chunk_runs(F, chunks):
+        _hip.check(_hip.lib().vrg_lab_stats_torch_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c,
+                                                     C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps), _hip.current_stream()),
+                   "vrg_lab_stats_torch_f32")
+    return ms
+
+
+def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None) -> torch.Tensor:
+    """fp32 ``[R, 3, 2]`` (mean, std + 1e-5) of the reference frame(s) (nodes.py:98-100): one reduction call over the whole
+    reference batch with the device statistics."""
+    ref = _check_frames(reference_image, "reference_image", channels=3)
+    if _cm_stats(cm_stats, cm_math) == "fp64":
+        return finalize_stats(lab_stats(ref, cm_math))
+    lab = torch.empty_like(ref)
+    chain_stats(ref, ChainSpec(cm_math=cm_math), lab_out=lab)
+    return lab_stats_device(lab, max(int(ref.shape[0]), 1))
+
+
 def merge_stats(parts: torch.Tensor) -> torch.Tensor:
     """Chan/Golub/LeVeque merge of (n, mean, M2) triples along dim 0, in index order (deterministic):
     used to combine the slices of one reference frame reduced on different GPUs.  ``parts``: [R, ..., 3]."""
@@ -516,15 +578,17 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
 
 @_on_device
 def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
-                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None) -> torch.Tensor:
+                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None, cm_chunk=1, cm_stats=None) -> torch.Tensor:
     """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124).  Two passes over HBM:
-    statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain."""
+    statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain.  `cm_chunk`: frames per statistics
+    call of the reference (the node's batch_size, or the list of call sizes) -- it shapes the device statistics like it shapes
+    the reference's (CM_STATS)."""
     x = _check_frames(images, channels=3)
+    stats = _cm_stats(cm_stats, cm_math)
     if ref_ms is None:
-        ref = _check_frames(reference_image.to(x.device), "reference_image", channels=3)
-        ref_ms = finalize_stats(lab_stats(ref, cm_math))
-    if cache_lab:
-        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math))
+        ref_ms = reference_stats(reference_image.to(x.device), cm_math, stats)
+    if cache_lab or stats == "device":
+        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math, cm_chunk=cm_chunk, cm_stats=stats))
     img_ms = finalize_stats(lab_stats(x, cm_math))
     return colormatch_apply(x, img_ms, ref_ms, match_strength, cm_math)
 
@@ -542,6 +606,8 @@ class ChainSpec:
     sharpen: Optional[tuple] = None        # (op name, strength, zero_border)
     variant: int = 0
     cm_math: object = None                 # None = default_cm_math(); "device" / "fast" (colour-match arithmetic policy)
+    cm_chunk: object = 1                   # frames per statistics call of the reference (batch_size), or the list of call sizes
+    cm_stats: object = None                # None = by cm_math; "device" (torch's reductions, bit for bit) / "fp64" (CM_STATS)
 
 
 def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep, like: Optional[torch.Tensor] = None):
@@ -661,6 +727,38 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             segments.append((F - tail.chunk_frames, tail.chunk_frames, tail))
     lib = _hip.lib()
     st = _hip.current_stream()
+    device_stats = spec.colormatch is not None and _cm_stats(spec.cm_stats, spec.cm_math) == "device"
+    lab_full = img_ms_full = None
+    if device_stats:
+        # The reference's statistics are torch reductions over each batch_size call: they need the Lab image of WHOLE calls, so
+        # pass 1 runs for every segment first, then the statistics over the batch, then pass 2 (cache_lab is implied).
+        if lab_workspace is not None:
+            if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
+                raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
+            lab_full = lab_workspace
+        else:
+            lab_full = torch.empty((F, H, W, 3), dtype=torch.float32, device=x.device)
+        for f0, nf, plan in segments:
+            keep = []
+            d = _chain_desc(spec, plan, keep, x)
+            stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
+            nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
+            scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
+            if kernel_events is not None:
+                s0, s1 = HipEvent(), HipEvent()
+                s0.record()
+            _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
+                                                  C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st), "vrg_chain_stats_lab_f32")
+            if kernel_events is not None:
+                s1.record()
+                kernel_events.append(("stats", s0, s1, nf))
+        if kernel_events is not None:
+            t0, t1 = HipEvent(), HipEvent()
+            t0.record()
+        img_ms_full = lab_stats_device(lab_full, spec.cm_chunk)
+        if kernel_events is not None:
+            t1.record()
+            kernel_events.append(("tstats", t0, t1, F))
     for f0, nf, plan in segments:
         keep = []
         d = _chain_desc(spec, plan, keep, x)
@@ -672,33 +770,38 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         if d.stages & _hip.STAGE_COLORMATCH:
             if d.ref_frames != 1 and (nf % d.ref_frames or f0 % d.ref_frames):
                 raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
-            stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
-            nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
-            scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
-            if kernel_events is not None:
-                s0, s1 = HipEvent(), HipEvent()
-                s0.record()
-            if cache_lab:
-                if lab_workspace is not None:
-                    if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
-                        raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
-                    lab = lab_workspace[f0:f0 + nf]
-                else:
-                    lab = torch.empty((nf, H, W, 3), dtype=torch.float32, device=x.device)
-                keep.append(lab)
-                _hip.check(lib.vrg_chain_stats_lab_f32(src, _hip.ptr(lab), nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
-                           "vrg_chain_stats_lab_f32")
-                src = C.c_void_p(lab.data_ptr())
+            if device_stats:
+                src = C.c_void_p(lab_full.data_ptr() + f0 * fe * 4)
                 d.stages = (d.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+                d.img_ms = img_ms_full.data_ptr() + f0 * 24
             else:
-                _hip.check(lib.vrg_chain_stats_f32(src, nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
-                           "vrg_chain_stats_f32")
-            if kernel_events is not None:
-                s1.record()
-                kernel_events.append(("stats", s0, s1, nf))
-            img_ms = finalize_stats(stats)
-            d.img_ms = img_ms.data_ptr()
-            keep.append(img_ms)
+                stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
+                nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
+                scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
+                if kernel_events is not None:
+                    s0, s1 = HipEvent(), HipEvent()
+                    s0.record()
+                if cache_lab:
+                    if lab_workspace is not None:
+                        if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
+                            raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
+                        lab = lab_workspace[f0:f0 + nf]
+                    else:
+                        lab = torch.empty((nf, H, W, 3), dtype=torch.float32, device=x.device)
+                    keep.append(lab)
+                    _hip.check(lib.vrg_chain_stats_lab_f32(src, _hip.ptr(lab), nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
+                               "vrg_chain_stats_lab_f32")
+                    src = C.c_void_p(lab.data_ptr())
+                    d.stages = (d.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+                else:
+                    _hip.check(lib.vrg_chain_stats_f32(src, nf, H, W, C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st),
+                               "vrg_chain_stats_f32")
+                if kernel_events is not None:
+                    s1.record()
+                    kernel_events.append(("stats", s0, s1, nf))
+                img_ms = finalize_stats(stats)
+                d.img_ms = img_ms.data_ptr()
+                keep.append(img_ms)
         if kernel_events is not None:
             e0, e1 = HipEvent(), HipEvent()
             e0.record()

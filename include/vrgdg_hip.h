@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 2
+#define VRG_ABI_VERSION 3
 
 enum vrg_status {
     VRG_OK = 0,
@@ -144,6 +144,18 @@ int64_t vrg_lab_stats_scratch_bytes(int64_t frames);
 int vrg_lab_stats_f32(const float* in, int64_t frames, int32_t height, int32_t width,
                       double* stats, void* scratch, int32_t cm_math, void* stream);
 int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames, void* stream);
+/* The same statistics with the BITS the reference gets on this GPU: `lab.mean(dim=[2,3])` / `lab.std(dim=[2,3]) + 1e-5` as
+ * torch-ROCm evaluates them (nodes.py:99-100, 109-110) -- ATen's reduce_kernel with MeanOps / WelfordOps in fp32, whose value
+ * depends on the launch geometry torch derives from the tensor shape ([chunk_frames,3,H,W] per call: the node's batch_size, or the
+ * whole reference batch), on the order in which thread accumulators, lanes and warps are combined, and on which multiply-adds of
+ * the Welford update hipcc contracted in libtorch_hip.so.  csrc/vrg_torch_stats.hip replays that computation (geometry of the
+ * MI355X: 256 CUs; VRG_ERR_UNSUPPORTED elsewhere) on the interleaved Lab image `lab` ([frames][H][W][3] fp32: the `lab_out` of
+ * vrg_chain_stats_lab_f32).  Frames are taken `chunk_frames` per reference call, the last call holds the remainder.
+ * mean_std = device fp32 [frames][3][2] = {mean, std + eps} (eps = 1e-5f for the node), the layout vrg_colormatch_apply_f32 /
+ * vrg_chain_desc::img_ms / ref_ms read.  With these statistics the whole colour match is bit-equal to the reference's formulas
+ * evaluated by torch on the device (tests/test_gpu_parity.py). */
+int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
+                            float* mean_std, float eps, void* stream);
 int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
                              const float* img_ms, const float* ref_ms, int32_t ref_frames,
                              float k, float one_minus_k, int32_t cm_math, void* stream);
@@ -299,6 +311,10 @@ int vrg_selftest_lanes(float* out128, void* stream);
  * 15: 1.0 where the rounding test of dev_pow_ziv fails for (x, y), else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
  * 18 / 19 dev_pow_ziv's table ln x, head / tail. */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
+/* Host-only (no GPU needed): the launch geometry vrg_lab_stats_torch_f32 derives -- torch's setReduceConfig on the MI355X -- for
+ * `num_outputs` outputs of `reduce_len` contiguous fp32 elements, `vec` = 4 (mean) or 2 (std): cfg4 = {block_width, block_height,
+ * reduction split across the rows (1) or one output per row (0), vectorised thread loop (1) or strided (0)}. */
+int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32_t vec, int32_t* cfg4);
 /* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;
  * 5 / 6: channel split -- one / two channels of the node table in LDS (8 ds_read per pixel), the rest gathered (4 / 2 x 16 B). */

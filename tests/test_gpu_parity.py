@@ -62,7 +62,7 @@ def assert_bit_equal(got, want, what=""):
 def test_native_library_is_loaded(pkg):
     from comfyui_vrgamedevgirl_amd import _hip
     lib = _hip.lib()
-    assert lib.vrg_abi_version() == 2
+    assert lib.vrg_abi_version() == 3
     with open("/proc/self/maps") as fh:
         assert any("libvrgdg_hip.so" in line for line in fh), "HIP extension not mapped into the process"
     import ctypes as C
@@ -645,7 +645,9 @@ def test_colour_match_apply_bit_equal_device_oracle_with_injected_statistics(ops
     lab = R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2))
     alt = R.color_match_apply(lab, oms[..., 0].view(4, 3, 1, 1), oms[..., 1].view(4, 3, 1, 1), orms[..., 0].view(1, 3, 1, 1),
                               orms[..., 1].view(1, 3, 1, 1), k).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
-    assert_bit_equal(ops.color_match(x, ref, k), alt, "whole colour match vs the oracle evaluated with our statistics")
+    assert_bit_equal(ops.color_match(x, ref, k, cm_stats="fp64"), alt, "whole colour match (fp64 statistics) vs the oracle evaluated with them")
+    # and with the device statistics (the default) the whole thing IS the device oracle
+    assert_bit_equal(ops.color_match(x, ref, k, cm_chunk=bs), want, "whole colour match, device statistics")
 
 
 def test_lab_statistics_against_fp64_and_the_device_reductions(ops, dev):
@@ -682,18 +684,77 @@ def test_lab_statistics_against_fp64_and_the_device_reductions(ops, dev):
     assert torch.equal(ops.lab_stats(xd, cm_math="fast")[..., 0], stats[..., 0])
 
 
+def _torch_reductions(lab_nhwc, chunk):
+    """(mean, std + 1e-5) as the reference takes them: torch reductions over dims [2,3] of the contiguous NCHW tensor of each call."""
+    ms = []
+    for i in range(0, lab_nhwc.shape[0], chunk):
+        t = lab_nhwc[i:i + chunk].permute(0, 3, 1, 2).contiguous()
+        ms.append(torch.stack([t.mean(dim=[2, 3]), t.std(dim=[2, 3]) + 1e-5], dim=-1))
+    return torch.cat(ms, dim=0)
+
+
+def _same_bits_or_nan(a, b):
+    a, b = a.cpu(), b.cpu()
+    return bool(((a.view(torch.int32) == b.view(torch.int32)) | (torch.isnan(a) & torch.isnan(b))).all())
+
+
+@pytest.mark.parametrize("F,H,W,chunk", [
+    (2, 2160, 3840, 1), (4, 1080, 1920, 2), (7, 540, 960, 3), (9, 270, 480, 4), (16, 64, 64, 16), (5, 72, 120, 2), (3, 40, 40, 1),
+    # planes that start at unaligned addresses in the reference's tensor (H*W % 4 != 0), the vectorisation threshold, tiny frames
+    (5, 15, 15, 2), (3, 15, 15, 1), (7, 11, 13, 3), (4, 5, 7, 2), (1, 5, 7, 1), (3, 1, 127, 1), (3, 1, 128, 3), (2, 1, 129, 2), (2, 1, 130, 1),
+    (4, 31, 33, 4), (2, 255, 257, 1), (3, 1023, 1025, 3), (2, 90, 91, 2), (1, 1, 1, 1), (2, 1, 2, 1), (3, 2, 2, 2), (6, 23, 29, 5), (40, 16, 16, 40)])
+def test_device_statistics_are_torch_reductions_bit_for_bit(ops, dev, F, H, W, chunk):
+    """vrg_lab_stats_torch_f32 against `mean(dim=[2,3])` / `std(dim=[2,3]) + 1e-5` evaluated by torch on this GPU, per call of
+    `chunk` frames (the geometry -- and with it the fp32 value -- changes with the call size and the frame size)."""
+    g = torch.Generator().manual_seed(F * 1000 + H + W + chunk)
+    lab = (torch.rand((F, H, W, 3), generator=g) * torch.tensor([100.0, 120.0, 120.0]) + torch.tensor([0.0, -60.0, -60.0])).to(dev)
+    got = ops.lab_stats_device(lab, chunk)
+    want = _torch_reductions(lab, chunk)
+    assert _same_bits_or_nan(got, want), (got - want).abs().max()
+    if F > chunk:       # explicit call sizes, in another split
+        sizes = [1] + [chunk] * ((F - 1) // chunk) + ([(F - 1) % chunk] if (F - 1) % chunk else [])
+        got2 = ops.lab_stats_device(lab, sizes)
+        want2 = torch.cat([_torch_reductions(lab[:1], 1), _torch_reductions(lab[1:], chunk)], dim=0)
+        assert _same_bits_or_nan(got2, want2)
+
+
+def test_device_statistics_numpy_restatement_equals_torch_on_this_gpu(dev):
+    """oracle/torch_device_reduce.py (the CPU restatement the -m 'not gpu' suite checks against the committed ground truth) against
+    torch on the device, on fresh data."""
+    from oracle import torch_device_reduce as TR
+    for seed, (b, H, W) in enumerate([(1, 135, 240), (2, 72, 120), (5, 33, 47), (3, 15, 15)]):
+        x = _rand((b, 3, H, W), 900 + seed) * 100 - 30
+        xd = x.to(dev)
+        m, s = TR.mean_std(x.numpy())
+        assert np.array_equal(m.view(np.int32), xd.mean(dim=[2, 3]).cpu().numpy().view(np.int32))
+        assert np.array_equal(s.view(np.int32), xd.std(dim=[2, 3]).cpu().numpy().view(np.int32))
+
+
+@pytest.mark.parametrize("F,H,W,bs,n_ref,k", [(5, 135, 240, 2, 1, 1.0), (6, 72, 120, 4, 1, 0.35), (4, 270, 480, 1, 1, 0.8), (3, 45, 51, 3, 3, 0.6),
+                                            (7, 30, 50, 7, 1, 1.0), (2, 1080, 1920, 1, 1, 1.0)])
+def test_colour_match_node_is_the_device_oracle_for_every_batch_size(pkg, dev, F, H, W, bs, n_ref, k):
+    """The statistics depend on batch_size in the reference (one reduction call per chunk); so do ours: node == device oracle,
+    bit for bit, for every chunking including ragged last chunks and odd frame sizes."""
+    x, ref = _cm_image((F, H, W, 3), 71), _rand((n_ref, 37, 53, 3), 72) * 0.8 + 0.1
+    (out,) = pkg.NODE_CLASS_MAPPINGS["ColorMatchToReference"]().match_color(x, ref, k, bs)
+    assert_bit_equal(out, R.color_match(x.to(dev), ref.to(dev), k, bs), f"batch_size {bs}")
+
+
 @pytest.mark.parametrize("shape,ref_shape,k,bs", [((4, 135, 240, 3), (1, 64, 80, 3), 1.0, 1), ((3, 270, 480, 3), (1, 300, 400, 3), 0.35, 1),
                                                   ((4, 96, 128, 3), (4, 50, 60, 3), 0.8, 4)])
 def test_colour_match_end_to_end_ulp_budget_vs_device_oracle(pkg, ops, dev, shape, ref_shape, k, bs):
-    """Node end to end (device policy) against the device oracle: the element-wise path is bit-equal (tests above), the
-    distance is the statistics (fp64-accumulated here, batch-shape dependent fp32 reductions there)."""
+    """Node end to end (device policy) against the device oracle: BIT-EQUAL -- element-wise path and statistics (torch's own
+    reductions per batch_size call, replayed).  The fp64-statistics variant keeps its measured distance (statistics only)."""
     x, ref = _cm_image(shape, 31), _rand(ref_shape, 32) * 0.7 + 0.1
     node = pkg.NODE_CLASS_MAPPINGS["ColorMatchToReference"]()
     (out,) = node.match_color(x, ref, k, bs)
     want = R.color_match(x.to(dev), ref.to(dev), k, bs).cpu()
-    d = _unit_ulps(out, want)
-    _record(f"e2e.device_vs_device_oracle.{shape[1]}p", d)
-    assert d <= CM_E2E_DEVICE_ULP, d
+    assert_bit_equal(out, want, "ColorMatchToReference vs the reference's formulas evaluated by torch on this GPU")
+    if ref_shape[0] == 1:
+        f64 = ops.color_match(x.to(dev), ref.to(dev), k, cm_stats="fp64").cpu()
+        d = _unit_ulps(f64, want)
+        _record(f"e2e.device_fp64stats_vs_device_oracle.{shape[1]}p", d)
+        assert d <= CM_E2E_DEVICE_ULP, d
     cpu = R.color_match(x, ref, k, bs)
     _record(f"e2e.cpu_oracle_vs_device_oracle.{shape[1]}p", _unit_ulps(cpu, want))
     _record(f"e2e.device_vs_cpu_oracle.{shape[1]}p", _unit_ulps(out, cpu))
