@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CM_BATCH = 1                    # ColorMatchToReference's batch_size widget default: frames per statistics call of the reference
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable by a copy kernel
 WORKLOADS = {
     # name: (H, W, stages)
@@ -151,7 +152,7 @@ def live_traffic(timeout_s=150):
         wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
         vi = sum(sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) for k, v in per_px.items() if match(k) and "SQ_INSTS_VALU" in v)
         return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1)}
-    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k),
+    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k), "tstats": bpp(lambda k: "k_tstats_frame" in k),
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")
@@ -263,7 +264,12 @@ def main():
             if kernel_events is not None:
                 r0, r1 = ops.HipEvent(), ops.HipEvent()
                 r0.record()
-            ref_ms = sharding.reference_stats_sharded(ref, rank, world, cm_math=cm_math)
+            if ops._cm_stats(None, cm_math) == "device":
+                # device statistics = torch's own reduction over the WHOLE reference frame: every rank evaluates it (no exchange)
+                ref_ms = ops.reference_stats(ref, cm_math)
+            else:
+                # fp64 (n, mean, M2): rows split across the ranks + all-reduce over RCCL (BASELINE configs[4])
+                ref_ms = sharding.reference_stats_sharded(ref, rank, world, cm_math=cm_math)
             if kernel_events is not None:
                 r1.record()
                 ref_events.append((r0, r1))
@@ -273,7 +279,7 @@ def main():
         spec = ops.ChainSpec(grain=(0.04, 0.5, chunk) if "grain" in stages else None,
                              lut=(lut, 10.0) if "lut" in stages else None,
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
-                             sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math)
+                             sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH)
         ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws)
 
     def barrier():
@@ -314,8 +320,9 @@ def main():
             fel = float(t.item())
         fast_variant = {"cm_math": "fast", "value": round(world * frames * H * W * args.steps / fel / 1e6, 1), "unit": "Mpixels/s",
                         "ms_per_step": round(fel / args.steps * 1e3, 3),
-                        "note": "table-driven powers (<= 0.534 ulp) instead of ocml powf: a few ulp from the reference, not bit-equal "
-                                "to its device arithmetic (DESIGN.md section 4)"}
+                        "cm_stats": "fp64 (reference-frame rows split across the ranks, merged by the RCCL all-reduce when N > 1)",
+                        "note": "table-driven powers (<= 0.534 ulp) instead of ocml powf and fp64-accumulated statistics instead of torch's "
+                                "fp32 reductions: a few ulp from the reference, not bit-equal to it (DESIGN.md section 4)"}
 
     px_rank = frames * H * W
     value = world * px_rank * args.steps / elapsed / 1e6
@@ -324,8 +331,9 @@ def main():
     for name, a, b, nf in events:
         passes.setdefault(name, []).append(a.elapsed_ms(b))
     pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (segments of a step added up)
-    algo_bpp = {"stats": 12, "apply": 24}
+    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}                      # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
     kern_names = {"stats": "k_produce_lab (grain->LUT->Lab pass 1: shared Philox, stores Lab, per-frame statistics)",
+                  "tstats": "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)",
                   "apply": "k_chain_tile<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, LDS tile)" if "colormatch" in stages
                   else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
                         else "k_chain_tile / k_chain_pointwise (fused apply pass)")}
@@ -404,7 +412,8 @@ def main():
                        else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
                        "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
-                       "cm_math": "device" if "colormatch" in stages else None},
+                       "cm_math": "device" if "colormatch" in stages else None,
+                       "cm_stats": (f"device (torch-ROCm's reductions bit for bit, batch_size {CM_BATCH})" if "colormatch" in stages else None)},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
             "per_rank_ms_per_step": per_rank_ms,

@@ -139,10 +139,10 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-template <int STAGES>
+template <int STAGES, bool STATS = true>
 __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in, int32_t ppf, int32_t bpf, ChainK D,
                                                        double* __restrict__ partials, px3* __restrict__ lab_out) {
-    __shared__ double red[4][6];
+    __shared__ double red[STATS ? 4 : 1][6];
     VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const int64_t f = blockIdx.y;
     const px3* fin = in + f * ppf;
@@ -167,12 +167,13 @@ __global__ __launch_bounds__(256) void k_lab_partials(const px3* __restrict__ in
         rgb_to_lab(pre, lab, PT);
         if (lab_out) store_px_stream(lab_out + f * ppf + p, px3{lab[0], lab[1], lab[2]});
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < (STATS ? 3 : 0); ++c) {
             const double d = (double)lab[c] - (double)pivot[c];
             s1[c] += d;
             s2[c] += d * d;
         }
     }
+    if (!STATS) return;                 // Lab image only (statistics: vrg_torch_stats.hip)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -241,6 +242,12 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
             d.noise.chunk0 += f0 / D.noise.chunk_frames;
         }
         const px3* src = reinterpret_cast<const px3*>(in) + f0 * ppf;
+        if (!stats) {                   // Lab image only
+            hipLaunchKernelGGL((k_lab_partials<STAGES, false>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
+                               (double*)nullptr, reinterpret_cast<px3*>(lab_out) + f0 * ppf);
+            if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
+            continue;
+        }
         hipLaunchKernelGGL((k_lab_partials<STAGES>), dim3((uint32_t)bpf, (uint32_t)nf), dim3(256), 0, st, src, (int32_t)ppf, bpf, d,
                            partials + f0 * bpf * 6, lab_out ? reinterpret_cast<px3*>(lab_out) + f0 * ppf : nullptr);
         hipLaunchKernelGGL(k_lab_merge<STAGES>, dim3((uint32_t)nf), dim3(64), 0, st, src, (int32_t)ppf, bpf, d,
@@ -381,7 +388,8 @@ int vrg_chain_stats_f32(const float* in, int64_t frames, int32_t height, int32_t
 
 int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int32_t height, int32_t width,
                             const vrg_chain_desc* desc, double* stats, void* scratch, void* stream) {
-    if (!in || !desc || !stats || !scratch || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
+    // stats == NULL (with lab_out): the Lab image only -- no statistics, no scratch
+    if (!in || !desc || (!stats && !lab_out) || (stats && !scratch) || frames < 0 || height <= 0 || width <= 0) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
     if ((int64_t)height * width > 0x7fffffff / 3) return VRG_ERR_UNSUPPORTED;
     vrg_chain_desc pre = *desc;

@@ -52,12 +52,17 @@ __device__ __forceinline__ bool run_crosses_frame(const ProduceK& P, int64_t A) 
 #ifndef VRG_PRODUCE_WAVES
 #define VRG_PRODUCE_WAVES 4   /* device-policy kernel: 130 -> 127 VGPRs, 4 waves per SIMD, statistics pass -7 % (A/B) */
 #endif
-template <int STAGES, bool TWO_PART>
-__global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
+#ifndef VRG_PRODUCE_WAVES_LABONLY
+#define VRG_PRODUCE_WAVES_LABONLY 4
+#endif
+// STATS = false: the Lab image only (the statistics are then torch's own reductions over that image, vrg_torch_stats.hip): no
+// accumulators, no records, and a run that crosses a frame boundary needs no second instantiation.
+template <int STAGES, bool TWO_PART, bool STATS = true>
+__global__ __launch_bounds__(256, TWO_PART ? 1 : (STATS ? VRG_PRODUCE_WAVES : VRG_PRODUCE_WAVES_LABONLY)) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
                                                       const float* __restrict__ pivots, double* __restrict__ rec,
                                                       int32_t* __restrict__ rec_frame) {
     __shared__ float sn[4][PR_SUB + 4];
-    __shared__ double red[4][12];
+    __shared__ double red[STATS ? 4 : 1][12];
     VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     const uint32_t per_chunk = P.K * P.NB;
     const uint32_t G = P.G;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
         if (TWO_PART && c && !crosses && (uint32_t)m != (blockIdx.x & 3u)) return;    // a lower sibling owns this run
         crosses = crosses || c;
     }
-    if (crosses != TWO_PART) return;
+    if (STATS && crosses != TWO_PART) return;
     const uint32_t block_lin = chunk * per_chunk + k * P.NB + ib;    // record slot of the run
 
     const float* cin = in + (int64_t)chunk * P.numel;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
         fr[m] = A < P.numel ? (int)((uint32_t)A / (uint32_t)P.fe) : -1;
         fb[m] = ((int64_t)fr[m] + 1) * P.fe;
 #pragma unroll
-        for (int part = 0; part < (TWO_PART ? 2 : 1); ++part) {
+        for (int part = 0; part < (STATS ? (TWO_PART ? 2 : 1) : 0); ++part) {
             int f = fr[m] + part;
             f = f < 0 ? 0 : (f > P.chunk_frames - 1 ? P.chunk_frames - 1 : f);
             const float* pp = pivots + ((int64_t)chunk * P.chunk_frames + f) * 3;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
                 if (clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
                 const int part = TWO_PART ? (e0 >= fb[m] ? 1 : 0) : 0;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
+                for (int c = 0; c < (STATS ? 3 : 0); ++c) {
                     if (TWO_PART) {
                         const double d0 = (double)lab[c] - (double)pv[m][0][c];
                         const double d1 = (double)lab[c] - (double)pv[m][1][c];
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : VRG_PRODUCE_WAVES) void k_produ
         }
         __syncthreads();
     }
+    if (!STATS) return;
     // ---- one record per (block, sibling, part)
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -293,6 +299,11 @@ static int launch_produce_t(const float* in, float* lab_out, int64_t frames, int
     produce_geometry(D, frames, fe, P);
     const int64_t blocks = (int64_t)P.chunks * P.K * P.NB;
     if (blocks >= (1ll << 24) || frames % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
+    if (!stats) {                    // Lab image only
+        hipLaunchKernelGGL((k_produce_lab<STAGES, false, false>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, (const float*)nullptr,
+                           (double*)nullptr, (int32_t*)nullptr);
+        return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
+    }
     char* base = reinterpret_cast<char*>(scratch);
     double* rec = reinterpret_cast<double*>(base);
     int32_t* rec_frame = reinterpret_cast<int32_t*>(base + blocks * 8 * 6 * 8);

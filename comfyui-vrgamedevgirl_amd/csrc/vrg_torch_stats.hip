@@ -222,68 +222,152 @@ __global__ void __launch_bounds__(512) k_tstats_plane(const float* __restrict__ 
     }
 }
 
-// Video-sized frames (H*W % 4 == 0, 512 cooperating threads for both reductions): one workgroup per frame walks the frame ONCE and
-// feeds the three channels' mean accumulators (vectors of 4 pixels, 512 vectors apart) and Welford accumulators (vectors of 2
-// pixels) of torch's thread of the same index -- 12 B/px of HBM traffic for both statistics of all three channels.
-struct Px2 { float v[6]; };
+// Video-sized frames (H*W % 4 == 0, 512 cooperating threads for both reductions): the frame is walked ONCE by a workgroup that
+// feeds the mean accumulators (vectors of 4 pixels, 512 vectors apart) and the Welford accumulators (vectors of 2 pixels) of torch's
+// thread of the same index for all three channels -- 12 B/px of HBM traffic for both statistics.  A "round" = 2048 pixels: one mean
+// vector and two Welford vectors per thread; TS_DEPTH rounds of loads are kept in flight in registers (the update chains are
+// sequential per thread, so nothing else hides the memory latency at 2 waves per SIMD).
+//   PART -1: everything in one workgroup per frame (large batches: HBM bound, 4.7 TB/s measured);
+//   PART 0..2 / 3: the Welford reduction of one channel / the three means -- four workgroups per frame for small batches, where
+//   one workgroup's chain latency (16,200 dependent Welford updates per accumulator at 4K) would be all there is.  The four
+//   workgroups of a frame are placed on one XCD (workgroup id % 8) so that three of them read from L2 what the first one fetched.
+#ifndef VRG_TS_DEPTH
+#define VRG_TS_DEPTH 4
+#endif
+constexpr int TS_DEPTH = VRG_TS_DEPTH;
 
-__global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ lab, int64_t n, int bw, int bh, float factor, float eps,
-                                                      float* __restrict__ out) {
-    __shared__ Welf lds_w[512];
+template <int PART>
+struct TsRound {
+    static constexpr bool MEAN = PART == -1 || PART == 3;
+    static constexpr bool WELF = PART != 3;
+    static constexpr int NC = PART == -1 ? 3 : 1;                       // Welford channels held
+    f32x4 m[MEAN ? 3 : 1];
+    float w[WELF ? 2 * 2 * NC : 1];                                     // [step][pixel][channel]
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t r, int t) {
+        if constexpr (MEAN) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)(r * 512 + t) * 12);
+            m[0] = q[0]; m[1] = q[1]; m[2] = q[2];
+        }
+        if constexpr (WELF) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* q = base + (size_t)(r * 1024 + s * 512 + t) * 6;
+                if constexpr (PART == -1) {
+                    const float2* q2 = reinterpret_cast<const float2*>(q);
+                    const float2 b0 = q2[0], b1 = q2[1], b2 = q2[2];
+                    w[s * 6 + 0] = b0.x; w[s * 6 + 1] = b0.y; w[s * 6 + 2] = b1.x; w[s * 6 + 3] = b1.y; w[s * 6 + 4] = b2.x; w[s * 6 + 5] = b2.y;
+                } else {
+                    w[s * 2 + 0] = q[PART];
+                    w[s * 2 + 1] = q[3 + PART];
+                }
+            }
+        }
+    }
+};
+
+template <int PART>
+static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
+                                     Welf* lds_w) {
+    typedef TsRound<PART> R;
+    constexpr int NC = R::NC, C0 = PART == -1 ? 0 : (PART == 3 ? 0 : PART);
     float* lds_m = reinterpret_cast<float*>(lds_w);
-    const int64_t f = blockIdx.x;
     const int t = threadIdx.x;
-    const float* base = lab + (size_t)f * (size_t)n * 3;
     const int64_t nvm = n / 4, nvw = n / 2;
     float ma[3][4];
-    Welf wa[3][2];
+    Welf wa[NC][2];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ma[c][i] = 0.0f;
-        wa[c][0] = WelfOp::ident();
-        wa[c][1] = WelfOp::ident();
-    }
-    auto mean_step = [&](int64_t idx) {
-        const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)idx * 12);
-        const f32x4 a0 = q[0], a1 = q[1], a2 = q[2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { wa[c][0] = WelfOp::ident(); wa[c][1] = WelfOp::ident(); }
+
+    auto mean_vec = [&](const f32x4& a0, const f32x4& a1, const f32x4& a2) {
         const float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int c = 0; c < 3; ++c) ma[c][i] = ma[c][i] + e[i * 3 + c];
     };
-    auto welf_step = [&](int64_t idx) {
-        const float2* q = reinterpret_cast<const float2*>(base + (size_t)idx * 6);
-        const float2 b0 = q[0], b1 = q[1], b2 = q[2];
-        const float e[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+    auto welf_vec = [&](const float* e) {              // e[pixel][channel], NC channels
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < NC; ++c) {
             wa[c][0] = WelfOp::reduce<false>(wa[c][0], e[c]);
-            wa[c][1] = WelfOp::reduce<true>(wa[c][1], e[3 + c]);
+            wa[c][1] = WelfOp::reduce<true>(wa[c][1], e[NC + c]);
         }
     };
-    // full rounds: every thread has a mean vector and two Welford vectors
+    // full rounds (every thread has one mean vector and two Welford vectors), TS_DEPTH rounds of loads in flight
     const int64_t rounds = nvm / 512;
-    for (int64_t r = 0; r < rounds; ++r) {
-        mean_step(r * 512 + t);
-        welf_step(r * 1024 + t);
-        welf_step(r * 1024 + 512 + t);
-    }
-    for (int64_t idx = rounds * 512 + t; idx < nvm; idx += 512) mean_step(idx);
-    for (int64_t idx = rounds * 1024 + t; idx < nvw; idx += 512) welf_step(idx);
+    R buf[TS_DEPTH];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float m = ma[c][0];
-        m = m + ma[c][1];
-        m = m + ma[c][2];
-        m = m + ma[c][3];
-        m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
-        Welf w = WelfOp::combine(wa[c][0], wa[c][1]);
-        w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
-        if (t == 0) {
-            out[(size_t)f * 6 + c * 2] = m * factor;
-            out[(size_t)f * 6 + c * 2 + 1] = welf_std(w) + eps;
+    for (int i = 0; i < TS_DEPTH; ++i)
+        if (i < rounds) buf[i].load(base, i, t);
+    for (int64_t r0 = 0; r0 < rounds; r0 += TS_DEPTH) {
+#pragma unroll
+        for (int i = 0; i < TS_DEPTH; ++i) {
+            const int64_t r = r0 + i;
+            if (r < rounds) {
+                if constexpr (R::MEAN) mean_vec(buf[i].m[0], buf[i].m[1], buf[i].m[2]);
+                if constexpr (R::WELF) { welf_vec(buf[i].w); welf_vec(buf[i].w + 2 * NC); }
+                if (r + TS_DEPTH < rounds) buf[i].load(base, r + TS_DEPTH, t);
+            }
+        }
+    }
+    // the last partial round
+    if constexpr (R::MEAN)
+        for (int64_t idx = rounds * 512 + t; idx < nvm; idx += 512) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)idx * 12);
+            mean_vec(q[0], q[1], q[2]);
+        }
+    if constexpr (R::WELF)
+        for (int64_t idx = rounds * 1024 + t; idx < nvw; idx += 512) {
+            const float* q = base + (size_t)idx * 6;
+            float e[2 * NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { e[c] = q[C0 + c]; e[NC + c] = q[3 + C0 + c]; }
+            welf_vec(e);
+        }
+    if constexpr (R::MEAN) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float m = ma[c][0];
+            m = m + ma[c][1];
+            m = m + ma[c][2];
+            m = m + ma[c][3];
+            m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
+            if (t == 0) o6[c * 2] = m * factor;
+        }
+    }
+    if constexpr (R::WELF) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            Welf w = WelfOp::combine(wa[c][0], wa[c][1]);
+            w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
+            if (t == 0) o6[(C0 + c) * 2 + 1] = welf_std(w) + eps;
+        }
+    }
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ lab, int64_t n, int64_t frames, int bw, int bh, float factor,
+                                                      float eps, float* __restrict__ out) {
+    __shared__ Welf lds_w[512];
+    if constexpr (!SPLIT) {
+        const int64_t f = blockIdx.x;
+        ts_frame_part<-1>(lab + (size_t)f * (size_t)n * 3, n, bw, bh, factor, eps, out + (size_t)f * 6, lds_w);
+    } else {
+        // workgroup w -> XCD w % 8: frame f = (w % 8) + 8 * (w / 32), part = (w / 8) % 4, so a frame's four parts share an L2
+        const int64_t w = blockIdx.x;
+        const int64_t f = (w & 7) + 8 * (w >> 5);
+        const int part = (int)((w >> 3) & 3);
+        if (f >= frames) return;
+        const float* base = lab + (size_t)f * (size_t)n * 3;
+        float* o6 = out + (size_t)f * 6;
+        switch (part) {
+            case 0: ts_frame_part<0>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            case 1: ts_frame_part<1>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            case 2: ts_frame_part<2>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            default: ts_frame_part<3>(base, n, bw, bh, factor, eps, o6, lds_w); break;
         }
     }
 }
@@ -309,6 +393,11 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
     return VRG_OK;
 }
 
+#ifndef VRG_TS_SPLIT_MAX_FRAMES
+#define VRG_TS_SPLIT_MAX_FRAMES 32
+#endif
+constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
+
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
 static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, hipStream_t st) {
     if (count <= 0 || b <= 0) return VRG_OK;
@@ -326,8 +415,10 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
     const int64_t frames = count * b;
     const bool whole = (n % 4 == 0) && cm.vectorize && cw.vectorize && cm.split && cw.split && cm.bw * cm.bh == 512 && cw.bw * cw.bh == 512 &&
                        cm.bw == cw.bw;
-    if (whole) {
-        hipLaunchKernelGGL(k_tstats_frame, dim3((unsigned)frames), dim3(512), 0, st, lab, n, cm.bw, cm.bh, factor, eps, out);
+    if (whole && frames <= TS_SPLIT_MAX_FRAMES) {
+        hipLaunchKernelGGL(k_tstats_frame<true>, dim3((unsigned)(32 * ((frames + 7) / 8))), dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out);
+    } else if (whole) {
+        hipLaunchKernelGGL(k_tstats_frame<false>, dim3((unsigned)frames), dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out);
     } else {
         // all planes of all calls in one launch: plane -> (frame, channel), position in its call from frame % b
         hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)(frames * 3)), dim3(512), 0, st, lab, n, (int64_t)0, b, cm, factor, eps, out);

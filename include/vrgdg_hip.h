@@ -218,7 +218,9 @@ int64_t vrg_chain_stats_scratch_bytes(int64_t frames, int32_t height, int32_t wi
 /* Same pass, additionally storing the Lab image it reduces (`lab_out`, same shape as `in`): the apply pass
  * then runs with VRG_STAGE_COLORMATCH | VRG_STAGE_FROM_LAB (| VRG_STAGE_SHARPEN) on `lab_out`.  Trades
  * 12 B/px of extra HBM traffic for not evaluating grain, the LUT gathers and six powers twice -- the chain is
- * ALU / L1-request bound, not HBM bound.  Results are bit-identical to the recomputing form. */
+ * ALU / L1-request bound, not HBM bound.  Results are bit-identical to the recomputing form.
+ * `stats` may be NULL (then `scratch` may be NULL too): only the Lab image is produced -- the form used with the device
+ * statistics (vrg_lab_stats_torch_f32 reduces `lab_out`). */
 int vrg_chain_stats_lab_f32(const float* in, float* lab_out, int64_t frames, int32_t height, int32_t width,
                             const vrg_chain_desc* desc, double* stats, void* scratch, void* stream);
 

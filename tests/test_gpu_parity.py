@@ -779,25 +779,30 @@ def test_colour_match_node_against_fixtures_and_truth(pkg, dev):
         gold = z[key]
         err_ours = np.abs(out.numpy().astype(np.float64) - truth).reshape(4, -1).max(axis=1)
         err_ref = np.abs(gold.astype(np.float64) - truth).reshape(4, -1).max(axis=1)
-        # bar: no further from the fp64 truth than the reference's own fp32 result, + tol
-        assert np.all(err_ours <= err_ref + tol), (key, err_ours, err_ref)
-        # well-conditioned frames also agree with the reference output directly; frame 3 is constant
-        # (sigma = 0): there the reference's fp32 mean is off by an ulp and its output is chaotic (0.6 off truth)
+        # bar: no further from the fp64 truth than the reference's own fp32 result, + tol -- on the
+        # well-conditioned frames.  Frame 3 is constant (sigma = 0): there the reference's fp32 mean of N equal values is not that
+        # value and (lab - mean) / 1e-5 amplifies the difference -- its output is chaotic (up to 0.6 off the truth on the CPU), and
+        # differently so on every device.  The node reproduces what the reference does on THIS device, chaos included:
+        assert np.all(err_ours[:3] <= err_ref[:3] + tol), (key, err_ours, err_ref)
+        assert_bit_equal(out, R.color_match(x.to(dev), ref.to(dev), k, bs), key + " vs the device oracle (constant frame included)")
         d = float(np.abs(out.numpy()[:3] - gold[:3]).max() / ULP1)
         _record("fixtures.device_vs_cpu_fixture", d)
         assert d <= CM_CROSS_REF_ULP, (key, d)
-        assert err_ours[3] <= tol
+        if ref.shape[0] == 1:          # the fp64 statistics return the exact limit on the constant frame
+            from comfyui_vrgamedevgirl_amd import ops as _ops
+            f64 = _ops.color_match(x.to(dev), ref.to(dev), k, cm_stats="fp64").cpu().numpy().astype(np.float64)
+            assert np.abs(f64 - truth).reshape(4, -1).max(axis=1)[3] <= tol
     with pytest.raises(RuntimeError):
         node.match_color(x, ref4[:3], 1.0, 4)                # reference batch neither 1 nor the chunk size
     # a chunk of ONE frame against several references broadcasts the other way: n_ref output frames per input frame
     (out,) = node.match_color(x[:2], ref4[:3], 0.7, 1)
     want = R.color_match(x[:2].to(dev), ref4[:3].to(dev), 0.7, 1).cpu()
     assert out.shape == want.shape == (6,) + tuple(x.shape[1:])
-    assert _unit_ulps(out, want) <= CM_CROSS_REF_ULP
+    assert_bit_equal(out, want, "one-frame chunks broadcast against three references")
     (out,) = node.match_color(x, ref4[:3], 0.7, 3)           # chunks of 3 and 1: 3 + 3 frames
     want = R.color_match(x.to(dev), ref4[:3].to(dev), 0.7, 3).cpu()
     assert out.shape == want.shape == (6,) + tuple(x.shape[1:])
-    assert _unit_ulps(out[:3], want[:3]) <= CM_CROSS_REF_ULP         # frame 3 is the constant frame (chaotic in the reference)
+    assert_bit_equal(out, want, "chunks of 3 and 1 against three references (constant frame included)")
     from comfyui_vrgamedevgirl_amd import ops
     xd = x.to(dev)
     for mode in ("device", "fast"):
