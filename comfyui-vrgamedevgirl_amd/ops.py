@@ -535,8 +535,12 @@ def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None) 
     if _cm_stats(cm_stats, cm_math) == "fp64":
         return finalize_stats(lab_stats(ref, cm_math))
     lab = torch.empty_like(ref)
-    chain_stats(ref, ChainSpec(cm_math=cm_math), lab_out=lab)
-    return lab_stats_device(lab, max(int(ref.shape[0]), 1))
+    Rn, H, W, _ = ref.shape
+    if Rn:
+        d = _chain_desc(ChainSpec(cm_math=cm_math), None, [], ref)
+        _hip.check(_hip.lib().vrg_chain_stats_lab_f32(_hip.ptr(ref), _hip.ptr(lab), Rn, H, W, C.byref(d), None, None, _hip.current_stream()),
+                   "vrg_chain_stats_lab_f32")        # the Lab image only
+    return lab_stats_device(lab, max(int(Rn), 1))
 
 
 def merge_stats(parts: torch.Tensor) -> torch.Tensor:
@@ -741,14 +745,11 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         for f0, nf, plan in segments:
             keep = []
             d = _chain_desc(spec, plan, keep, x)
-            stats = torch.empty((nf, 3, 3), dtype=torch.float64, device=x.device)
-            nbytes = int(lib.vrg_chain_stats_scratch_bytes(nf, H, W, C.byref(d)))
-            scratch = torch.empty((max(nbytes, 8) + 7) // 8, dtype=torch.float64, device=x.device)
             if kernel_events is not None:
                 s0, s1 = HipEvent(), HipEvent()
                 s0.record()
             _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
-                                                  C.byref(d), _hip.ptr(stats), _hip.ptr(scratch), st), "vrg_chain_stats_lab_f32")
+                                                  C.byref(d), None, None, st), "vrg_chain_stats_lab_f32")       # the Lab image only
             if kernel_events is not None:
                 s1.record()
                 kernel_events.append(("stats", s0, s1, nf))
