@@ -227,14 +227,10 @@ __global__ void __launch_bounds__(512) k_tstats_plane(const float* __restrict__ 
 // thread of the same index for all three channels -- 12 B/px of HBM traffic for both statistics.  A "round" = 2048 pixels: one mean
 // vector and two Welford vectors per thread; TS_DEPTH rounds of loads are kept in flight in registers (the update chains are
 // sequential per thread, so nothing else hides the memory latency at 2 waves per SIMD).
-//   PART -1: everything in one workgroup per frame (large batches: HBM bound, 4.7 TB/s measured);
+//   PART -1: everything in one workgroup per frame (large batches: HBM bound, 4.6 TB/s measured);
 //   PART 0..2 / 3: the Welford reduction of one channel / the three means -- four workgroups per frame for small batches, where
 //   one workgroup's chain latency (16,200 dependent Welford updates per accumulator at 4K) would be all there is.  The four
 //   workgroups of a frame are placed on one XCD (workgroup id % 8) so that three of them read from L2 what the first one fetched.
-#ifndef VRG_TS_DEPTH
-#define VRG_TS_DEPTH 4
-#endif
-constexpr int TS_DEPTH = VRG_TS_DEPTH;
 
 template <int PART>
 struct TsRound {
@@ -265,7 +261,7 @@ struct TsRound {
     }
 };
 
-template <int PART>
+template <int PART, int TS_DEPTH>
 static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
                                      Welf* lds_w) {
     typedef TsRound<PART> R;
@@ -348,13 +344,13 @@ static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, 
     }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, int DEPTH>
 __global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ lab, int64_t n, int64_t frames, int bw, int bh, float factor,
                                                       float eps, float* __restrict__ out) {
     __shared__ Welf lds_w[512];
     if constexpr (!SPLIT) {
         const int64_t f = blockIdx.x;
-        ts_frame_part<-1>(lab + (size_t)f * (size_t)n * 3, n, bw, bh, factor, eps, out + (size_t)f * 6, lds_w);
+        ts_frame_part<-1, DEPTH>(lab + (size_t)f * (size_t)n * 3, n, bw, bh, factor, eps, out + (size_t)f * 6, lds_w);
     } else {
         // workgroup w -> XCD w % 8: frame f = (w % 8) + 8 * (w / 32), part = (w / 8) % 4, so a frame's four parts share an L2
         const int64_t w = blockIdx.x;
@@ -364,10 +360,10 @@ __global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ 
         const float* base = lab + (size_t)f * (size_t)n * 3;
         float* o6 = out + (size_t)f * 6;
         switch (part) {
-            case 0: ts_frame_part<0>(base, n, bw, bh, factor, eps, o6, lds_w); break;
-            case 1: ts_frame_part<1>(base, n, bw, bh, factor, eps, o6, lds_w); break;
-            case 2: ts_frame_part<2>(base, n, bw, bh, factor, eps, o6, lds_w); break;
-            default: ts_frame_part<3>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            case 0: ts_frame_part<0, DEPTH>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            case 1: ts_frame_part<1, DEPTH>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            case 2: ts_frame_part<2, DEPTH>(base, n, bw, bh, factor, eps, o6, lds_w); break;
+            default: ts_frame_part<3, DEPTH>(base, n, bw, bh, factor, eps, o6, lds_w); break;
         }
     }
 }
@@ -394,7 +390,7 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
 }
 
 #ifndef VRG_TS_SPLIT_MAX_FRAMES
-#define VRG_TS_SPLIT_MAX_FRAMES 32
+#define VRG_TS_SPLIT_MAX_FRAMES 64
 #endif
 constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
@@ -415,10 +411,16 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
     const int64_t frames = count * b;
     const bool whole = (n % 4 == 0) && cm.vectorize && cw.vectorize && cm.split && cw.split && cm.bw * cm.bh == 512 && cw.bw * cw.bh == 512 &&
                        cm.bw == cw.bw;
-    if (whole && frames <= TS_SPLIT_MAX_FRAMES) {
-        hipLaunchKernelGGL(k_tstats_frame<true>, dim3((unsigned)(32 * ((frames + 7) / 8))), dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out);
-    } else if (whole) {
-        hipLaunchKernelGGL(k_tstats_frame<false>, dim3((unsigned)frames), dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out);
+    if (whole) {
+        // measured on the MI355X (4K frames, ms): 1 frame 1.45 split / 3.57 whole; 64 frames 1.98 / 3.76; 128 frames 5.2 / 3.9 (four
+        // readers per frame stop sharing their L2 lines); 256 frames 11.5 / 5.5 (the whole-frame form runs at 4.6 TB/s there).
+        // Two rounds of loads in flight help the latency-bound split form (1.45 vs 1.72 with four), none the HBM-bound one.
+        const bool split = frames <= TS_SPLIT_MAX_FRAMES;
+        const int depth = split ? 2 : 1;
+        const dim3 grid(split ? (unsigned)(32 * ((frames + 7) / 8)) : (unsigned)frames);
+#define TS_LAUNCH(S, D) hipLaunchKernelGGL((k_tstats_frame<S, D>), grid, dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out)
+        if (depth == 2) TS_LAUNCH(true, 2); else TS_LAUNCH(false, 1);
+#undef TS_LAUNCH
     } else {
         // all planes of all calls in one launch: plane -> (frame, channel), position in its call from frame % b
         hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)(frames * 3)), dim3(512), 0, st, lab, n, (int64_t)0, b, cm, factor, eps, out);

@@ -718,6 +718,24 @@ def test_device_statistics_are_torch_reductions_bit_for_bit(ops, dev, F, H, W, c
         assert _same_bits_or_nan(got2, want2)
 
 
+def test_device_statistics_of_a_call_beyond_32bit_indexing(ops, dev):
+    """A reduction call whose tensor has more than 2^29 elements (batch_size >= 22 at 4K): TensorIterator::with_32bit_indexing splits
+    the OUTPUTS depth first until every piece is 32-bit indexable, and each piece is reduced with its own geometry and mean factor
+    (ts_launch_planes).  22 x 4K frames = 66 planes -> 33 + 33."""
+    F, H, W = 22, 2160, 3840
+    g = torch.Generator(device=dev).manual_seed(77)
+    lab = torch.empty((F, H, W, 3), device=dev)
+    for i in range(F):
+        lab[i] = torch.rand((H, W, 3), generator=g, device=dev) * 100 - 35
+    got = ops.lab_stats_device(lab, F)
+    want = _torch_reductions(lab, F)
+    assert _same_bits_or_nan(got, want), (got - want).abs().max()
+    # and a size where the split leaves planes of one frame in different pieces: 23 frames = 69 planes -> 34 + 35
+    lab23 = torch.cat([lab, lab[:1] * 0.5], dim=0)
+    del lab
+    assert _same_bits_or_nan(ops.lab_stats_device(lab23, 23), _torch_reductions(lab23, 23))
+
+
 def test_device_statistics_numpy_restatement_equals_torch_on_this_gpu(dev):
     """oracle/torch_device_reduce.py (the CPU restatement the -m 'not gpu' suite checks against the committed ground truth) against
     torch on the device, on fresh data."""
@@ -1137,7 +1155,7 @@ def test_side_operands_are_validated(ops, pkg, dev):
         ops.lut3d(x, bad, 10.0)
     with pytest.raises(RuntimeError):
         ops.fused_chain(x, ops.ChainSpec(lut=(bad, 10.0)))
-    assert_bit_equal(ops.colormatch_apply(x, ms, ms[:1], 1.0), ops.color_match(x, None, 1.0, ref_ms=ms[:1], cache_lab=False), "apply forms")
+    assert_bit_equal(ops.colormatch_apply(x, ms, ms[:1], 1.0), ops.color_match(x, None, 1.0, ref_ms=ms[:1], cache_lab=False, cm_stats="fp64"), "apply forms")
 
 
 # ---------------------------------------------------------------------------------------- uint8 codec edge (8f-3)
