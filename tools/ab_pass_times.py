@@ -45,9 +45,17 @@ if which == "kernels":
 acc = {}
 for it in range(iters + 2):
     ev = []
+    w0, w1 = ops.HipEvent(), ops.HipEvent()
+    w0.record()
     ops.fused_chain(x, spec, generator=gen, out=out, lab_workspace=ws, kernel_events=ev)
+    w1.record()
     torch.cuda.synchronize()
     if it >= 2:
+        tot = {}
         for name, a, b, nf in ev:
-            acc.setdefault(name, []).append(a.elapsed_ms(b))
-print(os.environ.get("VRGDG_HIP_LIB", "default"), which, {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})
+            tot[name] = tot.get(name, 0.0) + a.elapsed_ms(b)          # pieces of a pass added up (they may overlap other streams' work)
+        tot["wall"] = w0.elapsed_ms(w1)
+        for k, v in tot.items():
+            acc.setdefault(k, []).append(v)
+print(os.environ.get("VRGDG_HIP_LIB", "default"), which, "pieces", os.environ.get("VRGDG_CM_PIECES", "auto"),
+      {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})
