@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2, help="4K frames of the bounded CPU-baseline sample (x4 at 1080p)")
     ap.add_argument("--no-fast-variant", action="store_true", help="skip the extra timing of the fast colour-match policy")
+    ap.add_argument("--sync-ref", action="store_true", help="reference-frame statistics on the main stream in front of pass 1 (A/B of the side-stream form)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic (use profiles/)")
     return ap.parse_args()
 
@@ -264,7 +265,10 @@ def main():
             if ops._cm_stats(None, cm_math) == "device":
                 # device statistics = torch's own reduction over the WHOLE reference frame: every rank evaluates it (no exchange), on
                 # the side stream -- only the apply pass needs it, pass 1 of the batch runs meanwhile
-                ref_ms, ref_ev = ops.reference_stats_async(ref, cm_math)
+                if args.sync_ref:
+                    ref_ms = ops.reference_stats(ref, cm_math)
+                else:
+                    ref_ms, ref_ev = ops.reference_stats_async(ref, cm_math)
             else:
                 # fp64 (n, mean, M2): rows split across the ranks + all-reduce over RCCL (BASELINE configs[4])
                 if kernel_events is not None:

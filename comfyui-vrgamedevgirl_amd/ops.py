@@ -551,8 +551,7 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
-    """One extra stream per device for work that is off the critical path of the frame passes: the statistics of the reference
-    frame, and the statistics reductions of one piece of a batch while the next piece's pass 1 runs."""
+    """One extra stream per device for work that is off the critical path of the frame passes: the statistics of the reference frame."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(key)
     if st is None:
@@ -647,7 +646,6 @@ class ChainSpec:
     cm_chunk: object = 1                   # frames per statistics call of the reference (batch_size), or the list of call sizes
     cm_stats: object = None                # None = by cm_math; "device" (torch's reductions, bit for bit) / "fp64" (CM_STATS)
     cm_ref_event: object = None            # torch.cuda.Event after which ref_ms is valid (reference_stats_async); waited for before pass 2
-    cm_pieces: int = 0                     # device statistics: pieces of the batch whose reductions overlap the next piece's pass 1 (0 = automatic)
 
 
 def _chain_desc(spec: ChainSpec, plan: Optional[NoisePlan], keep, like: Optional[torch.Tensor] = None):
@@ -719,47 +717,6 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     return stats
 
 
-def _calls_within(calls, first: int, n: int) -> list:
-    """the entries of the call-size list `calls` that make up frames [first, first + n)"""
-    out, f = [], 0
-    for c in calls:
-        if f >= first + n:
-            break
-        if f >= first:
-            out.append(int(c))
-        f += int(c)
-    if sum(out) != n:
-        raise ValueError("pieces of a batch must consist of whole statistics calls")
-    return out
-
-
-def _cm_pieces(segments, F: int, ppf: int, cm_chunk, want: int) -> list:
-    """Cut the RNG segments of a batch into pieces of whole RNG chunks and whole statistics calls (an int cm_chunk: calls of that
-    many frames from frame 0, the last one ragged).  `want` pieces per batch; 0 = four from a billion pixels up (measured), else one.
-    Returns (pieces, aligned): aligned = every piece consists of whole statistics calls (otherwise the caller reduces the batch
-    in one go after pass 1 of all pieces)."""
-    whole = [(f0, nf, plan, 0) for f0, nf, plan in segments]
-    if not isinstance(cm_chunk, int):
-        return whole, len(segments) == 1
-    for f0, nf, plan in segments:
-        if f0 % cm_chunk or ((f0 + nf) % cm_chunk and f0 + nf != F):
-            return whole, False                    # a statistics call straddles two segments: reduce the whole batch at once
-    if want <= 0:
-        want = int(os.environ.get("VRGDG_CM_PIECES", "0") or 0) or (4 if F * ppf >= 1_000_000_000 else 1)
-    if want <= 1:
-        return whole, True
-    import math
-    out = []
-    for f0, nf, plan in segments:
-        g = plan.chunk_frames if plan is not None else 1
-        unit = g * cm_chunk // math.gcd(g, cm_chunk)
-        units = -(-nf // unit)
-        per = max(1, -(-units // want)) * unit
-        for p0 in range(f0, f0 + nf, per):
-            out.append((p0, min(per, f0 + nf - p0), plan, (p0 - f0) // g))
-    return out, True
-
-
 @_on_device
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
@@ -810,73 +767,41 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     st = _hip.current_stream()
     device_stats = spec.colormatch is not None and _cm_stats(spec.cm_stats, spec.cm_math) == "device"
     lab_full = img_ms_full = None
-    pieces = [(f0, nf, plan, 0) for f0, nf, plan in segments]          # (first frame, frames, noise plan, RNG chunks into the plan)
     if device_stats:
-        # The reference's statistics are torch reductions over each batch_size call: they need the Lab image of WHOLE calls.  The
-        # batch is cut into pieces made of whole RNG chunks and whole statistics calls; pass 1 of every piece runs on the caller's
-        # stream, the reductions of a finished piece on the side stream (HBM-bound on 8 waves per CU, next to the issue-bound pass 1
-        # of the following piece), and pass 2 of a piece as soon as its statistics exist.  (cache_lab is implied.)
+        # The reference's statistics are torch reductions over each batch_size call: they need the Lab image of WHOLE calls, so
+        # pass 1 runs for every segment first, then the reductions over the batch, then pass 2 (cache_lab is implied).
+        # (Cutting the batch into pieces whose reductions run on a second stream next to the following piece's pass 1 was built and
+        # measured: 256 x 4K frames 63.2 ms in one piece, 65.8 / 67.9 / 67.3 in 2 / 4 / 8 -- the HBM-bound reductions slow the
+        # issue-bound pass they share the CUs with by more than they hide.  Not kept.)
         if lab_workspace is not None:
             if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
                 raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
             lab_full = lab_workspace
         else:
             lab_full = torch.empty((F, H, W, 3), dtype=torch.float32, device=x.device)
-        img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
-        pieces, aligned = _cm_pieces(segments, F, H * W, spec.cm_chunk, spec.cm_pieces)
-        overlap = aligned and len(pieces) > len(segments)
-        main = torch.cuda.current_stream()
-        side = _side_stream(x.device) if overlap else main
-        done = []
-        for p0, pn, plan, coff in pieces:
+        for f0, nf, plan in segments:
             keep = []
             d = _chain_desc(spec, plan, keep, x)
-            if plan is not None:
-                d.noise.chunk0 += coff
             if kernel_events is not None:
                 s0, s1 = HipEvent(), HipEvent()
                 s0.record()
-            _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + p0 * fe * 4), C.c_void_p(lab_full.data_ptr() + p0 * fe * 4), pn, H, W,
+            _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
                                                   C.byref(d), None, None, st), "vrg_chain_stats_lab_f32")       # the Lab image only
             if kernel_events is not None:
                 s1.record()
-                kernel_events.append(("stats", s0, s1, pn))
-            if not aligned:
-                continue
-            if overlap:
-                e1 = torch.cuda.Event()
-                e1.record(main)
-                side.wait_event(e1)
-            with torch.cuda.stream(side):
-                if kernel_events is not None:
-                    t0, t1 = HipEvent(), HipEvent()
-                    t0.record()
-                calls = spec.cm_chunk if isinstance(spec.cm_chunk, int) else _calls_within(spec.cm_chunk, p0, pn)
-                lab_stats_device(lab_full[p0:p0 + pn], calls, out=img_ms_full[p0:p0 + pn])
-                if kernel_events is not None:
-                    t1.record()
-                    kernel_events.append(("tstats", t0, t1, pn))
-                if overlap:
-                    e2 = torch.cuda.Event()
-                    e2.record(side)
-                    done.append(e2)
-        if not aligned:
-            if kernel_events is not None:
-                t0, t1 = HipEvent(), HipEvent()
-                t0.record()
-            lab_stats_device(lab_full, spec.cm_chunk, out=img_ms_full)
-            if kernel_events is not None:
-                t1.record()
-                kernel_events.append(("tstats", t0, t1, F))
-        if spec.cm_ref_event is not None:
-            main.wait_event(spec.cm_ref_event)
-    elif spec.colormatch is not None and spec.cm_ref_event is not None:
-        torch.cuda.current_stream().wait_event(spec.cm_ref_event)
-    for ip, (f0, nf, plan, coff) in enumerate(pieces):
+                kernel_events.append(("stats", s0, s1, nf))
+        if kernel_events is not None:
+            t0, t1 = HipEvent(), HipEvent()
+            t0.record()
+        img_ms_full = lab_stats_device(lab_full, spec.cm_chunk)
+        if kernel_events is not None:
+            t1.record()
+            kernel_events.append(("tstats", t0, t1, F))
+    if spec.colormatch is not None and spec.cm_ref_event is not None:
+        torch.cuda.current_stream().wait_event(spec.cm_ref_event)          # reference_stats_async: ref_ms is valid from here on
+    for f0, nf, plan in segments:
         keep = []
         d = _chain_desc(spec, plan, keep, x)
-        if plan is not None:
-            d.noise.chunk0 += coff
         if d.stages == 0:
             out[f0:f0 + nf] = x[f0:f0 + nf]
             continue
@@ -885,8 +810,6 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         if d.stages & _hip.STAGE_COLORMATCH:
             if d.ref_frames != 1 and (nf % d.ref_frames or f0 % d.ref_frames):
                 raise RuntimeError("reference_image batch must be 1 or divide the frame batch")
-            if device_stats and done:
-                torch.cuda.current_stream().wait_event(done[ip])
             if device_stats:
                 src = C.c_void_p(lab_full.data_ptr() + f0 * fe * 4)
                 d.stages = (d.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
