@@ -108,7 +108,7 @@ class ColorMatchToReference:
                 for b in sizes:
                     expand += [f] * n_ref if b == 1 else list(range(f, f + b))
                     f += b
-        ref_ms = ops.reference_stats(ref)
+        ref_ms, ref_ready = ops.reference_stats_async(ref)      # side stream: only the apply pass of the first group waits for it
         # The statistics of a chunk are ONE torch reduction call over its frames (nodes.py:109-110): the call sizes shape the
         # device statistics (ops.CM_STATS), so every piece streamed through the GPU is made of whole calls.
         if n_ref == 1:
@@ -130,7 +130,8 @@ class ColorMatchToReference:
             group = n_ref
 
         def run(gpu_frames, first):
-            return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])))
+            return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
+                                   ref_event=ref_ready)
 
         if expand is not None:
             images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]

@@ -615,17 +615,21 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
 
 @_on_device
 def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
-                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None, cm_chunk=1, cm_stats=None) -> torch.Tensor:
+                ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None, cm_chunk=1, cm_stats=None,
+                ref_event=None) -> torch.Tensor:
     """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124).  Two passes over HBM:
     statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain.  `cm_chunk`: frames per statistics
     call of the reference (the node's batch_size, or the list of call sizes) -- it shapes the device statistics like it shapes
-    the reference's (CM_STATS)."""
+    the reference's (CM_STATS).  `ref_event`: the event of reference_stats_async when `ref_ms` comes from it."""
     x = _check_frames(images, channels=3)
     stats = _cm_stats(cm_stats, cm_math)
     if ref_ms is None:
         ref_ms = reference_stats(reference_image.to(x.device), cm_math, stats)
     if cache_lab or stats == "device":
-        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math, cm_chunk=cm_chunk, cm_stats=stats))
+        return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math, cm_chunk=cm_chunk, cm_stats=stats,
+                                        cm_ref_event=ref_event))
+    if ref_event is not None:
+        torch.cuda.current_stream().wait_event(ref_event)
     img_ms = finalize_stats(lab_stats(x, cm_math))
     return colormatch_apply(x, img_ms, ref_ms, match_strength, cm_math)
 

@@ -749,7 +749,7 @@ def test_device_statistics_numpy_restatement_equals_torch_on_this_gpu(dev):
 
 
 @pytest.mark.parametrize("F,H,W,bs,n_ref,k", [(5, 135, 240, 2, 1, 1.0), (6, 72, 120, 4, 1, 0.35), (4, 270, 480, 1, 1, 0.8), (3, 45, 51, 3, 3, 0.6),
-                                            (7, 30, 50, 7, 1, 1.0), (2, 1080, 1920, 1, 1, 1.0)])
+                                            (7, 30, 50, 7, 1, 1.0), (2, 1080, 1920, 1, 1, 1.0), (3, 2160, 3840, 2, 1, 1.0)])
 def test_colour_match_node_is_the_device_oracle_for_every_batch_size(pkg, dev, F, H, W, bs, n_ref, k):
     """The statistics depend on batch_size in the reference (one reduction call per chunk); so do ours: node == device oracle,
     bit for bit, for every chunking including ragged last chunks and odd frame sizes."""
@@ -939,7 +939,7 @@ def test_fused_chain_with_colour_match(ops, dev, variant):
     x = _rand((4, 48, 80, 3), 61)
     ref = _rand((1, 30, 30, 3), 62)
     xd = x.to(dev)
-    ref_ms = ops.finalize_stats(ops.lab_stats(ref.to(dev)))
+    ref_ms = ops.reference_stats(ref.to(dev))
     spec = ops.ChainSpec(grain=(0.04, 0.5, 2), lut=(dlut, 10.0), colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.5, False), variant=variant)
     torch.manual_seed(5)
     fused = ops.fused_chain(xd, spec)
@@ -948,9 +948,20 @@ def test_fused_chain_with_colour_match(ops, dev, variant):
     y = ops.lut3d(y, dlut, 10.0)
     y = ops.color_match(y, None, 0.9, ref_ms=ref_ms)
     y = ops.stencil3x3(y, "unsharp", 0.5, False)
-    # the fused pass-1 (shared-Philox kernel) and the stand-alone statistics kernel add the same fp64 terms in a
-    # different order: the fp32 mean/std agree except when a sum sits on a rounding boundary (~1e-6 of cases)
-    assert (fused - y).abs().max() <= 1e-6, "fused 4-stage vs sequential kernels"
+    assert_bit_equal(fused, y, "fused 4-stage vs sequential kernels (device statistics: the same reductions over the same Lab image)")
+    # with the fp64 statistics the fused pass 1 (shared-Philox kernel) and the stand-alone statistics kernel add the same fp64 terms
+    # in a different order: the fp32 mean/std agree except when a sum sits on a rounding boundary (~1e-6 of cases)
+    import dataclasses
+    ref64 = ops.reference_stats(ref.to(dev), cm_stats="fp64")
+    spec64 = dataclasses.replace(spec, colormatch=(ref64, 0.9), cm_stats="fp64")
+    torch.manual_seed(5)
+    fused64 = ops.fused_chain(xd, spec64)
+    torch.manual_seed(5)
+    y64 = ops.stencil3x3(ops.color_match(ops.lut3d(ops.film_grain(xd, 0.04, 0.5, chunk_frames=2), dlut, 10.0), None, 0.9, ref_ms=ref64, cm_stats="fp64"),
+                         "unsharp", 0.5, False)
+    assert (fused64 - y64).abs().max() <= 1e-6, "fused 4-stage vs sequential kernels, fp64 statistics"
+    torch.manual_seed(5)
+    assert_bit_equal(ops.fused_chain(xd, spec64, cache_lab=False), fused64, "Lab-caching vs recomputing two-pass forms (fp64 statistics)")
     torch.manual_seed(5)
     recompute = ops.fused_chain(xd, spec, cache_lab=False)          # 36 B/px form: grain/LUT/Lab evaluated in both passes
     assert_bit_equal(recompute, fused, "Lab-caching vs recomputing two-pass forms")
@@ -962,8 +973,9 @@ def test_fused_chain_with_colour_match(ops, dev, variant):
     o = R.apply_lut_with_strength(o, data, 10.0)
     o = R.color_match(o.to(dev), ref.to(dev), 0.9, 1).cpu()         # the colour match of the reference, evaluated on the device
     o = R.unsharp(o, 0.5, False)
-    d = _unit_ulps(fused, o)
-    _record("e2e.fused_chain4_vs_device_oracle", d)
+    assert_bit_equal(fused, o, "grain -> LUT -> colour match -> unsharp vs the oracle (colour match evaluated by torch on the device)")
+    d = _unit_ulps(fused64, o)
+    _record("e2e.fused_chain4_fp64stats_vs_device_oracle", d)
     assert d <= 2 * CM_E2E_DEVICE_ULP, d                            # unsharp at 0.5 amplifies a difference by <= 1 + 2*0.5*(8/9)
 
 
