@@ -512,6 +512,37 @@ def _chunk_runs(frames: int, chunks) -> list:
     return runs
 
 
+_TS_CHECKED = set()
+
+
+def _device_stats_selfcheck(device) -> None:
+    """Once per device and process: the replayed reductions against THIS torch build's `mean` / `std` on a small probe (two call
+    shapes).  The replay follows torch 2.10.0+rocm7.0's reduce_kernel; another build may pick another geometry or contraction -- then
+    the node is no longer bit-equal to the reference run under that build (it stays within the statistics band, ~20 ulp(1.0)), and
+    that is worth a warning rather than silence."""
+    key = torch.device(device).index
+    if key in _TS_CHECKED:
+        return
+    _TS_CHECKED.add(key)
+    g = torch.Generator().manual_seed(20260926)
+    probe = (torch.rand((3, 24, 40, 3), generator=g) * 100.0 - 30.0).to(device)
+    ok = True
+    for calls in (1, 3):
+        got = torch.empty((3, 3, 2), dtype=torch.float32, device=device)
+        _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), 3, 24, 40, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
+                   "vrg_lab_stats_torch_f32")
+        want = []
+        for i in range(0, 3, calls):
+            t = probe[i:i + calls].permute(0, 3, 1, 2).contiguous()
+            want.append(torch.stack([t.mean(dim=[2, 3]), t.std(dim=[2, 3])], dim=-1))
+        ok = ok and torch.equal(got, torch.cat(want, dim=0))
+    if not ok:
+        import warnings
+        warnings.warn(f"comfyui-vrgamedevgirl_amd: torch {torch.__version__} reduces mean()/std() in another order than the one this "
+                      "library replays (torch 2.10.0+rocm7.0): ColorMatchToReference stays within a few ulp of the reference instead of "
+                      "bit-equal to it", RuntimeWarning)
+
+
 @_on_device
 def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 ``[F, 3, 2]`` = (mean, unbiased std + eps) of an interleaved Lab image ``[F,H,W,3]`` with the BITS
@@ -525,6 +556,8 @@ def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Option
         if int(out.shape[0]) != F:
             raise ValueError("statistics output must hold one [3, 2] record per frame")
     fe = H * W * 3
+    if F:
+        _device_stats_selfcheck(x.device)
     for f0, nf, c in _chunk_runs(F, chunks):
         _hip.check(_hip.lib().vrg_lab_stats_torch_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c,
                                                      C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps), _hip.current_stream()),

@@ -736,6 +736,15 @@ def test_device_statistics_of_a_call_beyond_32bit_indexing(ops, dev):
     assert _same_bits_or_nan(ops.lab_stats_device(lab23, 23), _torch_reductions(lab23, 23))
 
 
+def test_device_statistics_selfcheck_is_silent_on_this_torch_build(ops, dev):
+    import warnings
+    ops._TS_CHECKED.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ops.lab_stats_device(torch.rand((2, 8, 8, 3), device=dev), 1)
+    assert dev.index in ops._TS_CHECKED or 0 in ops._TS_CHECKED
+
+
 def test_device_statistics_numpy_restatement_equals_torch_on_this_gpu(dev):
     """oracle/torch_device_reduce.py (the CPU restatement the -m 'not gpu' suite checks against the committed ground truth) against
     torch on the device, on fresh data."""

@@ -213,3 +213,48 @@ def test_opening_match_host_terms_cube_and_weight(pkg):
         for k in (0, 3, 29, 1000):
             got = WR._opening_color_match_weight(k, 30.0, m["strength"], m["fade_seconds"])
             assert got == R.opening_match_weight(k, 30.0, m["strength"], m["fade_seconds"])
+
+
+def test_statistics_call_runs(pkg):
+    """ops._chunk_runs: frames per reference statistics call (an int = the node's batch_size with a ragged last call, or the explicit
+    list of call sizes) -> runs of equally sized calls, one library call each."""
+    from comfyui_vrgamedevgirl_amd import ops
+    assert ops._chunk_runs(10, 4) == [(0, 10, 4)]                 # the library takes the ragged tail itself
+    assert ops._chunk_runs(0, 3) == []
+    assert ops._chunk_runs(5, [2, 2, 1]) == [(0, 4, 2), (4, 1, 1)]
+    assert ops._chunk_runs(7, [3, 1, 1, 1, 1]) == [(0, 3, 3), (3, 4, 1)]
+    assert ops._chunk_runs(6, [1, 2, 2, 1]) == [(0, 1, 1), (1, 4, 2), (5, 1, 1)]
+    for bad in ([2, 2], [3, 0, 2], 0):
+        with pytest.raises(ValueError):
+            ops._chunk_runs(5, bad)
+
+
+def test_colour_match_node_hands_whole_statistics_calls_to_every_piece(pkg, monkeypatch):
+    """ColorMatchToReference.match_color: the pieces streamed through the GPU consist of whole batch_size calls, and a one-frame
+    chunk broadcast against n_ref references becomes n_ref one-frame calls (control flow only: the ops are stubbed)."""
+    from comfyui_vrgamedevgirl_amd import nodes, ops
+    seen = []
+    monkeypatch.setattr(nodes, "compute_device", lambda: torch.device("cpu"))
+    monkeypatch.setattr(ops, "reference_stats_async", lambda ref, *a, **k: (torch.zeros((ref.shape[0], 3, 2)), None))
+
+    def fake_color_match(frames, _ref, k, ref_ms=None, cm_chunk=1, ref_event=None, **kw):
+        seen.append((int(frames.shape[0]), cm_chunk))
+        return frames
+
+    monkeypatch.setattr(ops, "color_match", fake_color_match)
+
+    def grouped(images, fn, multiple_of=1):            # pieces of at most 2 * multiple_of frames
+        step = 2 * multiple_of
+        return torch.cat([fn(images[s:s + step], s) for s in range(0, images.shape[0], step)], dim=0)
+
+    monkeypatch.setattr(nodes, "_run_grouped", grouped)
+    node = nodes.ColorMatchToReference()
+    x = torch.zeros((7, 4, 4, 3))
+    node.match_color(x, torch.zeros((1, 4, 4, 3)), 1.0, 3)
+    assert seen == [(6, 3), (1, 3)]                                          # int batch_size per piece; the last piece holds the remainder
+    seen.clear()
+    (out,) = node.match_color(x, torch.zeros((3, 4, 4, 3)), 1.0, 3)           # chunks 3, 3, 1 -> the single frame is matched to 3 references
+    assert out.shape[0] == 9 and seen == [(6, [3, 3]), (3, [1, 1, 1])]
+    seen.clear()
+    (out,) = node.match_color(x[:2], torch.zeros((3, 4, 4, 3)), 1.0, 1)       # one-frame chunks: 3 calls of one frame each, per frame
+    assert out.shape[0] == 6 and seen == [(6, [1] * 6)]
