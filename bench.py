@@ -339,7 +339,9 @@ def main():
         passes.setdefault(name, []).append(a.elapsed_ms(b))
     pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (segments of a step added up)
     algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}                      # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
-    kern_names = {"stats": "k_produce_lab (grain->LUT->Lab pass 1: shared Philox, stores Lab, per-frame statistics)",
+    kern_names = {"stats": ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it "
+                            "by k_tstats_frame)" if "grain" in stages else
+                            "k_lab_partials, Lab-only form (rgb->Lab pass 1, stores the Lab image; the statistics are reduced from it by k_tstats_frame)"),
                   "tstats": "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)",
                   "apply": "k_chain_tile<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, LDS tile)" if "colormatch" in stages
                   else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
