@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default 256; 128 for the 1080p workload)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: BASELINE's 256; 128 for the 1080p workload, 512 for colour match alone)")
     ap.add_argument("--workload", default="chain4_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--dist", default="uniform", choices=["uniform", "video"], help="synthetic pixel distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,7 +239,7 @@ def main():
             raise SystemExit("bench.py: RCCL process group did not come up with the requested world size")
     dev = torch.device("cuda", torch.cuda.current_device())
     H, W, stages = WORKLOADS[args.workload]
-    frames = args.frames or (128 if H == 1080 else 256)
+    frames = args.frames or {"grain_lut_1080p": 128, "colormatch_4k": 512}.get(args.workload, 256)      # BASELINE.json configs[1..4]
     chunk = 4
 
     lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
