@@ -769,7 +769,8 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     and (cache_lab=True) stored as a Lab image, (2) match -> Lab->RGB -> sharpen on that Lab image.  With
     cache_lab=False pass 2 re-evaluates grain/LUT/Lab from the input instead (36 B/px instead of 48 B/px of HBM
     traffic, but the gathers and powers twice); both forms give bit-identical results.  `lab_workspace` may
-    supply the fp32 buffer (same shape as images)."""
+    supply the fp32 buffer (same shape as images).  With the device statistics (CM_STATS, the default) the statistics are torch's
+    own reductions over the stored Lab image, per `spec.cm_chunk` frames: that form always keeps the Lab image (cache_lab is moot)."""
     u8 = isinstance(images, torch.Tensor) and images.dtype == torch.uint8       # decoded BGR frames (video routes)
     x = _check_frames(images, channels=3, dtype=torch.uint8 if u8 else torch.float32)
     if u8 and spec.colormatch is not None:
