@@ -31,13 +31,13 @@ def _strength_widget():
 
 def _graded(image, lut_data, requested_device, strength):
     """Shared tail of both nodes: resolve device, run the kernel, hand the result back on image.device."""
-    target = VRGDG_LUTS._resolve_device(requested_device, image)
-    dev_lut = ops.upload_lut(lut_data, target)
     if isinstance(image, torch.Tensor) and image.dtype in (torch.float16, torch.bfloat16):
         # the reference grades half-precision images in fp32 and casts the RGB result back (IV_Adjustments.py:293, 341-342);
         # its partial-strength blend then runs in the image's dtype -- here the blend is fp32 as well, rounded once at the end.
         # (float64 images are promoted to an fp64 evaluation by the reference: not offered, ops.lut3d raises.)
         return _graded(image.to(torch.float32), lut_data, requested_device, strength).to(image.dtype)
+    target = VRGDG_LUTS._resolve_device(requested_device, image)
+    dev_lut = ops.upload_lut(lut_data, target)
     if image.device.type == "cpu" and image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0:
         # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames)
         return stream_frames(image, lambda frames, _first: ops.lut3d(frames, dev_lut, strength))

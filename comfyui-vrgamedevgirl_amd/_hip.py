@@ -69,6 +69,7 @@ _SIGNATURES = {
     "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
     "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
+    "vrg_debug_copy_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
     "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,

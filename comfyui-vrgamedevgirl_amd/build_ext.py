@@ -101,7 +101,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl"]      # vrg_collective.hip: dlopen / dlsym (RCCL at run time)
     if verbose:
         print("[vrgdg-amd] linking:", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

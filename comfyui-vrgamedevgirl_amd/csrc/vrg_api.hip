@@ -228,6 +228,50 @@ __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ i
 
 namespace vrg {
 
+// Streaming-copy ceiling: out[i] = in[i], 16 B per lane.  The practical HBM roofline every streaming kernel of this library is
+// priced against (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy).
+//  mode 0: one float4 per thread, plain loads / stores        mode 1: the same with the non-temporal hint on both sides
+//  mode 2: four float4 per thread (one 64-B run per lane would break coalescing: the four are a workgroup-stride apart), non-temporal
+//  mode 3: read only (sum into one float per workgroup)          mode 4: write only
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dbg_copy(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t n4) {
+    if (MODE == 0 || MODE == 1) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= n4) return;
+        if (MODE == 0) out[i] = in[i];
+        else {
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(in) + i);
+            __builtin_nontemporal_store(v, reinterpret_cast<v4*>(out) + i);
+        }
+    } else if (MODE == 2) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+        v4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j * 256 < n4) v[j] = __builtin_nontemporal_load(reinterpret_cast<const v4*>(in) + base + j * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j * 256 < n4) __builtin_nontemporal_store(v[j], reinterpret_cast<v4*>(out) + base + j * 256);
+    } else if (MODE == 3) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (base + j * 256 < n4) {
+                const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(in) + base + j * 256);
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        if (acc == 12345.678f) reinterpret_cast<float*>(out)[blockIdx.x] = acc;      // keeps the loads alive, writes (almost) never
+    } else {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < n4) __builtin_nontemporal_store(v4{1.0f, 2.0f, 3.0f, 4.0f}, reinterpret_cast<v4*>(out) + i);
+    }
+}
+
 // Issue-rate probe: every lane runs `iters` passes over 64 independent-enough instructions of one kind (8 chains x 8),
 // nothing else in the loop but the counter.  The measured lane-instructions per second are the VALU roofline the fused
 // chains are priced against in DESIGN.md (they are issue bound, not HBM bound).
@@ -300,6 +344,27 @@ int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode,
         case 5: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<5>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         case 6: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<6>, dim3(blocks), dim3(256), 0, st, out, iters); break;
         default: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<7>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    }
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
+int vrg_debug_copy_f32(const float* in, float* out, int64_t n_floats, int32_t mode, void* stream) {
+    if (!in || !out || n_floats <= 0 || (n_floats & 3) || mode < 0 || mode > 4) return VRG_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) return VRG_ERR_BAD_ARG;
+    const int64_t n4 = n_floats / 4;
+    const int64_t per_block = (mode == 2 || mode == 3) ? 1024 : 256;
+    const uint64_t blocks = (uint64_t)((n4 + per_block - 1) / per_block);
+    if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
+    const vrg::f32x4* src = reinterpret_cast<const vrg::f32x4*>(in);
+    vrg::f32x4* dst = reinterpret_cast<vrg::f32x4*>(out);
+    hipStream_t st = (hipStream_t)stream;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(vrg::k_dbg_copy<0>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n4); break;
+        case 1: hipLaunchKernelGGL(vrg::k_dbg_copy<1>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n4); break;
+        case 2: hipLaunchKernelGGL(vrg::k_dbg_copy<2>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n4); break;
+        case 3: hipLaunchKernelGGL(vrg::k_dbg_copy<3>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n4); break;
+        default: hipLaunchKernelGGL(vrg::k_dbg_copy<4>, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n4); break;
     }
     VRG_CHECK_LAUNCH();
     return VRG_OK;

@@ -791,7 +791,12 @@ VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
     for (int i = first; i < ZIV_TABLE_WORDS; i += stride) dst[i] = f32_from_bits(VRG_ZIV_LOGT[i >> 2][i & 3]);
 }
 
-// (Lh, Ll) = ln x for a normal positive x; T = the table in LDS
+// (Lh, Ll) = ln x for a normal positive x; T = the table in LDS.  The pair is NOT normalised (Lh is not the rounded head: |Ll| can
+// reach 2^-20 |Lh|): its only consumer is the double-word product y * (Lh + Ll) of ziv_try, which does not need that, and the
+// three operations of the final renormalisation are saved.  Both two-sums use the three-operation form where its ordering
+// condition holds for every argument: |e ln2 + T_j| >= |r - r^2/2| whenever the former is not zero (e != 0: >= 0.28; e == 0: the
+// table's smallest non-zero |T_j| is 0.0078 against max |r| 0.0051 in those intervals -- asserted for every (e, j) by
+// tools/make_ziv_log_table.py), and |r| >= r^2/2.
 VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out) {
     const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
     const float ef = (float)(d >> 23);
@@ -803,25 +808,23 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
     const float Eh = ef * f32_from_bits(0x3f317200u);                // e * ln2 head (15 bits: exact product)
     const float h = r * r;
     const float l = __builtin_fmaf(r, r, -h);                        // r^2 = h + l
-    const float nh = -0.5f * h;
     float P = __builtin_fmaf(r, (float)(-1.0 / 6.0), 0.2f);
     P = __builtin_fmaf(r, P, -0.25f);
     P = __builtin_fmaf(r, P, (float)(1.0 / 3.0));
     const float tail = __builtin_fmaf(-0.5f, l, (h * r) * P);        // -l/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
     const float s1 = Eh + th;                                        // |Eh| >= 0.69 > |th|, or Eh = 0: fast two-sum
     const float e1 = th - (s1 - Eh);
-    const float s2 = r + nh;                                         // |r| >= |r^2 / 2|
-    const float e2 = nh - (s2 - r);
-    const float s3 = s1 + s2;                                        // no ordering: two-sum
-    const float bb = s3 - s1;
-    const float e3 = (s1 - (s3 - bb)) + (s2 - bb);
+    const float s2 = __builtin_fmaf(-0.5f, h, r);                    // r - h/2 (h/2 is exact): |r| >= |h/2|, fast two-sum
+    const float e2 = __builtin_fmaf(-0.5f, h, r - s2);               // (-h/2) - (s2 - r)
+    const float s3 = s1 + s2;                                        // s1 = 0 or |s1| >= |s2|: fast two-sum
+    const float e3 = s2 - (s3 - s1);
     float low = __builtin_fmaf(ef, f32_from_bits(0x35bfbe8eu), tl);  // e * (ln2 - head) + T_lo
     low = low + e1;
     low = low + e3;
     low = low + e2;
     low = low + tail;
-    Lh = s3 + low;
-    Ll = low - (Lh - s3);
+    Lh = s3;
+    Ll = low;
     Eh_out = Eh;
 }
 
@@ -845,12 +848,13 @@ VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t
     const float p24 = __builtin_fmaf(y, Lh, -p17);
     const float p44 = __builtin_fmaf(y, Ll, p24);
     const float delta = ziv_delta(y, Lh, Eh);
-    const float php = p17 + (p44 + delta);
-    const float phm = p17 + (p44 - delta);
-    const float pl = p44 - (php - p17);
+    const float up = p44 + delta, dn = p44 - delta;
+    const float php = p17 + up;
+    const float phm = p17 + dn;
+    const float t = php - p17;                                       // exact; ocml's tail is y ln x - head = (p44 -+ ...) - t
     const float e8 = dev_exp_core(php);
-    const float rp = __builtin_fmaf(e8, pl + delta, e8);
-    const float rm = __builtin_fmaf(e8, pl - delta, e8);
+    const float rp = __builtin_fmaf(e8, up - t, e8);
+    const float rm = __builtin_fmaf(e8, dn - t, e8);
     out = rp;
     return ((f32_bits(x) - lo_bits) <= (hi_bits - lo_bits)) & (php == phm) & (rp == rm);      // bitwise: no control flow here
 }

@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void k_noise(float* __restrict__ out, NoiseK n
 // neighbours outside the block's range (per sibling range) are produced by the general per-element
 // routine on 8 lanes.
 // ----------------------------------------------------------------------------------------------
+#ifndef VRG_GRAIN_NT
+#define VRG_GRAIN_NT 0
+#endif
 constexpr int GRAIN_IPT = 4;                    // subsequences per thread
 constexpr int GRAIN_N = 256 * GRAIN_IPT;        // subsequences per block
 
@@ -66,6 +69,29 @@ __global__ __launch_bounds__(256) void k_grain(const void* __restrict__ in_, voi
     const uint64_t seed = chunk_seed(nk, chunk);
     const uint64_t off = chunk_offset(nk, chunk);
     const uint64_t ctr = (off >> 2) + k;
+
+    // the frame data of this thread's four element quads is requested BEFORE the Philox rounds: the ~700 instructions of noise
+    // synthesis then run under the HBM latency instead of in front of it (VEC form; the ragged forms load below)
+    const int64_t group_base0 = (int64_t)4 * G * k + idx_base;
+    float4 pre[4];
+    bool pre_ok[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const int64_t li0 = group_base0 + (int64_t)G * ii + t4;
+        pre_ok[ii] = VEC && !U8 && t4 < valid_n && li0 + 3 < chunk_numel;
+        if (VEC && !U8) {       // branch-free: lanes with nothing to load re-read the chunk's first quad (the result is not used)
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            const v4* src = reinterpret_cast<const v4*>(in + chunk * chunk_numel + (pre_ok[ii] ? li0 : 0));
+#if VRG_GRAIN_NT
+            const v4 v = __builtin_nontemporal_load(src);
+#else
+            const v4 v = *src;
+#endif
+            pre[ii] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            pre[ii] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
 
     float nz[GRAIN_IPT][4];
 #pragma unroll
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(256) void k_grain(const void* __restrict__ in_, voi
                 cc = (cc == 2) ? 0 : cc + 1;
             }
         } else if (VEC && full) {
-            const float4 v = *reinterpret_cast<const float4*>(cin + li0);
+            const float4 v = pre[ii];          // == pre_ok[ii]: requested before the Philox rounds
             x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
         } else {
 #pragma unroll
@@ -134,7 +160,12 @@ __global__ __launch_bounds__(256) void k_grain(const void* __restrict__ in_, voi
                 cc = (cc == 2) ? 0 : cc + 1;
             }
         } else if (VEC && full) {
+#if VRG_GRAIN_NT
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4*>(cout + li0));
+#else
             *reinterpret_cast<float4*>(cout + li0) = make_float4(o[0], o[1], o[2], o[3]);
+#endif
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

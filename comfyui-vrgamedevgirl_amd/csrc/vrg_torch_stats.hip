@@ -37,9 +37,12 @@ static int ts_last_pow2(int n) {
 }
 static int64_t ts_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// setReduceConfig for iter.ndim() == 2, reduction over the contiguous fastest dimension, 256 CUs, warp 64, 512 threads max.
-// false: a geometry with ctas_per_output > 1 (not reachable for >= 2 outputs; kept as a guard).
-static bool ts_config(int64_t num_outputs, int64_t n, int vec, TsCfg& c) {
+// setReduceConfig for iter.ndim() == 2, reduction over the contiguous fastest dimension, warp 64, 512 threads max.
+// false: a geometry with ctas_per_output > 1 (not reachable for >= 2 outputs; kept as a guard).  `num_mp` = the device's CU count
+// (256 on the MI355X): it enters only through target_grid_size = num_mp * (max_threads_per_mp / block threads), and ROCm's cap of
+// max_threads_per_mp = 256 for 2-dim iterators makes that 0 for the 512-thread blocks of every call with more than one output --
+// the geometry of the calls this file replays is therefore the same on any CU count (a compute-partitioned MI355X, another gfx950 SKU).
+static bool ts_config(int64_t num_outputs, int64_t n, int vec, TsCfg& c, int num_mp = 256) {
     int64_t dim0 = n;
     c.vectorize = dim0 >= 128;
     if (c.vectorize) dim0 /= vec;
@@ -55,7 +58,7 @@ static bool ts_config(int64_t num_outputs, int64_t n, int vec, TsCfg& c) {
     const int64_t step_in = (int64_t)bw * (c.split ? bh : 1), step_out = c.split ? 1 : bh;
     const int64_t grid_x = ts_div_up(num_outputs, step_out);
     const int max_tpm = grid_x == 1 ? 2048 : 256;          // `grid.x == grid.y == grid.z == 1` as C evaluates it
-    const int64_t target = 256 * (int64_t)(max_tpm / (bw * bh));
+    const int64_t target = (int64_t)num_mp * (int64_t)(max_tpm / (bw * bh));
     vpt = ts_div_up(n, step_in);
     if (c.split && vpt >= 256 && grid_x <= target) {
         const int64_t c1 = ts_div_up(target, grid_x), c2 = ts_div_up(vpt, 16), c3 = ts_div_up(vpt, 256);
@@ -369,20 +372,22 @@ __global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ 
 }
 
 // planes [o0, o1) of one reference call: the sub-iterators TensorIterator::with_32bit_indexing would produce (depth first, first half =
-// floor(size / 2)) when the call's tensor has more than 2^29 elements; each has its own geometry and mean factor
-static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_t o1, int chunk_frames, float eps, float* out_call,
-                            hipStream_t st) {
+// floor(size / 2)) when the call's tensor has more than 2^29 elements; each has its own geometry
+// (the mean factor is NOT per sub-iterator: mean_kernel_impl forms float(num_output_elements) / numel once from the whole call and
+// gpu_reduce_kernel hands the same `ops` to every sub_iter, Reduce.cuh:1273-1279 -- (float)O_sub / (float)(O_sub * n) differs from it
+// by one ulp whenever O * n is not an fp32 number, e.g. 87 x 1079 x 1919 frames)
+static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_t o1, int chunk_frames, float factor, float eps, float* out_call,
+                            int num_mp, hipStream_t st) {
     const int64_t O = o1 - o0;
     if (O * n > ((int64_t)1 << 29) && O > 1) {
         const int64_t half = O / 2;
-        int rc = ts_launch_planes(lab_call, n, o0, o0 + half, chunk_frames, eps, out_call, st);
+        int rc = ts_launch_planes(lab_call, n, o0, o0 + half, chunk_frames, factor, eps, out_call, num_mp, st);
         if (rc != VRG_OK) return rc;
-        return ts_launch_planes(lab_call, n, o0 + half, o1, chunk_frames, eps, out_call, st);
+        return ts_launch_planes(lab_call, n, o0 + half, o1, chunk_frames, factor, eps, out_call, num_mp, st);
     }
     if (O * n > ((int64_t)1 << 29)) return VRG_ERR_UNSUPPORTED;      // a single plane beyond 32-bit indexing: torch splits the reduction itself
     TsCfg cm, cw;
-    if (!ts_config(O, n, 4, cm) || !ts_config(O, n, 2, cw)) return VRG_ERR_UNSUPPORTED;
-    const float factor = (float)O / (float)(O * n);                  // static_cast<float>(num_output_elements) / numel
+    if (!ts_config(O, n, 4, cm, num_mp) || !ts_config(O, n, 2, cw, num_mp)) return VRG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)O), dim3(512), 0, st, lab_call, n, o0, chunk_frames, cm, factor, eps, out_call);
     hipLaunchKernelGGL((k_tstats_plane<WelfOp, 1>), dim3((unsigned)O), dim3(512), 0, st, lab_call, n, o0, chunk_frames, cw, factor, eps, out_call);
     VRG_CHECK_LAUNCH();
@@ -395,19 +400,19 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
 constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
-static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, hipStream_t st) {
+static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, int num_mp, hipStream_t st) {
     if (count <= 0 || b <= 0) return VRG_OK;
     const int64_t O = (int64_t)b * 3;
+    const float factor = (float)O / (float)(O * n);                  // static_cast<float>(num_output_elements) / numel, of the WHOLE call
     if (O * n > ((int64_t)1 << 29)) {
         for (int64_t k = 0; k < count; ++k) {
-            const int rc = ts_launch_planes(lab + (size_t)k * b * n * 3, n, 0, O, b, eps, out + (size_t)k * b * 6, st);
+            const int rc = ts_launch_planes(lab + (size_t)k * b * n * 3, n, 0, O, b, factor, eps, out + (size_t)k * b * 6, num_mp, st);
             if (rc != VRG_OK) return rc;
         }
         return VRG_OK;
     }
     TsCfg cm, cw;
-    if (!ts_config(O, n, 4, cm) || !ts_config(O, n, 2, cw)) return VRG_ERR_UNSUPPORTED;
-    const float factor = (float)O / (float)(O * n);
+    if (!ts_config(O, n, 4, cm, num_mp) || !ts_config(O, n, 2, cw, num_mp)) return VRG_ERR_UNSUPPORTED;
     const int64_t frames = count * b;
     const bool whole = (n % 4 == 0) && cm.vectorize && cw.vectorize && cm.split && cw.split && cm.bw * cm.bh == 512 && cw.bw * cw.bh == 512 &&
                        cm.bw == cw.bw;
@@ -441,15 +446,19 @@ extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return VRG_ERR_NO_DEVICE;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return VRG_ERR_NO_DEVICE;
-    if (cus != 256) return VRG_ERR_UNSUPPORTED;        // the geometry above is the MI355X's (256 CUs); other parts pick other grids
+    // The CU count enters torch's geometry twice: target_grid_size (inert here, see ts_config) and `force_splitting_output`, which
+    // setReduceConfig only considers on devices with fewer than 100 CUs (a CPX-partitioned MI355X has 32): not replayed, the host falls
+    // back to the fp64 statistics there (ops._cm_stats).
+    if (cus <= 0) return VRG_ERR_NO_DEVICE;
+    if (cus < 100) return VRG_ERR_UNSUPPORTED;
     const int64_t n = (int64_t)height * width;
     if (frames * 3 > 0x7fffffff / 2) return VRG_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int64_t full = frames / chunk_frames;
     const int tail = (int)(frames % chunk_frames);
-    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, st);
+    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, cus, st);
     if (rc != VRG_OK) return rc;
-    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, st);
+    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, st);
     return rc;
 }
 

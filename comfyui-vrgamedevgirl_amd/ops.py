@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -51,9 +52,34 @@ def _cm_math(value) -> int:
 CM_STATS = ("device", "fp64")
 
 
-def _cm_stats(value, cm_math) -> str:
+_NO_DEVICE_STATS_WARNED = set()
+_STATE_LOCK = threading.Lock()          # guards the small per-process caches below (first-use races between host threads)
+
+
+def device_stats_supported(device) -> bool:
+    """Can csrc/vrg_torch_stats.hip replay torch's reductions on this GPU?  torch's setReduceConfig takes another branch
+    (force_splitting_output) on devices with fewer than 100 CUs -- e.g. one CPX partition of an MI355X; vrg_lab_stats_torch_f32 returns
+    VRG_ERR_UNSUPPORTED there."""
+    return torch.cuda.get_device_properties(device).multi_processor_count >= 100
+
+
+def _cm_stats(value, cm_math, device=None) -> str:
+    """Resolve the statistics policy.  An explicit value is taken as it is; the DEFAULT ("device" with the device arithmetic) falls
+    back to "fp64" with a one-time warning on a GPU whose reduction geometry is not replayed (`device` given and unsupported)."""
     if value is None:
         value = os.environ.get("VRGDG_CM_STATS", "").strip().lower() or ("device" if _cm_math(cm_math) == _hip.CM_MATH_DEVICE else "fp64")
+        if value == "device" and device is not None and torch.device(device).type == "cuda" and not device_stats_supported(device):
+            key = torch.device(device).index
+            with _STATE_LOCK:
+                first = key not in _NO_DEVICE_STATS_WARNED
+                _NO_DEVICE_STATS_WARNED.add(key)
+            if first:
+                import warnings
+                warnings.warn(f"comfyui-vrgamedevgirl_amd: {torch.cuda.get_device_name(device)} reports "
+                              f"{torch.cuda.get_device_properties(device).multi_processor_count} CUs; torch's reduction geometry is replayed for "
+                              "devices with >= 100 CUs only -- colour statistics fall back to the fp64 form (a few ulp from the reference "
+                              "run on this GPU instead of bit-equal to it)", RuntimeWarning)
+            value = "fp64"
     if value not in CM_STATS:
         raise ValueError(f"cm_stats must be one of {CM_STATS}, got {value!r}")
     return value
@@ -512,35 +538,71 @@ def _chunk_runs(frames: int, chunks) -> list:
     return runs
 
 
-_TS_CHECKED = set()
+_TS_CHECKED = {}             # device index -> True (replay == this torch build) / False
 
 
-def _device_stats_selfcheck(device) -> None:
-    """Once per device and process: the replayed reductions against THIS torch build's `mean` / `std` on a small probe (two call
-    shapes).  The replay follows torch 2.10.0+rocm7.0's reduce_kernel; another build may pick another geometry or contraction -- then
-    the node is no longer bit-equal to the reference run under that build (it stays within the statistics band, ~20 ulp(1.0)), and
-    that is worth a warning rather than silence."""
-    key = torch.device(device).index
-    if key in _TS_CHECKED:
-        return
-    _TS_CHECKED.add(key)
+def _selfcheck_planes(device):
+    """Probe tensors of the self-check: small planes for the generic (one workgroup per plane) form -- an aligned one and one whose
+    H*W is odd, so that planes start off a vector boundary -- and, for the whole-frame forms the video-sized calls take, one plane
+    per batch_size class (block (256,2) for 1, (128,4) for 2, (64,8) for >= 3) shaped like a 4K row band: long enough (>= 2 rounds of
+    2048 pixels plus a ragged tail) to run the same thread loop, lane tree and warp tree as a full frame."""
     g = torch.Generator().manual_seed(20260926)
-    probe = (torch.rand((3, 24, 40, 3), generator=g) * 100.0 - 30.0).to(device)
+    small = (torch.rand((3, 24, 40, 3), generator=g) * 100.0 - 30.0).to(device)
+    odd = (torch.rand((4, 23, 41, 3), generator=g) * 100.0 - 30.0).to(device)
+    band = (torch.rand((6, 4, 3840, 3), generator=g) * 120.0 - 40.0).to(device)          # H*W = 15,360: 7.5 rounds
+    many = (torch.rand((66, 4, 3840, 3), generator=g) * 120.0 - 40.0).to(device)        # > 64 frames: the one-workgroup-per-frame form
+    return [(small, (1, 3)), (odd, (1, 2, 4)), (band, (1, 2, 3, 6)), (many, (1,))]
+
+
+def device_stats_selfcheck(device, force: bool = False) -> bool:
+    """Once per device and process (a few ms): the replayed reductions against THIS torch build's `mean` / `std` over the call
+    geometries that matter -- every batch_size class of the whole-frame kernels, an unaligned plane, ragged last calls.  The replay
+    follows torch 2.10.0+rocm7.0's reduce_kernel; another build may pick another geometry or contraction -- then the node is no longer
+    bit-equal to the reference run under that build (it stays within the statistics band, ~20 ulp(1.0)).  Returns whether the replay
+    matched; a mismatch warns once and is reported by `device_stats_status()` so that a host can surface it next to its results."""
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    with _STATE_LOCK:
+        if key in _TS_CHECKED and not force:
+            return _TS_CHECKED[key]
     ok = True
-    for calls in (1, 3):
-        got = torch.empty((3, 3, 2), dtype=torch.float32, device=device)
-        _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), 3, 24, 40, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
-                   "vrg_lab_stats_torch_f32")
-        want = []
-        for i in range(0, 3, calls):
-            t = probe[i:i + calls].permute(0, 3, 1, 2).contiguous()
-            want.append(torch.stack([t.mean(dim=[2, 3]), t.std(dim=[2, 3])], dim=-1))
-        ok = ok and torch.equal(got, torch.cat(want, dim=0))
-    if not ok:
+    with torch.cuda.device(key):
+        for probe, call_sizes in _selfcheck_planes(torch.device("cuda", key)):
+            F, H, W, _ = probe.shape
+            for calls in call_sizes:
+                got = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
+                _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
+                           "vrg_lab_stats_torch_f32")
+                want = []
+                for i in range(0, F, calls):
+                    t = probe[i:i + calls].permute(0, 3, 1, 2).contiguous()
+                    want.append(torch.stack([t.mean(dim=[2, 3]), t.std(dim=[2, 3])], dim=-1))
+                ok = ok and torch.equal(got, torch.cat(want, dim=0))
+    with _STATE_LOCK:
+        first = key not in _TS_CHECKED
+        _TS_CHECKED[key] = ok
+    if not ok and first:
         import warnings
         warnings.warn(f"comfyui-vrgamedevgirl_amd: torch {torch.__version__} reduces mean()/std() in another order than the one this "
                       "library replays (torch 2.10.0+rocm7.0): ColorMatchToReference stays within a few ulp of the reference instead of "
-                      "bit-equal to it", RuntimeWarning)
+                      "bit-equal to it (ops.device_stats_status())", RuntimeWarning)
+    return ok
+
+
+def device_stats_status(device=None) -> dict:
+    """What a host can log next to a colour-match result: which statistics the default policy uses on `device` and whether the
+    replay of torch's reductions was verified against this torch build in this process."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if not device_stats_supported(device):
+        return {"cm_stats": "fp64", "bit_equal_to_torch": False, "reason": "fewer than 100 CUs: torch's reduction geometry is not replayed"}
+    ok = device_stats_selfcheck(device)
+    return {"cm_stats": "device", "bit_equal_to_torch": bool(ok), "torch": torch.__version__,
+            "reason": None if ok else "this torch build reduces in another order than the replayed one (torch 2.10.0+rocm7.0)"}
+
+
+def _device_stats_selfcheck(device) -> None:
+    device_stats_selfcheck(device)
 
 
 @_on_device
@@ -569,7 +631,7 @@ def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None) 
     """fp32 ``[R, 3, 2]`` (mean, std + 1e-5) of the reference frame(s) (nodes.py:98-100): one reduction call over the whole
     reference batch with the device statistics."""
     ref = _check_frames(reference_image, "reference_image", channels=3)
-    if _cm_stats(cm_stats, cm_math) == "fp64":
+    if _cm_stats(cm_stats, cm_math, ref.device) == "fp64":
         return finalize_stats(lab_stats(ref, cm_math))
     lab = torch.empty_like(ref)
     Rn, H, W, _ = ref.shape
@@ -584,11 +646,15 @@ _SIDE_STREAMS = {}
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
-    """One extra stream per device for work that is off the critical path of the frame passes: the statistics of the reference frame."""
+    """One extra stream per device for work that is off the critical path of the frame passes: the statistics of the reference frame.
+    HIGH priority: its kernels are a handful of latency-bound workgroups; on a normal-priority stream they queue behind the thousands of
+    workgroups of pass 1 (measured: 32 x 4K frames per step 11.7 ms = the passes' 9.4 ms + the reference statistics' 2.2 ms, nothing
+    hidden), a high-priority queue lets the dispatcher slot them in as soon as they are submitted."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    with _STATE_LOCK:
+        st = _SIDE_STREAMS.get(key)
+        if st is None:
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key, priority=-1)
     return st
 
 
@@ -655,7 +721,7 @@ def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_stren
     call of the reference (the node's batch_size, or the list of call sizes) -- it shapes the device statistics like it shapes
     the reference's (CM_STATS).  `ref_event`: the event of reference_stats_async when `ref_ms` comes from it."""
     x = _check_frames(images, channels=3)
-    stats = _cm_stats(cm_stats, cm_math)
+    stats = _cm_stats(cm_stats, cm_math, x.device)
     if ref_ms is None:
         ref_ms = reference_stats(reference_image.to(x.device), cm_math, stats)
     if cache_lab or stats == "device":
@@ -784,9 +850,19 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     if F == 0:
         return out
     fe = H * W * 3
-    if spec.grain is not None and plans is None and not u8 and oversize_chunks(F, fe, spec.grain[2]):
+    if spec.grain is not None and plans is not None and any(p is not None and p.chunk_frames * fe > rng.MAX_CHUNK_NUMEL for p in plans[:2]):
+        raise ValueError("fused_chain: a caller-supplied noise plan cannot describe an RNG chunk of more than 2^29 elements (torch splits "
+                         "such a randn into several kernels, rng.reserve_split); pass the generator instead of `plans`")
+    if spec.grain is not None and plans is None and oversize_chunks(F, fe, spec.grain[2]):
         # RNG chunks that torch itself splits (see _film_grain_oversize): grain as its own pass, then the rest of the chain
         import dataclasses
+        if u8:
+            # decoded uint8 frames: the same detour on the fp32 image (u8 -> f32 -> chain -> u8 equals the uint8 kernels byte for byte,
+            # tests/test_gpu_parity.py); costs two fp32 copies of the chunk on top of the noise buffer -- a > 0.5 G-element chunk of
+            # uint8 video is not a route the reference takes at speed either
+            res = fused_chain(frames_u8_to_f32(x), spec, generator=generator, kernel_events=kernel_events, cache_lab=cache_lab)
+            out.copy_(f32_to_frames_u8(res))
+            return out
         grained = film_grain(x, spec.grain[0], spec.grain[1], spec.grain[2], generator=generator)
         rest = dataclasses.replace(spec, grain=None)
         if rest.lut is None and rest.colormatch is None and rest.sharpen is None:
@@ -803,7 +879,7 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             segments.append((F - tail.chunk_frames, tail.chunk_frames, tail))
     lib = _hip.lib()
     st = _hip.current_stream()
-    device_stats = spec.colormatch is not None and _cm_stats(spec.cm_stats, spec.cm_math) == "device"
+    device_stats = spec.colormatch is not None and _cm_stats(spec.cm_stats, spec.cm_math, x.device) == "device"
     lab_full = img_ms_full = None
     if device_stats:
         # The reference's statistics are torch reductions over each batch_size call: they need the Lab image of WHOLE calls, so
@@ -898,9 +974,18 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
 # ------------------------------------------------------------------------------------------------
 
 class HipEvent:
+    """A hipEvent_t on the kernels' stream.  Handles are pooled per process: creating and destroying an event costs a driver call each
+    (bench.py brackets every pass of every step), recording a pooled one does not."""
+    _pool = {}          # device index -> free handles (an event belongs to the device it was created on)
+
     def __init__(self):
-        self._ev = C.c_void_p()
-        _hip.check(_hip.lib().vrg_event_create(C.byref(self._ev)), "vrg_event_create")
+        self._dev = torch.cuda.current_device()
+        with _STATE_LOCK:
+            free = HipEvent._pool.get(self._dev)
+            self._ev = free.pop() if free else None
+        if self._ev is None:
+            self._ev = C.c_void_p()
+            _hip.check(_hip.lib().vrg_event_create(C.byref(self._ev)), "vrg_event_create")
 
     def record(self):
         _hip.check(_hip.lib().vrg_event_record(self._ev, _hip.current_stream()), "vrg_event_record")
@@ -913,6 +998,12 @@ class HipEvent:
     def __del__(self):
         try:
             if self._ev:
-                _hip.lib().vrg_event_destroy(self._ev)
+                with _STATE_LOCK:
+                    free = HipEvent._pool.setdefault(self._dev, [])
+                    if len(free) < 256:
+                        free.append(self._ev)
+                        self._ev = None
+                if self._ev:
+                    _hip.lib().vrg_event_destroy(self._ev)
         except Exception:
             pass

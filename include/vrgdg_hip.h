@@ -325,6 +325,10 @@ int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float
  * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,
  * 6 v_cmp+v_cndmask pairs, 7 v_mul_f64/v_fma_f64); `out` = blocks*256 floats.  Measures the VALU roofline. */
 int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream);
+/* Streaming-copy ceiling: out[i] = in[i] over n_floats fp32 values (a multiple of 4; 16-byte aligned
+ * pointers), 16 B per lane.  mode 0: plain loads / stores; 1: non-temporal; 2: non-temporal, four float4 per thread; 3: read only;
+ * 4: write only (a constant).  What every streaming kernel of this library is priced against, next to the 8 TB/s spec peak. */
+int vrg_debug_copy_f32(const float* in, float* out, int64_t n_floats, int32_t mode, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

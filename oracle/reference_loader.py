@@ -7,10 +7,15 @@ has no reference checkout: nothing under ``-m gpu`` tests, ``smoke()`` or
 
 The reference's ``nodes.py`` imports ComfyUI / kornia / audio libraries at the
 top (nodes.py:5-12) that are not installed; empty ``types.ModuleType`` stubs are
-put in ``sys.modules`` for the duration of the import.  ``kornia.color`` is
+put in ``sys.modules`` for the duration of the import.  ``kornia.color``: the
+INSTALLED library is used whenever it is importable (``installed_kornia()``) --
+the fixtures of ``make_golden.py`` are then outputs of kornia itself and
+``tests/test_oracle_golden.py::test_restated_lab_equals_installed_kornia`` pins
+the restatement to it; where it is absent (this image: no index access) it is
 stubbed with the restated Lab transforms of ``oracle.restated`` so that the
 reference's *own* ``match_color`` control flow (statistics, blend, clamp,
-permute) can be executed.
+permute) can still be executed.  ``kornia_source()`` says which one was used; it
+is recorded in ``tests/golden/provenance.json``.
 """
 from __future__ import annotations
 
@@ -32,6 +37,29 @@ def reference_available() -> bool:
     return os.path.isfile(os.path.join(REFERENCE_ROOT, "nodes.py"))
 
 
+def installed_kornia():
+    """(kornia.color module, version string) of a REAL installed kornia, or None.  Never returns this file's stub."""
+    import importlib
+    for name in ("kornia.color", "kornia"):
+        mod = sys.modules.get(name)
+        if mod is not None and getattr(mod, "__vrgdg_stub__", False):
+            return None                    # called while the stubs are installed and the stub is ours: kornia is absent
+    try:
+        kc = importlib.import_module("kornia.color")
+        kornia = importlib.import_module("kornia")
+    except Exception:
+        return None
+    if getattr(kc, "__vrgdg_stub__", False) or not hasattr(kc, "rgb_to_lab") or not hasattr(kc, "lab_to_rgb"):
+        return None
+    return kc, str(getattr(kornia, "__version__", "unknown"))
+
+
+def kornia_source() -> str:
+    """What stands behind kornia.color when the reference's modules are loaded here."""
+    real = installed_kornia()
+    return f"kornia {real[1]} (installed)" if real else "restated (oracle/restated.py: kornia is not installed)"
+
+
 def _install_stubs():
     import torch
     from . import restated
@@ -44,15 +72,18 @@ def _install_stubs():
     mm.get_torch_device = lambda: torch.device("cpu")
     mm.intermediate_device = lambda: torch.device("cpu")
     comfy.model_management = mm
-    kornia = types.ModuleType("kornia")
-    kcolor = types.ModuleType("kornia.color")
-    kcolor.rgb_to_lab = restated.kornia_rgb_to_lab
-    kcolor.lab_to_rgb = restated.kornia_lab_to_rgb
-    kornia.color = kcolor
     sys.modules["comfy"] = comfy
     sys.modules["comfy.model_management"] = mm
-    sys.modules["kornia"] = kornia
-    sys.modules["kornia.color"] = kcolor
+    if installed_kornia() is None:
+        kornia = types.ModuleType("kornia")
+        kcolor = types.ModuleType("kornia.color")
+        kornia.__vrgdg_stub__ = kcolor.__vrgdg_stub__ = True
+        kcolor.rgb_to_lab = restated.kornia_rgb_to_lab
+        kcolor.lab_to_rgb = restated.kornia_lab_to_rgb
+        kornia.color = kcolor
+        sys.modules["kornia"] = kornia
+        sys.modules["kornia.color"] = kcolor
+    # else: the reference's `import kornia.color` binds the installed library
     for name in ("librosa", "torchaudio", "folder_paths", "av", "imageio"):
         if saved[name] is None:
             sys.modules[name] = types.ModuleType(name)

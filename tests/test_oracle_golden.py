@@ -113,6 +113,40 @@ def test_colour_match_control_flow():
     assert torch.equal(R.color_match(x, ref4, 0.8, 4), _t(z["out.ref4.k0.8.bs4"]))
 
 
+def _lab_probe_images():
+    """The colour-match probe set: video-like frames, the sRGB / Lab branch points and their float neighbours, 0, 1, tiny values."""
+    g = torch.Generator().manual_seed(11)
+    smooth = torch.rand(2, 3, 24, 32, generator=g)
+    low = torch.rand(1, 3, 24, 32, generator=g) * 0.06                       # around the 0.04045 sRGB knee and the 0.008856 Lab knee
+    specials = torch.tensor([0.0, 1.0, 0.04045, 0.040450003, 0.04044999, 0.0031308, 0.008856, 1e-6, 1e-3, 0.5, 0.999999, 0.2068966],
+                            dtype=torch.float32)
+    grid = torch.stack(torch.meshgrid(specials, specials, specials, indexing="ij"), 0).reshape(1, 3, 12 * 12, 12)
+    return [smooth, low, grid]
+
+
+@pytest.mark.skipif(RL.installed_kornia() is None, reason="kornia is not installed: the restated Lab transforms stay unpinned (DESIGN.md section 4)")
+def test_restated_lab_equals_installed_kornia():
+    """The pin of SURVEY.md section 8 row a8: wherever the reference's own dependency exists, the restated transforms are held to it
+    bit for bit on the CPU -- forward, inverse (on in- and out-of-gamut Lab values) and through the reference's match_color."""
+    kc, version = RL.installed_kornia()
+    for img in _lab_probe_images():
+        lab_k, lab_r = kc.rgb_to_lab(img), R.kornia_rgb_to_lab(img)
+        assert torch.equal(lab_k, lab_r), f"rgb_to_lab: restatement vs kornia {version}"
+        for scale in (1.0, 1.3):                                               # 1.3: pushes a / b out of gamut (negative linear RGB, clip)
+            assert torch.equal(kc.lab_to_rgb(lab_k * scale), R.kornia_lab_to_rgb(lab_k * scale)), f"lab_to_rgb: restatement vs kornia {version}"
+            assert torch.equal(kc.lab_to_rgb(lab_k * scale, clip=False), R.kornia_lab_to_rgb(lab_k * scale, clip=False))
+    with open(os.path.join(GOLDEN, "provenance.json")) as fh:
+        made_with = json.load(fh)["colormatch.npz"]["kornia.color"]
+    if made_with.startswith("kornia"):                                         # fixtures regenerated on a box with kornia: they ARE kornia's
+        test_colour_match_control_flow()
+
+
+def test_golden_provenance_names_the_lab_source():
+    with open(os.path.join(GOLDEN, "provenance.json")) as fh:
+        src = json.load(fh)["colormatch.npz"]["kornia.color"]
+    assert src.startswith("kornia ") or src.startswith("restated"), src
+
+
 def test_lab_restated_self_consistency():
     # kornia is absent (parity unpinned): check the published algorithm's invariants instead
     g = torch.Generator().manual_seed(5)

@@ -18,5 +18,5 @@ def one(src):
 with ThreadPoolExecutor(8) as pool:
     objs = list(pool.map(one, be.SOURCES))
 lib = os.path.join(out_dir, f"lib_{name}.so")
-subprocess.run([be._hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs, check=True)
+subprocess.run([be._hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + objs + ["-ldl"], check=True)
 print(lib)
