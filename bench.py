@@ -57,6 +57,14 @@ def parse_args():
     ap.add_argument("--no-fast-variant", action="store_true", help="skip the extra timing of the fast colour-match policy")
     ap.add_argument("--sync-ref", action="store_true", help="reference-frame statistics on the main stream in front of pass 1 (A/B of the side-stream form)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic (use profiles/)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output check after the timed region (first and last RNG chunk of rank 0 against "
+                                                             "the stand-alone operators and the device oracle)")
+    ap.add_argument("--digest", action="store_true", help="add the SHA-256 of every rank's output (per RNG chunk) to the line: equal frame ranges of "
+                                                          "runs with different GPU counts must give equal digests")
+    ap.add_argument("--same-data", action="store_true", help="frames are a function of their ABSOLUTE index in the job (rank r holds frames "
+                                                             "[r*frames, (r+1)*frames) of one job-wide batch), so that runs with different GPU counts process "
+                                                             "the same data; default: an independent batch per rank")
+    ap.add_argument("--cm-stats", default=None, choices=["device", "fp64"], help="colour statistics of the headline leg (default: device)")
     return ap.parse_args()
 
 
@@ -81,10 +89,16 @@ def self_launch(args):
     os.execvpe(sys.executable, cmd, env)
 
 
-def make_frames(n, H, W, dev, seed, dist):
+def make_frames(n, H, W, dev, seed, dist, first_frame=None):
     """Synthetic frames generated on the device.  uniform: iid U[0,1) (worst case for LUT gathers);
-    video: smooth low-frequency field + N(0, 0.02) texture, clamped (LUT-coherent like real footage)."""
+    video: smooth low-frequency field + N(0, 0.02) texture, clamped (LUT-coherent like real footage).
+    `first_frame` (--same-data): frame i is drawn from a generator seeded by its absolute index first_frame + i."""
     g = torch.Generator(device=dev).manual_seed(seed)
+    if first_frame is not None:
+        x = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
+        for i in range(n):
+            x[i] = make_frames(1, H, W, dev, seed * 1000003 + first_frame + i, dist)[0]
+        return x
     if dist == "uniform":
         x = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
         for i in range(0, n, 16):
@@ -214,6 +228,51 @@ def cpu_baseline(stages, cpu_frames, H, W, lut_cpu, per_node=False):
     return out
 
 
+def verify_output(ops, x, out, ref, lut, lut_cpu, stages, geom_stream, rank, frames, chunk, dev, cm_stats):
+    """Outside the timed region, on rank 0's own output: the first and the last RNG chunk of the rank's batch (at 4K with chunk 4 the
+    Philox quarters of a chunk span 11.4 rows and their sibling runs cross frame boundaries inside every chunk) are re-derived
+      (a) with the stand-alone operators of this library, one after the other (film_grain -> lut3d -> color_match -> stencil3x3), and
+      (b) with the oracle composition (oracle/chain_oracle.py: torch.randn on the device, the CPU restatements pinned to the reference's
+          fixtures for grain / LUT / unsharp, the restated colour match evaluated by torch on the device) -- the checker, never timed,
+    and compared bit for bit with what the timed steps left in `out`.  (b) holds with the device statistics; with fp64 statistics the
+    oracle differs by the statistics band and only (a) is asserted."""
+    from oracle import chain_oracle as CO          # checker only (like the cpu_baseline leg)
+    res = {"frames_checked": [], "vs_standalone_operators": True, "vs_device_oracle": None, "max_abs_vs_oracle": 0.0}
+    chunks = sorted({0, frames // chunk - 1}) if "grain" in stages else [0, max(frames // chunk - 1, 0)]
+    ref_ms = ops.reference_stats(ref, cm_stats=cm_stats) if "colormatch" in stages else None
+    for c in sorted(set(chunks)):
+        f0, f1 = c * chunk, min(frames, (c + 1) * chunk)
+        xs = x[f0:f1]
+        y = xs
+        if "grain" in stages:
+            plan = ops.NoisePlan(chunk, geom_stream, chunk0=rank * (frames // chunk) + c)
+            y = ops.film_grain(y, 0.04, 0.5, chunk_frames=chunk, plans=(plan, None, 1))
+        if "lut" in stages:
+            y = ops.lut3d(y, lut, 10.0)
+        if "colormatch" in stages:
+            y = ops.color_match(y, None, 1.0, ref_ms=ref_ms, cm_chunk=CM_BATCH, cm_stats=cm_stats)
+        if "sharpen" in stages:
+            y = ops.stencil3x3(y, "unsharp", 0.5, False)
+        got = out[f0:f1]
+        res["vs_standalone_operators"] = bool(res["vs_standalone_operators"] and torch.equal(got, y))
+        want = CO.headline_chain(xs.cpu(), dev, stages=stages, stream=geom_stream, chunk0=rank * (frames // chunk) + c, chunk_frames=chunk,
+                                 lut_cpu=lut_cpu, reference_dev=ref, cm_batch=CM_BATCH)
+        same = torch.equal(got.cpu(), want)
+        res["max_abs_vs_oracle"] = max(res["max_abs_vs_oracle"], float((got.cpu() - want).abs().max()))
+        res["vs_device_oracle"] = same if res["vs_device_oracle"] is None else (res["vs_device_oracle"] and same)
+        res["frames_checked"].append([f0, f1])
+        del y, want
+    oracle_must_hold = "colormatch" not in stages or (cm_stats or "device") == "device"
+    res["verified"] = bool(res["vs_standalone_operators"] and (res["vs_device_oracle"] or not oracle_must_hold))
+    return res
+
+
+def output_digests(out, chunk):
+    """SHA-256 per RNG chunk of a rank's output (bytes of the fp32 frames): independent of how many ranks share the job."""
+    import hashlib
+    return [hashlib.sha256(out[f:f + chunk].cpu().numpy().tobytes()).hexdigest() for f in range(0, out.shape[0], chunk)]
+
+
 def main():
     args = parse_args()
     self_launch(args)
@@ -244,7 +303,7 @@ def main():
 
     lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
     lut = ops.upload_lut(lut_cpu, dev)
-    x = make_frames(frames, H, W, dev, 1234 + rank, args.dist)
+    x = make_frames(frames, H, W, dev, 1234 + (0 if args.same_data else rank), args.dist, first_frame=rank * frames if args.same_data else None)
     out = torch.empty_like(x)
     lab_ws = torch.empty_like(x) if "colormatch" in stages else None      # Lab image between the two colour-match passes
     ref = make_frames(1, H, W, dev, 4321, args.dist)          # same reference frame on every rank
@@ -259,10 +318,10 @@ def main():
 
     ref_events = []
 
-    def step(kernel_events=None, cm_math=None):
+    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats):
         ref_ms = ref_ev = None
         if "colormatch" in stages:
-            if ops._cm_stats(None, cm_math) == "device":
+            if ops._cm_stats(cm_stats, cm_math, dev) == "device":
                 # device statistics = torch's own reduction over the WHOLE reference frame: every rank evaluates it (no exchange), on
                 # the side stream -- only the apply pass needs it, pass 1 of the batch runs meanwhile
                 if args.sync_ref:
@@ -274,7 +333,7 @@ def main():
                 if kernel_events is not None:
                     r0, r1 = ops.HipEvent(), ops.HipEvent()
                     r0.record()
-                ref_ms = sharding.reference_stats_sharded(ref, rank, world, cm_math=cm_math)
+                ref_ms = sharding.reference_stats_sharded(ref, rank, world, cm_math=cm_math)      # fp64 triples, RCCL all-reduce
                 if kernel_events is not None:
                     r1.record()
                     ref_events.append((r0, r1))
@@ -285,7 +344,7 @@ def main():
                              lut=(lut, 10.0) if "lut" in stages else None,
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
-                             cm_ref_event=ref_ev)
+                             cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
         ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws)
 
     def barrier():
@@ -310,15 +369,28 @@ def main():
         per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 3) for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the timed steps' own output, checked and fingerprinted BEFORE anything else overwrites it (never inside the timed region)
+    verify = digests = None
+    if rank == 0 and not args.no_verify:
+        try:
+            verify = verify_output(ops, x, out, ref, lut, lut_cpu, stages, geom_stream, rank, frames, chunk, dev, args.cm_stats)
+        except Exception as exc:              # a checker problem must not lose the measurement; it is reported as unverified
+            verify = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
+    if args.digest:
+        mine = output_digests(out, chunk)
+        digests = [mine]
+        if dist.is_initialized():
+            digests = [None] * world
+            dist.all_gather_object(digests, mine)
     # the fast colour-match policy, same data, timed the same way (reported beside the headline, never as `value`)
     fast_variant = None
     if "colormatch" in stages and not args.no_fast_variant:
-        step(cm_math="fast")
+        step(cm_math="fast", cm_stats=None)
         barrier()
         fast_events = []
         f0 = time.perf_counter()
         for _ in range(args.steps):
-            step(fast_events, cm_math="fast")
+            step(fast_events, cm_math="fast", cm_stats=None)
         barrier()
         fel = time.perf_counter() - f0
         if dist.is_initialized():
@@ -433,7 +505,10 @@ def main():
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
                        "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
                        "cm_math": "device" if "colormatch" in stages else None,
-                       "cm_stats": (f"device (torch-ROCm's reductions bit for bit, batch_size {CM_BATCH})" if "colormatch" in stages else None)},
+                       "cm_stats": ((f"device (torch-ROCm's reductions bit for bit, batch_size {CM_BATCH})" if (args.cm_stats or "device") == "device"
+                                     else "fp64 (reference-frame rows split across the ranks, RCCL all-reduce)") if "colormatch" in stages else None),
+                       "lut_note": "synthetic-uniform pixels make the LUT gathers content-independent; with --dist video their cost depends on the "
+                                   "cube's shape (this pack's AMD_TealOrange_33.cube, not the reference's Vintage Color.cube)"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
             "per_rank_ms_per_step": per_rank_ms,
@@ -448,6 +523,10 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "issue": issue},
         }
+        line["verified"] = None if verify is None else bool(verify.get("verified"))
+        line["verify"] = verify
+        if digests is not None:
+            line["output_sha256_per_rank_per_chunk"] = digests
         if fast_variant is not None:
             line["fast_variant"] = fast_variant
         if world == 1 and not args.no_cpu_baseline:

@@ -900,9 +900,21 @@ VRG_HD void dev_pow_ziv3(const float x[3], float y, const float* T, uint32_t lo_
 VRG_HD float cm_div_scalar(float x, float c, float rc, float, const PowTables&) { return div_const(x, c, rc); }
 VRG_HD float cm_div_scalar(float x, float, float, float rc_dev, const DevMath&) { return x * rc_dev; }
 #define VRG_CM_DIVS(x, c, M) ::vrg::cm_div_scalar((x), (float)(c), 1.0f / (float)(c), (float)(1.0 / (double)(c)), (M))
-// x / c for a tensor-valued constant c (the D65 white point)
+// x / c for a tensor-valued constant c (the D65 white point): the IEEE quotient under both policies.  The fast policy takes the
+// FMA form outright; the device policy takes it for a whole wave when every active lane's |x| lies in the range over which the
+// form is PROVEN equal to x / c for these constants (1e-30 .. 1e30: all 2^32 inputs swept on the device, vrg_selftest_divconst) or
+// is zero (0 / c = 0 either way; the sign of a zero does not survive lab_f's 7.787 * t + 4/29), and the backend's IEEE division
+// sequence (~10 instructions plus v_rcp_f32, 13 issue slots) otherwise -- 6 slots instead of 13 for every ordinary pixel.
 VRG_HD float cm_div_tensor(float x, float c, float rc, const PowTables&) { return div_const(x, c, rc); }
-VRG_HD float cm_div_tensor(float x, float c, float, const DevMath&) { return x / c; }
+VRG_HD float cm_div_tensor(float x, float c, float rc, const DevMath&) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VRG_NO_DIVT_FASTPATH)
+    const bool proven = ((__builtin_fabsf(x) - 1e-30f) <= (1e30f - 1e-30f)) | (x == 0.0f);
+    if (__builtin_amdgcn_ballot_w64(!proven) == 0) return div_const(x, c, rc);
+#else
+    (void)rc;
+#endif
+    return x / c;
+}
 #define VRG_CM_DIVT(x, c, M) ::vrg::cm_div_tensor((x), (c), 1.0f / (c), (M))
 
 VRG_HD float srgb_to_linear(float v, const PowTables& T) {

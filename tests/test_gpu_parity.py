@@ -1781,3 +1781,138 @@ def test_march_with_lds_resident_lut(ops, dev, lut_name):
     want = R.unsharp(R.apply_lut_with_strength(cpu, data, 10.0), 0.5, False)
     got = ops.fused_chain(x, ops.ChainSpec(lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False), variant=2))
     assert torch.equal(got[0, 0:3].cpu(), want[0, 0:3])
+
+
+# ---------------------------------------------------------------------------------------- the benchmark's own geometry, held to the oracle
+def _job_stream(ops, dev, fe, chunk, n_chunks, seed=42):
+    """bench.py's job-wide noise stream: one generator, `n_chunks` chunks of `chunk` frames (absolute chunk index -> offset)."""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    return ops.rng.reserve(chunk * fe, n_chunks, dev, gen)
+
+
+def test_headline_chain_at_bench_geometry_is_the_oracle(ops, dev):
+    """BASELINE configs[4] as bench.py runs it -- 4K frames, grain chunk 4, AMD_TealOrange_33, colour match batch_size 1, unsharp 0.5,
+    noise keyed by absolute chunk index, caller-supplied Lab workspace and output -- on 8 frames, against the oracle composition
+    (oracle/chain_oracle.py: torch.randn on the device -> restated grain / LUT on the CPU -> restated colour match evaluated by torch on
+    the device -> restated unsharp), BIT FOR BIT.  At 4K a chunk's Philox quarter G = 524,288 elements spans 11.4 rows and a chunk holds
+    47.5 quarters per frame: the four sibling runs of k_produce_lab's workgroups cross frame boundaries inside every chunk, and the
+    kernels that run are exactly the bench's: k_produce_lab<3,false,false> -> k_tstats_frame -> k_chain_tile<COLORMATCH|FROM_LAB>."""
+    from oracle import chain_oracle as CO
+    H, W, chunk, frames, first_chunk = 2160, 3840, 4, 8, 5             # chunks 5 and 6 of a larger job (a rank that is not rank 0)
+    data, dlut = _lut_pair(ops, dev, "AMD_TealOrange_33.cube")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.rand((frames, H, W, 3), generator=g, device=dev)
+    ref = torch.rand((1, H, W, 3), generator=g, device=dev)
+    stream = _job_stream(ops, dev, H * W * 3, chunk, 64)
+    out, ws = torch.empty_like(x), torch.empty_like(x)
+    ref_ms, ev = ops.reference_stats_async(ref)
+    spec = ops.ChainSpec(grain=(0.04, 0.5, chunk), lut=(dlut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), cm_chunk=1,
+                         cm_ref_event=ev)
+    ops.fused_chain(x, spec, plans=(ops.NoisePlan(chunk, stream, chunk0=first_chunk), None, frames // chunk), out=out, lab_workspace=ws)
+    want = CO.headline_chain(x.cpu(), dev, stages=("grain", "lut", "colormatch", "sharpen"), stream=stream, chunk0=first_chunk,
+                             chunk_frames=chunk, lut_cpu=data, reference_dev=ref, cm_batch=1)
+    assert_bit_equal(out, want, "4K x 8 frames, chunk 4: fused headline chain vs the oracle composition")
+
+
+def test_grain_lut_1080p_at_bench_geometry_is_the_oracle(ops, dev):
+    """BASELINE configs[1]: 1080p, grain (chunk 4) + 33^3 LUT, job-wide noise stream -- 8 frames against the oracle, bit for bit."""
+    from oracle import chain_oracle as CO
+    H, W, chunk, frames, first_chunk = 1080, 1920, 4, 8, 3
+    data, dlut = _lut_pair(ops, dev, "AMD_TealOrange_33.cube")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.rand((frames, H, W, 3), generator=g, device=dev)
+    stream = _job_stream(ops, dev, H * W * 3, chunk, 32)
+    out = torch.empty_like(x)
+    ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, chunk), lut=(dlut, 10.0)),
+                    plans=(ops.NoisePlan(chunk, stream, chunk0=first_chunk), None, frames // chunk), out=out)
+    want = CO.headline_chain(x.cpu(), dev, stages=("grain", "lut"), stream=stream, chunk0=first_chunk, chunk_frames=chunk, lut_cpu=data)
+    assert_bit_equal(out, want, "1080p x 8 frames, chunk 4: fused grain + LUT vs the oracle composition")
+
+
+def test_chain3_4k_at_bench_geometry_is_the_oracle(ops, dev):
+    """BASELINE configs[2]: 4K, grain (chunk 4) + LUT + unsharp through the wave-march kernel -- 4 frames against the oracle."""
+    from oracle import chain_oracle as CO
+    H, W, chunk, frames, first_chunk = 2160, 3840, 4, 4, 2
+    data, dlut = _lut_pair(ops, dev, "AMD_TealOrange_33.cube")
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = torch.rand((frames, H, W, 3), generator=g, device=dev)
+    stream = _job_stream(ops, dev, H * W * 3, chunk, 16)
+    out = torch.empty_like(x)
+    ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, chunk), lut=(dlut, 10.0), sharpen=("unsharp", 0.5, False)),
+                    plans=(ops.NoisePlan(chunk, stream, chunk0=first_chunk), None, frames // chunk), out=out)
+    want = CO.headline_chain(x.cpu(), dev, stages=("grain", "lut", "sharpen"), stream=stream, chunk0=first_chunk, chunk_frames=chunk, lut_cpu=data)
+    assert_bit_equal(out, want, "4K x 4 frames, chunk 4: fused grain + LUT + unsharp vs the oracle composition")
+
+
+def test_colour_match_4k_at_bench_geometry_is_the_device_oracle(ops, dev):
+    """BASELINE configs[3]: colour match alone on 4K frames (k_lab_partials Lab-only form -> k_tstats_frame -> k_chain_tile<FROM_LAB>,
+    what bench.py --workload colormatch_4k runs), 3 frames, batch_size 1, against the restated reference evaluated by torch on the GPU."""
+    H, W = 2160, 3840
+    g = torch.Generator(device=dev).manual_seed(4321)
+    x = torch.rand((3, H, W, 3), generator=g, device=dev)
+    ref = torch.rand((1, H, W, 3), generator=g, device=dev)
+    out, ws = torch.empty_like(x), torch.empty_like(x)
+    ref_ms, ev = ops.reference_stats_async(ref)
+    ops.fused_chain(x, ops.ChainSpec(colormatch=(ref_ms, 1.0), cm_chunk=1, cm_ref_event=ev), out=out, lab_workspace=ws)
+    assert_bit_equal(out, R.color_match(x, ref, 1.0, 1), "4K colour match alone vs the device oracle")
+
+
+def test_bench_verifies_its_own_output(dev):
+    """bench.py --verify (on by default): after the timed steps the first and the last RNG chunk of `out` are re-derived with the
+    stand-alone operators and with the oracle composition; the JSON line says so."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-live-traffic", "--no-fast-variant", "--digest"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["verified"] is True, line["verify"]
+    assert line["verify"]["vs_standalone_operators"] and line["verify"]["vs_device_oracle"] and line["verify"]["frames_checked"] == [[0, 4], [4, 8]]
+    assert len(line["output_sha256_per_rank_per_chunk"]) == 1 and len(line["output_sha256_per_rank_per_chunk"][0]) == 2
+
+
+@pytest.mark.parametrize("cm_stats", ["device", "fp64"])
+def test_output_bits_do_not_depend_on_the_number_of_ranks(dev, cm_stats):
+    """GPU-count invariance, proven without a second GPU: bench.py --digest emits the SHA-256 of every RNG chunk of every rank's
+    output.  Two ranks x 8 frames (sharing cuda:0 over gloo: everything but the RCCL transport is the production path -- noise keyed by
+    absolute chunk index, reference statistics per rank / rows split + all-reduce) must produce, chunk for chunk, the digests of ONE
+    rank x 16 frames -- with the device statistics (no exchange step) AND with the fp64 statistics merged by the collective."""
+    import json
+    import subprocess
+    from conftest import ROOT
+
+    def run(gpus, frames):
+        env = dict(os.environ, VRGDG_DIST_BACKEND="gloo")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--frames", str(frames), "--steps", "1",
+                            "--warmup", "0", "--no-cpu-baseline", "--no-live-traffic", "--no-fast-variant", "--no-verify", "--digest",
+                            "--same-data", "--cm-stats", cm_stats], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    two, one = run(2, 8), run(1, 16)
+    assert two["n_gpus"] == 2 and len(two["output_sha256_per_rank_per_chunk"]) == 2
+    flat_two = [d for rank in two["output_sha256_per_rank_per_chunk"] for d in rank]
+    assert flat_two == one["output_sha256_per_rank_per_chunk"][0], "2 ranks x 8 frames vs 1 rank x 16 frames: output bits differ"
+
+
+def test_device_statistics_of_a_split_call_use_the_whole_calls_mean_factor(ops, dev):
+    """ATen forms the mean factor float(outputs) / numel ONCE from the whole reduction call and hands it to every 32-bit sub-iterator;
+    per piece it would differ by one ulp whenever outputs * H*W is not an fp32 number -- e.g. batch_size 87 at 1079 x 1919 (odd H and
+    W: planes also start off the vector boundary)."""
+    F, H, W = 87, 1079, 1919
+    assert F * 3 * H * W > 2 ** 29
+    g = torch.Generator(device=dev).manual_seed(5)
+    lab = torch.empty((F, H, W, 3), device=dev)
+    for i in range(0, F, 8):
+        lab[i:i + 8] = torch.rand((min(8, F - i), H, W, 3), generator=g, device=dev) * 100 - 35
+    o = F * 3
+    assert np.float32(o) / np.float32(o * H * W) != np.float32(o // 2) / np.float32((o // 2) * H * W) or \
+        np.float32(o) / np.float32(o * H * W) != np.float32(o - o // 2) / np.float32((o - o // 2) * H * W), "pick a size where the factors differ"
+    got = ops.lab_stats_device(lab, F)
+    want = _torch_reductions(lab, F)
+    assert _same_bits_or_nan(got, want), (got - want).abs().max()
