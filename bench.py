@@ -61,6 +61,8 @@ def parse_args():
                                                              "the stand-alone operators and the device oracle)")
     ap.add_argument("--digest", action="store_true", help="add the SHA-256 of every rank's output (per RNG chunk) to the line: equal frame ranges of "
                                                           "runs with different GPU counts must give equal digests")
+    ap.add_argument("--pieces", type=int, default=None, help="frame ranges the two-pass chain is pipelined over (pass 2 of piece i next to pass 1 of "
+                                                           "piece i+1 on a second stream); default: ops.default_overlap_pieces; 1 = sequential passes")
     ap.add_argument("--same-data", action="store_true", help="frames are a function of their ABSOLUTE index in the job (rank r holds frames "
                                                              "[r*frames, (r+1)*frames) of one job-wide batch), so that runs with different GPU counts process "
                                                              "the same data; default: an independent batch per rank")
@@ -318,7 +320,7 @@ def main():
 
     ref_events = []
 
-    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats):
+    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats, pieces=args.pieces):
         ref_ms = ref_ev = None
         if "colormatch" in stages:
             if ops._cm_stats(cm_stats, cm_math, dev) == "device":
@@ -345,7 +347,7 @@ def main():
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
                              cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
-        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws)
+        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws, overlap_pieces=pieces)
 
     def barrier():
         if dist.is_initialized():
@@ -409,7 +411,23 @@ def main():
     passes = {}
     for name, a, b, nf in events:
         passes.setdefault(name, []).append(a.elapsed_ms(b))
-    pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (segments of a step added up)
+    pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (pieces of a step added up)
+    launches_per_step = {k: len(v) // max(args.steps, 1) for k, v in passes.items()}
+    # When the passes of a step overlap (pipelined pieces on two streams), a launch's duration includes the time it shares the CUs with
+    # the other pass: the same kernels are timed once more one after the other (outside the timed region) for their exclusive durations
+    n_pieces_used = max(launches_per_step.values()) if launches_per_step else 1
+    exclusive_ms = None
+    if "colormatch" in stages and n_pieces_used > 1:
+        step(pieces=1)
+        barrier()
+        ex_events = []
+        for _ in range(2):
+            step(ex_events, pieces=1)
+        barrier()
+        acc = {}
+        for name, a, b, nf in ex_events:
+            acc.setdefault(name, []).append(a.elapsed_ms(b))
+        exclusive_ms = {k: round(sum(v) / 2, 4) for k, v in acc.items()}
     algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}                      # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
     kern_names = {"stats": ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it "
                             "by k_tstats_frame)" if "grain" in stages else
@@ -503,6 +521,7 @@ def main():
                                    f"(BASELINE configs[4] per-GPU shard)" if args.workload == "chain4_4k"
                        else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
+                       "pipelined_pieces_per_step": n_pieces_used,
                        "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
                        "cm_math": "device" if "colormatch" in stages else None,
                        "cm_stats": ((f"device (torch-ROCm's reductions bit for bit, batch_size {CM_BATCH})" if (args.cm_stats or "device") == "device"
@@ -521,7 +540,13 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
-                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "issue": issue},
+                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": launches_per_step,
+                         "exclusive_passes_ms": exclusive_ms,
+                         "overlap_note": (None if exclusive_ms is None else
+                                          f"the step is pipelined over {n_pieces_used} frame ranges: pass 2 (and the statistics reductions) of piece i run on a "
+                                          "second stream next to pass 1 of piece i+1, so `passes_ms` / `avg_launch_ms` are launch durations WHILE the other pass "
+                                          "shares the CUs (their sum exceeds ms_per_step); `exclusive_passes_ms` = the same kernels run one after the other"),
+                         "issue": issue},
         }
         line["verified"] = None if verify is None else bool(verify.get("verified"))
         line["verify"] = verify

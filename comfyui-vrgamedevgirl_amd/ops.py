@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import math
 import os
 import threading
 from dataclasses import dataclass
@@ -820,10 +821,95 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     return stats
 
 
+
+_PIPE_STREAMS = {}
+
+
+def _pipe_stream(device) -> "torch.cuda.Stream":
+    """The second frame-pass stream of a device: pass 2 (and the statistics reductions) of piece i run on it while pass 1 of piece
+    i + 1 runs on the caller's stream (fused_chain, `overlap_pieces`)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    with _STATE_LOCK:
+        st = _PIPE_STREAMS.get(key)
+        if st is None:
+            st = _PIPE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
+
+
+def default_overlap_pieces(frames: int, frame_elems: int) -> int:
+    """How many pieces the two-pass colour-match chain is cut into so that its passes overlap (0 / 1 = one piece, sequential passes).
+    VRGDG_CM_PIECES overrides.  Measured on the MI355X (profiles/r03_*): pass 1 (grain -> LUT -> Lab) is bound by the LUT's gather
+    address path with the vector ALUs 64 % busy, pass 2 (match -> Lab->RGB -> sharpen) by the vector ALUs with the address path idle;
+    run next to each other they share a CU's two bottlenecks instead of taking turns on them."""
+    env = os.environ.get("VRGDG_CM_PIECES", "").strip()
+    if env:
+        return max(int(env), 0)
+    mpix = frames * frame_elems / 3.0 / 1e6
+    if mpix < 2 * 66.0:                    # fewer than two 8-frame 4K pieces: nothing to pipeline
+        return 0
+    return int(min(8, mpix // 66.0))
+
+
+def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
+    """Device-statistics two-pass chain as a software pipeline over `pieces` frame ranges (multiples of the RNG chunk and of the
+    statistics call size): on the caller's stream pass 1 of piece i; on the second stream, behind an event, the statistics reductions
+    and pass 2 of piece i -- next to pass 1 of piece i + 1.  Same kernels, same arguments per frame range, same results as the
+    one-piece form (the statistics calls and the RNG chunks are the same ones)."""
+    F, H, W, _ = x.shape
+    fe = H * W * 3
+    lib = _hip.lib()
+    main = torch.cuda.current_stream()
+    aux = _pipe_stream(x.device)
+    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
+    aux.wait_stream(main)                       # `out`, the Lab workspace and the statistics buffer may still be in use by earlier work
+    if spec.cm_ref_event is not None:
+        aux.wait_event(spec.cm_ref_event)
+    _device_stats_selfcheck(x.device)
+    keep = []
+    for f0, nf in pieces:
+        d1 = _chain_desc(spec, plan, keep, x)
+        if plan is not None:
+            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
+        if kernel_events is not None:
+            s0, s1 = HipEvent(), HipEvent()
+            s0.record()
+        _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
+                                              C.byref(d1), None, None, _hip.current_stream()), "vrg_chain_stats_lab_f32")
+        if kernel_events is not None:
+            s1.record()
+            kernel_events.append(("stats", s0, s1, nf))
+        done1 = torch.cuda.Event()
+        done1.record(main)
+        with torch.cuda.stream(aux):
+            aux.wait_event(done1)
+            if kernel_events is not None:
+                t0, t1 = HipEvent(), HipEvent()
+                t0.record()
+            lab_stats_device(lab_full[f0:f0 + nf], spec.cm_chunk, out=img_ms_full[f0:f0 + nf])
+            if kernel_events is not None:
+                t1.record()
+                kernel_events.append(("tstats", t0, t1, nf))
+            d2 = _chain_desc(spec, plan, keep, x)
+            d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+            d2.img_ms = img_ms_full.data_ptr() + f0 * 24
+            if kernel_events is not None:
+                e0, e1 = HipEvent(), HipEvent()
+                e0.record()
+            _hip.check(lib.vrg_fused_chain_f32(C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), C.c_void_p(out.data_ptr() + f0 * fe * 4), nf, H, W,
+                                              C.byref(d2), _hip.current_stream()), "vrg_fused_chain_f32")
+            if kernel_events is not None:
+                e1.record()
+                kernel_events.append(("apply", e0, e1, nf))
+    main.wait_stream(aux)
+    for t in (x, out, lab_full, img_ms_full):
+        t.record_stream(aux)
+    return out
+
+
 @_on_device
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
-                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
+                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True, overlap_pieces: Optional[int] = None) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
     pass).  Bit-identical to applying the stand-alone operators in that order.
 
@@ -893,6 +979,21 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             lab_full = lab_workspace
         else:
             lab_full = torch.empty((F, H, W, 3), dtype=torch.float32, device=x.device)
+        # Software pipeline over frame ranges (see _fused_chain_pipelined / default_overlap_pieces): only when the batch is one run of
+        # equal RNG chunks and equal statistics calls, so that every piece is made of whole chunks and whole calls
+        n_pieces = default_overlap_pieces(F, fe) if overlap_pieces is None else int(overlap_pieces)
+        if n_pieces > 1 and len(segments) == 1 and isinstance(spec.cm_chunk, int):
+            plan = segments[0][2]
+            unit = spec.cm_chunk * (plan.chunk_frames if plan is not None else 1) // math.gcd(spec.cm_chunk, plan.chunk_frames if plan is not None else 1)
+            R = int(spec.colormatch[0].shape[0])
+            if R != 1:
+                unit = unit * R // math.gcd(unit, R)
+            units = F // unit
+            if units >= 2:
+                n_pieces = min(n_pieces, units)
+                per = (units + n_pieces - 1) // n_pieces * unit
+                pieces = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
+                return _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events)
         for f0, nf, plan in segments:
             keep = []
             d = _chain_desc(spec, plan, keep, x)

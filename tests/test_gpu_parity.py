@@ -1916,3 +1916,30 @@ def test_device_statistics_of_a_split_call_use_the_whole_calls_mean_factor(ops, 
     got = ops.lab_stats_device(lab, F)
     want = _torch_reductions(lab, F)
     assert _same_bits_or_nan(got, want), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("F,chunk,bs,n_ref,pieces", [(12, 2, 3, 1, 2), (12, 2, 1, 1, 8), (16, 4, 1, 1, 3), (12, 0, 2, 2, 4), (7, 0, 1, 1, 7), (24, 4, 6, 3, 2)])
+def test_pipelined_pieces_equal_the_one_piece_chain(ops, dev, F, chunk, bs, n_ref, pieces):
+    """fused_chain(overlap_pieces=n): pass 1 of piece i+1 on the caller's stream next to the statistics reductions and pass 2 of piece i
+    on a second stream.  Pieces are whole RNG chunks, whole statistics calls and whole reference groups, so every kernel sees the same
+    frames with the same arguments: output bits equal the sequential form's (and the generator ends where it would have)."""
+    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
+    x = _rand((F, 54, 96, 3), 311).to(dev)
+    ref = _rand((n_ref, 30, 40, 3), 312).to(dev)
+    ref_ms = ops.reference_stats(ref)
+    grain = (0.05, 0.4, chunk) if chunk else None
+    spec = ops.ChainSpec(grain=grain, lut=(dlut, 8.0), colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.6, False), cm_chunk=bs)
+    gen = torch.cuda.default_generators[dev.index]
+    torch.manual_seed(9)
+    want = ops.fused_chain(x, spec, overlap_pieces=1)
+    off_want = gen.get_offset()
+    torch.manual_seed(9)
+    got = ops.fused_chain(x, spec, overlap_pieces=pieces)
+    torch.cuda.synchronize()
+    assert gen.get_offset() == off_want
+    assert_bit_equal(got, want, f"{pieces} pipelined pieces vs one piece")
+    ev = []
+    torch.manual_seed(9)
+    again = ops.fused_chain(x, spec, overlap_pieces=pieces, kernel_events=ev, out=torch.empty_like(x), lab_workspace=torch.empty_like(x))
+    assert_bit_equal(again, want, "pipelined, caller-supplied buffers, timed")
+    assert {n for n, *_ in ev} == {"stats", "tstats", "apply"} and all(a.elapsed_ms(b) >= 0 for _, a, b, _ in ev)
