@@ -61,6 +61,7 @@ def parse_args():
                                                              "the stand-alone operators and the device oracle)")
     ap.add_argument("--digest", action="store_true", help="add the SHA-256 of every rank's output (per RNG chunk) to the line: equal frame ranges of "
                                                           "runs with different GPU counts must give equal digests")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (CPU tensors in and out, PCIe inclusive) node rates of the line's `host_fed` key")
     ap.add_argument("--pieces", type=int, default=None, help="frame ranges the two-pass chain is pipelined over (pass 2 of piece i next to pass 1 of "
                                                            "piece i+1 on a second stream); default: ops.default_overlap_pieces; 1 = sequential passes")
     ap.add_argument("--same-data", action="store_true", help="frames are a function of their ABSOLUTE index in the job (rank r holds frames "
@@ -548,6 +549,16 @@ def main():
                                           "shares the CUs (their sum exceeds ms_per_step); `exclusive_passes_ms` = the same kernels run one after the other"),
                          "issue": issue},
         }
+        if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":
+            # what a ComfyUI graph sees: CPU tensors in, CPU tensors out, every node call crossing PCIe both ways -- never `value`
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import host_fed
+                del x
+                torch.cuda.empty_cache()
+                line["host_fed"] = host_fed.measure(frames=8, reps=1)
+            except Exception as exc:
+                line["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
         line["verified"] = None if verify is None else bool(verify.get("verified"))
         line["verify"] = verify
         if digests is not None:

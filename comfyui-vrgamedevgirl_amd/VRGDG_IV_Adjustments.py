@@ -40,7 +40,10 @@ def _graded(image, lut_data, requested_device, strength):
     dev_lut = ops.upload_lut(lut_data, target)
     if image.device.type == "cpu" and image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0:
         # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames)
-        return stream_frames(image, lambda frames, _first: ops.lut3d(frames, dev_lut, strength))
+        def on(device):             # several GPUs (VRGDG_DEVICES): every device gets its own copy of the record table
+            lut_d = dev_lut if torch.device(device) == torch.device(target) else ops.upload_lut(lut_data, device)
+            return lambda frames, _first: ops.lut3d(frames, lut_d, strength)
+        return stream_frames(image, on(target), fn_for_device=on)
     working = image.to(device=target)
     return ops.lut3d(working, dev_lut, strength).to(device=image.device)
 

@@ -31,6 +31,26 @@ def compute_device() -> torch.device:
     return dev
 
 
+def compute_devices() -> list:
+    """The GPUs a host-fed batch is spread over.  Default: the one compute device.  ``VRGDG_DEVICES=all``: every visible GPU (the node
+    path's way to the other seven MI355X of a node: ComfyUI runs its graph in ONE process, so torchrun-style sharding is not available
+    to it); ``VRGDG_DEVICES=0,2,3``: those device indices, the first one being the primary (its generator is the one the reference's
+    torch.randn calls would consume).  An index may repeat (``0,0``: two lanes on one GPU -- how the 1-GPU test box exercises this).
+    GPUs with another CU count than the primary are dropped: the Philox geometry of a randn call depends on it."""
+    primary = compute_device()
+    spec = os.environ.get("VRGDG_DEVICES", "").strip().lower()
+    if not spec:
+        return [primary]
+    if spec == "all":
+        idx = [primary.index] + [i for i in range(torch.cuda.device_count()) if i != primary.index]
+    else:
+        idx = [int(v) for v in spec.split(",") if v.strip() != ""]
+        if not idx or any(i < 0 or i >= torch.cuda.device_count() for i in idx):
+            raise ValueError(f"VRGDG_DEVICES={spec!r}: expected 'all' or a comma-separated list of visible device indices")
+    cus = torch.cuda.get_device_properties(idx[0]).multi_processor_count
+    return [torch.device("cuda", i) for i in idx if torch.cuda.get_device_properties(i).multi_processor_count == cus]
+
+
 def intermediate_device() -> torch.device:
     try:
         import comfy.model_management as mm  # type: ignore
@@ -86,11 +106,14 @@ class _Staging:
             self.buffers[slot] = buf
         return buf
 
-    def side_streams(self, dev: torch.device):
+    def side_streams(self, dev: torch.device, lane: int = 0):
+        """(h2d, d2h, compute) of one lane: lane 0 computes on the caller's current stream of its device (compute = None), further
+        lanes on the same device get a compute stream of their own."""
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
-        if idx not in self.streams:
-            self.streams[idx] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-        return self.streams[idx]
+        key = (idx, lane)
+        if key not in self.streams:
+            self.streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        return self.streams[key]
 
 
 _STAGING = _Staging()
@@ -102,16 +125,31 @@ def piece_frames(n_frames: int, frame_bytes: int, multiple_of: int = 1) -> int:
     return min(per, max(n_frames, 1))
 
 
-def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None) -> torch.Tensor:
+def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None, fn_for_device=None) -> torch.Tensor:
     """Run ``fn(gpu_frames, first_frame) -> gpu_frames`` over a CPU-resident batch with copies and kernels overlapped.
     Returns a CPU tensor shaped like `images` (dtype `out_dtype`, default the input's), page-locked when it fits
-    PIN_LIMIT_BYTES."""
-    dev = compute_device()
-    with torch.cuda.device(dev):          # kernels, side streams and events all on the compute device
-        return _stream_frames_on(dev, images, fn, multiple_of, out_dtype)
+    PIN_LIMIT_BYTES.
+
+    Several GPUs (``compute_devices()``, VRGDG_DEVICES): the pieces -- whole multiples of `multiple_of` frames -- go round-robin to
+    the devices, each with its own upload / compute / download streams, and are SUBMITTED in frame order from this host thread, so
+    host-side bookkeeping inside `fn` (the generator reservations of the grain nodes) happens in the order a single device would see.
+    `fn_for_device(device) -> fn` builds the per-device callable (device-resident operands -- LUT tables, reference statistics -- must
+    live on the device that runs the piece); without it only one device is used.  Results are identical to one device."""
+    devices = compute_devices() if fn_for_device is not None else [compute_device()]
+    if len(devices) == 1:
+        dev = devices[0]
+        with torch.cuda.device(dev):          # kernels, side streams and events all on the compute device
+            return _stream_frames_on([dev], [fn if fn_for_device is None else fn_for_device(dev)], images, multiple_of, out_dtype)
+    fns, made = [], {}
+    for d in devices:
+        if d.index not in made:
+            with torch.cuda.device(d):
+                made[d.index] = fn_for_device(d)
+        fns.append(made[d.index])
+    return _stream_frames_on(devices, fns, images, multiple_of, out_dtype)
 
 
-def _stream_frames_on(dev, images, fn, multiple_of, out_dtype):
+def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
     images = images.contiguous()
     F = int(images.shape[0])
     out_dtype = out_dtype or images.dtype
@@ -129,12 +167,27 @@ def _stream_frames_on(dev, images, fn, multiple_of, out_dtype):
         out = torch.empty(images.shape, dtype=out_dtype)
     per = piece_frames(F, max(in_fb, out_fb), multiple_of)
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
-    compute = torch.cuda.current_stream(dev)
+    n_lanes = min(len(devices), len(pieces))
     with _STAGING.lock:
-        h2d, d2h = _STAGING.side_streams(dev)
-        depth = min(PIPE_DEPTH, len(pieces))
+        lanes = []
+        seen = {}
+        for li in range(n_lanes):
+            dev = devices[li]
+            k = seen.get(dev.index, 0)
+            seen[dev.index] = k + 1
+            h2d, d2h, own = _STAGING.side_streams(dev, k)
+            lanes.append((dev, h2d, d2h, torch.cuda.current_stream(dev) if k == 0 else own, fns[li]))
+        depth = min(PIPE_DEPTH * n_lanes, len(pieces))
         ring = None if pin_out else [_STAGING.pinned(("out", k), per * out_fb) for k in range(depth)]
         pending = []                    # (slot, s, e, d2h_done_event, keep_alive)
+        caller = torch.cuda.current_stream(lanes[0][0])
+        for li in range(1, n_lanes):    # further lanes start after whatever the caller's stream has queued (the frames may depend on it)
+            if lanes[li][3] is not caller:
+                with torch.cuda.device(lanes[0][0]):
+                    ev0 = torch.cuda.Event()
+                    ev0.record(caller)
+                with torch.cuda.device(lanes[li][0]):
+                    lanes[li][3].wait_event(ev0)
 
         def retire(entry):
             k, s, e, done, _keep = entry
@@ -144,31 +197,37 @@ def _stream_frames_on(dev, images, fn, multiple_of, out_dtype):
 
         for i, (s, e) in enumerate(pieces):
             k = i % depth
+            dev, h2d, d2h, compute, fn = lanes[i % n_lanes]
             if len(pending) == depth:           # bounds the device memory in flight; frees ring slot k
                 retire(pending.pop(0))
-            with torch.cuda.stream(h2d):
-                # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
-                # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
-                # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
-                # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
-                # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
-                # than the copy.
-                gpu_in = images[s:e].to(dev, non_blocking=True)
-                up = torch.cuda.Event()
-                up.record(h2d)
-            compute.wait_event(up)
-            gpu_out = fn(gpu_in, s)                                 # kernels on the caller's current stream
-            if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
-                gpu_out = gpu_out.to(out_dtype).contiguous()
-            ran = torch.cuda.Event()
-            ran.record(compute)
-            dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
-            with torch.cuda.stream(d2h):
-                d2h.wait_event(ran)
-                dst.copy_(gpu_out, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record(d2h)
+            with torch.cuda.device(dev):
+                with torch.cuda.stream(h2d):
+                    # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
+                    # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
+                    # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
+                    # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
+                    # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
+                    # than the copy.
+                    gpu_in = images[s:e].to(dev, non_blocking=True)
+                    up = torch.cuda.Event()
+                    up.record(h2d)
+                with torch.cuda.stream(compute):
+                    compute.wait_event(up)
+                    gpu_out = fn(gpu_in, s)                             # kernels on this lane's compute stream
+                    if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
+                        gpu_out = gpu_out.to(out_dtype).contiguous()
+                    gpu_in.record_stream(compute)
+                    ran = torch.cuda.Event()
+                    ran.record(compute)
+                dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(ran)
+                    dst.copy_(gpu_out, non_blocking=True)
+                    gpu_out.record_stream(d2h)
+                    done = torch.cuda.Event()
+                    done.record(d2h)
             pending.append((k, s, e, done, (gpu_in, gpu_out)))      # tensors stay referenced until their DMA retired
         while pending:
             retire(pending.pop(0))
+        # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
     return out

@@ -17,7 +17,7 @@ STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
 ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NoiseDesc(C.Structure):
@@ -92,6 +92,8 @@ _SIGNATURES = {
     "vrg_lab_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_lab_stats_torch_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P]),
+    "vrg_lab_stats_torch_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "vrg_lab_stats_torch_ws_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, C.c_int64, _P]),
     "vrg_stats_allreduce_scratch_bytes": (C.c_int64, [C.c_int64]),
     "vrg_stats_allreduce": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "vrg_colormatch_apply_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_float,

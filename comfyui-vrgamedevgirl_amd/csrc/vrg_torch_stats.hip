@@ -264,13 +264,20 @@ struct TsRound {
     }
 };
 
-template <int PART, int TS_DEPTH>
+// ROWS = false: a 512-thread workgroup is torch's whole block and finishes the reduction (block_x_reduce, block_y_reduce, project).
+// ROWS = true: a 256-thread workgroup is HALF of torch's block -- threads [t0, t0 + 256), i.e. whole rows of the (bw, bh) block, since
+// bw divides 256 -- and stops after block_x_reduce: the per-row results go to `rows_out` ([3 channels][8 rows] Welf records, then
+// [3][8] floats for the means) and k_tstats_rows_finish runs block_y_reduce + project over them.  One wave per SIMD instead of two:
+// the Welford update chains of a wave are issue bound next to a second wave's (170 cycles per update with two waves per SIMD).
+struct TsRows { Welf w[3][8]; float m[3][8]; };
+
+template <int PART, int TS_DEPTH, bool ROWS = false>
 static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
-                                     Welf* lds_w) {
+                                     Welf* lds_w, int t0 = 0, TsRows* rows_out = nullptr) {
     typedef TsRound<PART> R;
     constexpr int NC = R::NC, C0 = PART == -1 ? 0 : (PART == 3 ? 0 : PART);
     float* lds_m = reinterpret_cast<float*>(lds_w);
-    const int t = threadIdx.x;
+    const int t = t0 + (int)threadIdx.x;
     const int64_t nvm = n / 4, nvw = n / 2;
     float ma[3][4];
     Welf wa[NC][2];
@@ -326,6 +333,7 @@ static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, 
             for (int c = 0; c < NC; ++c) { e[c] = q[C0 + c]; e[NC + c] = q[3 + C0 + c]; }
             welf_vec(e);
         }
+    const int tl = (int)threadIdx.x;                   // index within this workgroup (== t unless ROWS)
     if constexpr (R::MEAN) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -333,17 +341,68 @@ static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, 
             m = m + ma[c][1];
             m = m + ma[c][2];
             m = m + ma[c][3];
-            m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
-            if (t == 0) o6[c * 2] = m * factor;
+            if constexpr (ROWS) {
+                m = ts_block_reduce<MeanOp>(m, bw, bh, false, tl, true, lds_m);          // block_x_reduce only
+                if (tl % bw == 0) rows_out->m[c][t / bw] = m;
+            } else {
+                m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
+                if (t == 0) o6[c * 2] = m * factor;
+            }
         }
     }
     if constexpr (R::WELF) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             Welf w = WelfOp::combine(wa[c][0], wa[c][1]);
-            w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
-            if (t == 0) o6[(C0 + c) * 2 + 1] = welf_std(w) + eps;
+            if constexpr (ROWS) {
+                w = ts_block_reduce<WelfOp>(w, bw, bh, false, tl, true, lds_w);
+                if (tl % bw == 0) rows_out->w[C0 + c][t / bw] = w;
+            } else {
+                w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
+                if (t == 0) o6[(C0 + c) * 2 + 1] = welf_std(w) + eps;
+            }
         }
+    }
+}
+
+// Small batches: eight 256-thread workgroups per frame -- (Welford of channel 0 / 1 / 2, the three means) x (lower / upper half of
+// torch's 512 threads) -- all on one XCD (workgroup id % 8), one wave per SIMD.
+template <int DEPTH>
+__global__ void __launch_bounds__(256) k_tstats_rows(const float* __restrict__ lab, int64_t n, int64_t frames, int bw, int bh, TsRows* __restrict__ rows) {
+    __shared__ Welf lds_w[256];
+    const int64_t w = blockIdx.x;
+    const int64_t f = (w & 7) + 8 * (w >> 6);
+    const int sub = (int)((w >> 3) & 7), part = sub >> 1, t0 = (sub & 1) * 256;
+    if (f >= frames) return;
+    const float* base = lab + (size_t)f * (size_t)n * 3;
+    TsRows* ro = rows + f;
+    switch (part) {
+        case 0: ts_frame_part<0, DEPTH, true>(base, n, bw, bh, 0.0f, 0.0f, nullptr, lds_w, t0, ro); break;
+        case 1: ts_frame_part<1, DEPTH, true>(base, n, bw, bh, 0.0f, 0.0f, nullptr, lds_w, t0, ro); break;
+        case 2: ts_frame_part<2, DEPTH, true>(base, n, bw, bh, 0.0f, 0.0f, nullptr, lds_w, t0, ro); break;
+        default: ts_frame_part<3, DEPTH, true>(base, n, bw, bh, 0.0f, 0.0f, nullptr, lds_w, t0, ro); break;
+    }
+}
+
+// block_y_reduce (the tree over the bh rows, in the order ts_block_reduce walks it) + project, one thread per output
+__global__ void __launch_bounds__(64) k_tstats_rows_finish(const TsRows* __restrict__ rows, int64_t frames, int bh, float factor, float eps,
+                                                          float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= frames * 6) return;
+    const int64_t f = i / 6;
+    const int c = (int)(i % 6) >> 1, which = (int)(i & 1);
+    if (which == 0) {
+        float v[8];
+        for (int r = 0; r < bh; ++r) v[r] = rows[f].m[c][r];
+        for (int off = bh / 2; off > 0; off >>= 1)
+            for (int ty = 0; ty < off; ++ty) v[ty] = MeanOp::combine(v[ty], v[ty + off]);
+        out[(size_t)f * 6 + c * 2] = v[0] * factor;
+    } else {
+        Welf v[8];
+        for (int r = 0; r < bh; ++r) v[r] = rows[f].w[c][r];
+        for (int off = bh / 2; off > 0; off >>= 1)
+            for (int ty = 0; ty < off; ++ty) v[ty] = WelfOp::combine(v[ty], v[ty + off]);
+        out[(size_t)f * 6 + c * 2 + 1] = welf_std(v[0]) + eps;
     }
 }
 
@@ -400,7 +459,13 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
 constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
-static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, int num_mp, hipStream_t st) {
+#ifndef VRG_TS_ROWS_MAX_FRAMES
+#define VRG_TS_ROWS_MAX_FRAMES 32
+#endif
+constexpr int64_t TS_ROWS_MAX_FRAMES = VRG_TS_ROWS_MAX_FRAMES;
+
+static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, int num_mp, void* scratch, int64_t scratch_bytes,
+                           hipStream_t st) {
     if (count <= 0 || b <= 0) return VRG_OK;
     const int64_t O = (int64_t)b * 3;
     const float factor = (float)O / (float)(O * n);                  // static_cast<float>(num_output_elements) / numel, of the WHOLE call
@@ -420,6 +485,15 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
         // measured on the MI355X (4K frames, ms): 1 frame 1.45 split / 3.57 whole; 64 frames 1.98 / 3.76; 128 frames 5.2 / 3.9 (four
         // readers per frame stop sharing their L2 lines); 256 frames 11.5 / 5.5 (the whole-frame form runs at 4.6 TB/s there).
         // Two rounds of loads in flight help the latency-bound split form (1.45 vs 1.72 with four), none the HBM-bound one.
+        // up to 32 frames (and a caller-supplied scratch buffer): eight half-block workgroups per frame, one wave per SIMD
+        if (frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsRows) && cm.bh == cw.bh && cm.bh <= 8 && 256 % cm.bw == 0 &&
+            (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
+            TsRows* rows = reinterpret_cast<TsRows*>(scratch);
+            hipLaunchKernelGGL((k_tstats_rows<2>), dim3((unsigned)(64 * ((frames + 7) / 8))), dim3(256), 0, st, lab, n, frames, cm.bw, cm.bh, rows);
+            hipLaunchKernelGGL(k_tstats_rows_finish, dim3((unsigned)((frames * 6 + 63) / 64)), dim3(64), 0, st, rows, frames, cm.bh, factor, eps, out);
+            VRG_CHECK_LAUNCH();
+            return VRG_OK;
+        }
         const bool split = frames <= TS_SPLIT_MAX_FRAMES;
         const int depth = split ? 2 : 1;
         const dim3 grid(split ? (unsigned)(32 * ((frames + 7) / 8)) : (unsigned)frames);
@@ -437,8 +511,19 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
 
 }  // namespace vrg
 
+extern "C" int64_t vrg_lab_stats_torch_scratch_bytes(int64_t frames) {
+    if (frames <= 0) return 0;
+    const int64_t f = frames < vrg::TS_ROWS_MAX_FRAMES ? frames : vrg::TS_ROWS_MAX_FRAMES;       // only the small-batch form uses it
+    return f * (int64_t)sizeof(vrg::TsRows);
+}
+
 extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
                                        float* mean_std, float eps, void* stream) {
+    return vrg_lab_stats_torch_ws_f32(lab, frames, height, width, chunk_frames, mean_std, eps, nullptr, 0, stream);
+}
+
+extern "C" int vrg_lab_stats_torch_ws_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
+                                          float* mean_std, float eps, void* scratch, int64_t scratch_bytes, void* stream) {
     using namespace vrg;
     if (frames < 0 || height <= 0 || width <= 0 || chunk_frames <= 0) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
@@ -456,9 +541,9 @@ extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int64_t full = frames / chunk_frames;
     const int tail = (int)(frames % chunk_frames);
-    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, cus, st);
+    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, cus, scratch, scratch_bytes, st);
     if (rc != VRG_OK) return rc;
-    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, st);
+    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, scratch, scratch_bytes, st);
     return rc;
 }
 

@@ -28,8 +28,9 @@ def _frames_bytes(images: torch.Tensor) -> int:
 PIPELINED = True
 
 
-def _run_grouped(images, fn, multiple_of=1):
-    """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame)` returns GPU frames."""
+def _run_grouped(images, fn, multiple_of=1, fn_for_device=None):
+    """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame)` returns GPU frames.  `fn_for_device(device)`
+    builds that callable for one of several GPUs (VRGDG_DEVICES, _devices.stream_frames); `fn` is the compute device's."""
     dev = compute_device()
     out_dev = intermediate_device()
     if images.is_cuda:
@@ -38,7 +39,7 @@ def _run_grouped(images, fn, multiple_of=1):
         images = images.float()
     if PIPELINED and out_dev.type == "cpu" and images.shape[0] > 0:
         # CPU in, CPU out (ComfyUI's default): H2D, kernels and D2H overlapped on three streams
-        return stream_frames(images, fn, multiple_of)
+        return stream_frames(images, fn, multiple_of, fn_for_device=fn_for_device)
     pieces = []
     for s, e in frame_groups(images.shape[0], _frames_bytes(images), multiple_of):
         pieces.append(fn(images[s:e].to(dev), s).to(out_dev))
@@ -70,7 +71,19 @@ class FastFilmGrain:
         def run(gpu_frames, _first):
             return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step)
 
-        return (_run_grouped(images, run, multiple_of=step),)
+        primary = compute_device()
+
+        def run_on(dev):
+            # several GPUs: the noise of every piece is reserved -- in submission order, on the host -- from the PRIMARY device's
+            # generator, the one the reference's torch.randn calls would consume; the piece itself may run on any of the GPUs
+            def run_d(gpu_frames, _first):
+                n = int(gpu_frames.shape[0])
+                plans = ops.plan_noise(n, int(gpu_frames[0].numel()), step, primary)
+                return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step, plans=plans)
+            return run_d
+
+        many = images.ndim == 4 and images.shape[0] > 0 and not ops.oversize_chunks(int(images.shape[0]), int(images[0].numel()), step)
+        return (_run_grouped(images, run, multiple_of=step, fn_for_device=run_on if many else None),)
 
 
 class ColorMatchToReference:
@@ -133,9 +146,19 @@ class ColorMatchToReference:
             return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
                                    ref_event=ref_ready)
 
+        def run_on(device):
+            if device == dev:
+                return run
+            ms_d, ready_d = ops.reference_stats_async(ref.to(device))        # every GPU reduces the reference frame itself: same bits
+
+            def run_d(gpu_frames, first):
+                return ops.color_match(gpu_frames, None, match_strength, ref_ms=ms_d, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
+                                       ref_event=ready_d)
+            return run_d
+
         if expand is not None:
             images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]
-        return (_run_grouped(images, run, multiple_of=group),)
+        return (_run_grouped(images, run, multiple_of=group, fn_for_device=run_on),)
 
 
 class _Sharpen:
@@ -163,7 +186,7 @@ class _Sharpen:
         def run(gpu_frames, _first):
             return ops.stencil3x3(gpu_frames, self._OP, strength, zero_border=bool(use_gpu))
 
-        return (_run_grouped(images, run),)
+        return (_run_grouped(images, run, fn_for_device=lambda _device: run),)
 
 
 class FastUnsharpSharpen(_Sharpen):

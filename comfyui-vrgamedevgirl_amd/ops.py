@@ -621,10 +621,13 @@ def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Option
     fe = H * W * 3
     if F:
         _device_stats_selfcheck(x.device)
+    lib = _hip.lib()
     for f0, nf, c in _chunk_runs(F, chunks):
-        _hip.check(_hip.lib().vrg_lab_stats_torch_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c,
-                                                     C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps), _hip.current_stream()),
-                   "vrg_lab_stats_torch_f32")
+        nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(nf)) if nf <= 32 else 0      # small batches: the half-block form wants a scratch buffer
+        scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=x.device) if nbytes else None
+        _hip.check(lib.vrg_lab_stats_torch_ws_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c, C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps),
+                                                 _hip.ptr(scratch) if scratch is not None else None, nbytes, _hip.current_stream()),
+                   "vrg_lab_stats_torch_ws_f32")
     return ms
 
 
@@ -837,17 +840,16 @@ def _pipe_stream(device) -> "torch.cuda.Stream":
 
 
 def default_overlap_pieces(frames: int, frame_elems: int) -> int:
-    """How many pieces the two-pass colour-match chain is cut into so that its passes overlap (0 / 1 = one piece, sequential passes).
-    VRGDG_CM_PIECES overrides.  Measured on the MI355X (profiles/r03_*): pass 1 (grain -> LUT -> Lab) is bound by the LUT's gather
-    address path with the vector ALUs 64 % busy, pass 2 (match -> Lab->RGB -> sharpen) by the vector ALUs with the address path idle;
-    run next to each other they share a CU's two bottlenecks instead of taking turns on them."""
+    """How many pieces the two-pass colour-match chain is cut into so that its passes overlap (0 / 1 = one piece, sequential passes: the
+    default).  VRGDG_CM_PIECES overrides.  Pass 1 (grain -> LUT -> Lab) is bound by the LUT's gather address path with the vector ALUs
+    64 % busy, pass 2 (match -> Lab->RGB -> sharpen) by the vector ALUs with the address path idle -- on paper they should share a CU's
+    two bottlenecks.  Measured on the MI355X (profiles/r03_pipelined_pieces_sweep.log): they do not -- two full-size grids on two
+    streams are dispatched one after the other (256 x 4K frames: 59.3 ms in one piece, 61.9 / 62.4 / 68.9 / 82.0 in 2 / 4 / 8 / 16;
+    the small pieces' statistics reductions are latency bound on top), so the pipeline stays an option, off by default."""
     env = os.environ.get("VRGDG_CM_PIECES", "").strip()
     if env:
         return max(int(env), 0)
-    mpix = frames * frame_elems / 3.0 / 1e6
-    if mpix < 2 * 66.0:                    # fewer than two 8-frame 4K pieces: nothing to pipeline
-        return 0
-    return int(min(8, mpix // 66.0))
+    return 0
 
 
 def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):

@@ -62,7 +62,7 @@ def assert_bit_equal(got, want, what=""):
 def test_native_library_is_loaded(pkg):
     from comfyui_vrgamedevgirl_amd import _hip
     lib = _hip.lib()
-    assert lib.vrg_abi_version() == 3
+    assert lib.vrg_abi_version() == 4
     with open("/proc/self/maps") as fh:
         assert any("libvrgdg_hip.so" in line for line in fh), "HIP extension not mapped into the process"
     import ctypes as C
@@ -1943,3 +1943,64 @@ def test_pipelined_pieces_equal_the_one_piece_chain(ops, dev, F, chunk, bs, n_re
     again = ops.fused_chain(x, spec, overlap_pieces=pieces, kernel_events=ev, out=torch.empty_like(x), lab_workspace=torch.empty_like(x))
     assert_bit_equal(again, want, "pipelined, caller-supplied buffers, timed")
     assert {n for n, *_ in ev} == {"stats", "tstats", "apply"} and all(a.elapsed_ms(b) >= 0 for _, a, b, _ in ev)
+
+
+def test_node_path_over_several_gpu_lanes_equals_one_device(pkg, dev, monkeypatch):
+    """VRGDG_DEVICES: a host-fed batch goes round-robin over several GPUs (ComfyUI runs its graph in ONE process: this, not torchrun,
+    is how a node reaches the other GPUs of a node).  The 1-GPU test box exercises it with the device list [cuda:0, cuda:0, cuda:0] --
+    three lanes with their own upload / compute / download streams: per-lane LUT tables and reference statistics, grain noise
+    reserved from the primary generator in submission order -- and the results (and the generator afterwards) must equal the
+    single-device path bit for bit."""
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+    x = _rand((13, 48, 80, 3), 223)
+    ref = _rand((1, 20, 30, 3), 224)
+    ref3 = _rand((3, 20, 30, 3), 225)
+    frame_bytes = x[0].numel() * 4
+    calls = {
+        "grain bs=2": lambda: nodes.FastFilmGrain().apply_grain(x, 0.05, 0.5, 2)[0],
+        "grain bs=0": lambda: nodes.FastFilmGrain().apply_grain(x, 0.05, 0.5, 0)[0],
+        "sobel": lambda: nodes.FastSobelSharpen().apply_sobel(x, 0.7, False)[0],
+        "colour match bs=3": lambda: nodes.ColorMatchToReference().match_color(x, ref, 0.8, 3)[0],
+        "colour match, 3 references": lambda: nodes.ColorMatchToReference().match_color(x[:12], ref3, 1.0, 3)[0],
+        "lut": lambda: iv.VRGDG_LUTS().apply_lut(x, "AMD_WarmFilm_25.cube", "auto", 7.0)[0],
+    }
+    monkeypatch.setattr(nodes, "PIPELINED", True)
+    for pipe_bytes in (frame_bytes * 2, frame_bytes // 2):
+        monkeypatch.setattr(_devices, "PIPE_BYTES", pipe_bytes)
+        for name, fn in calls.items():
+            monkeypatch.delenv("VRGDG_DEVICES", raising=False)
+            torch.manual_seed(41)
+            one = fn()
+            after_one = torch.cuda.get_rng_state(dev)
+            monkeypatch.setenv("VRGDG_DEVICES", "0,0,0")
+            assert len(_devices.compute_devices()) == 3
+            torch.manual_seed(41)
+            many = fn()
+            assert torch.equal(torch.cuda.get_rng_state(dev), after_one), name
+            assert torch.equal(one, many), (name, pipe_bytes)
+    monkeypatch.setenv("VRGDG_DEVICES", "all")
+    assert [d.index for d in _devices.compute_devices()] == [dev.index] + [i for i in range(torch.cuda.device_count()) if i != dev.index]
+    monkeypatch.setenv("VRGDG_DEVICES", "7,99")
+    with pytest.raises(ValueError):
+        _devices.compute_devices()
+
+
+@pytest.mark.parametrize("F,H,W,b", [(1, 64, 3840, 1), (5, 8, 3840, 1), (6, 8, 3840, 2), (9, 8, 3840, 3), (32, 4, 3840, 1), (40, 4, 3840, 1), (12, 270, 480, 6),
+                                     (2, 2160, 3840, 1)])
+def test_device_statistics_forms_agree_with_torch(pkg, ops, dev, F, H, W, b):
+    """The three whole-frame forms of the statistics replay -- eight half-block workgroups per frame + finishing kernel (<= 32 frames,
+    scratch supplied), four workgroups per frame (<= 64 frames), one workgroup per frame -- against torch's mean / std on the device,
+    for every block shape ((256,2) / (128,4) / (64,8) = batch_size 1 / 2 / >= 3) and ragged last calls."""
+    import ctypes as C
+    from comfyui_vrgamedevgirl_amd import _hip
+    lab = (_rand((F, H, W, 3), 700 + F) * 130.0 - 45.0).to(dev)
+    want = _torch_reductions(lab, b)
+    lib = _hip.lib()
+    for with_scratch in (True, False):
+        got = torch.empty((F, 3, 2), device=dev)
+        nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(F)) if with_scratch else 0
+        scratch = torch.empty(max(nbytes // 4, 4), device=dev) if with_scratch else None
+        _hip.check(lib.vrg_lab_stats_torch_ws_f32(_hip.ptr(lab), F, H, W, b, _hip.ptr(got), ops._f32(1e-5), _hip.ptr(scratch) if with_scratch else None,
+                                                 nbytes, _hip.current_stream()), "vrg_lab_stats_torch_ws_f32")
+        assert _same_bits_or_nan(got, want), (with_scratch, (got - want).abs().max())
+    assert _same_bits_or_nan(ops.lab_stats_device(lab, b), want)

@@ -1,0 +1,62 @@
+"""Host-fed ("ComfyUI-realistic") rates of the four nodes: CPU tensors in, CPU tensors out, PCIe inclusive -- what a graph sees, never
+bench.py's `value`.  16 x 4K fp32 frames (1.6 GB each way per node call); pageable input (fresh torch.rand) and page-locked input (the
+result of a previous node of this pack); second call onwards (the first call page-locks the result buffer).
+    python tools/host_fed.py [--frames 16] [--out gpurun_out/host_fed_nodes.json]
+bench.py imports `measure` for its `host_fed` key (8 frames)."""
+import argparse, json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def measure(frames=16, H=2160, W=3840, reps=2):
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_vrgamedevgirl_amd import nodes, VRGDG_IV_Adjustments as iv
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((frames, H, W, 3), generator=g)
+    ref = x[:1].clone()
+    px = frames * H * W
+    nbytes = x.numel() * 4
+
+    def wall(fn):
+        r = fn(); torch.cuda.synchronize(); del r
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0); del r
+        return best
+
+    cases = [("FastFilmGrain (bs 4)", lambda t: nodes.FastFilmGrain().apply_grain(t, 0.04, 0.5, 4)[0]),
+             ("VRGDG_LUTS (AMD_TealOrange_33)", lambda t: iv.VRGDG_LUTS().apply_lut(t, "AMD_TealOrange_33.cube", "auto", 10.0)[0]),
+             ("ColorMatchToReference (bs 1)", lambda t: nodes.ColorMatchToReference().match_color(t, ref, 1.0, 1)[0]),
+             ("FastUnsharpSharpen", lambda t: nodes.FastUnsharpSharpen().apply_unsharp(t, 0.5, False)[0])]
+    rows = []
+    xp = x.pin_memory()
+    for name, fn in cases:
+        for label, src in (("pageable input", x), ("page-locked input", xp)):
+            t = wall(lambda: fn(src))
+            rows.append({"node": name, "input": label, "frames": frames, "seconds": round(t, 4), "Mpix_s": round(px / t / 1e6, 1),
+                         "GB_s_each_way": round(nbytes / t / 1e9, 2)})
+
+    def chain(t):
+        for _, fn in cases:
+            t = fn(t)
+        return t
+    t = wall(lambda: chain(x))
+    rows.append({"node": "grain -> LUT -> colour match -> unsharp, four node calls (each crosses PCIe both ways)", "input": "pageable input", "frames": frames,
+                 "seconds": round(t, 4), "Mpix_s": round(px / t / 1e6, 1)})
+    return {"frames": frames, "height": H, "width": W, "devices": os.environ.get("VRGDG_DEVICES", "") or "one", "rows": rows}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--out", default="gpurun_out/host_fed_nodes.json")
+    a = ap.parse_args()
+    res = measure(a.frames)
+    for r in res["rows"]:
+        print("[host]", r, flush=True)
+    os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+    with open(a.out, "w") as fh:
+        json.dump(res, fh, indent=1)
