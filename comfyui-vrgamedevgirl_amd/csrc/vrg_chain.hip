@@ -328,6 +328,8 @@ static int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) 
 }
 
 int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D0, int stages, hipStream_t st);
+bool apply_march_applicable(int stages, int32_t H, int32_t W);                                   // vrg_apply_march.hip
+int launch_apply_march(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, int stages, bool fast, hipStream_t st);
 bool produce_applicable(int stages, int64_t frame_elems);
 int launch_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
                     float one_minus_sat, const vrg_noise_desc* nd, void* stream);      // vrg_pointwise.hip
@@ -453,6 +455,14 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
         const int rc = launch_march(in, out, frames, height, width, D, desc->stages, (hipStream_t)stream);
         if (rc != VRG_ERR_UNSUPPORTED) return rc;
     }
+    // (LUT ->) colour match -> stencil without a grain stage -- pass 2 of the headline chain: the apply march (variant 0 and 2; 1 forces
+    // the LDS-tile kernel for A/B and cross-checks).  Frames whose statistics groups it cannot keep together fall through.
+#ifndef VRG_NO_APPLY_MARCH
+    if ((desc->variant & 0xff) != 1 && apply_march_applicable(desc->stages, height, width)) {
+        const int rc = launch_apply_march(in, out, frames, height, width, D, desc->stages, desc->cm_math == VRG_CM_MATH_FAST, (hipStream_t)stream);
+        if (rc != VRG_ERR_UNSUPPORTED) return rc;
+    }
+#endif
     if ((desc->variant & 0xff) == 0 && desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
         return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, false, (hipStream_t)stream);   // small cube: table in LDS
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)

@@ -18,7 +18,7 @@ lut = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOra
 ref_ms = ops.finalize_stats(ops.lab_stats(x[:1]))
 gen = torch.Generator(device=dev).manual_seed(5)
 spec = ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0) if which.startswith("chain4") else None,
-                     sharpen=("unsharp", 0.5, False), cm_math="fast" if which == "chain4fast" else None)
+                     sharpen=("unsharp", 0.5, False), cm_math="fast" if which == "chain4fast" else None, variant=int(os.environ.get("VRGDG_VARIANT", "0")))
 if which == "kernels":
     # stand-alone kernels: median HIP-event ms each
     from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as LVT
@@ -57,4 +57,4 @@ for it in range(iters + 2):
         tot["wall"] = w0.elapsed_ms(w1)
         for k, v in tot.items():
             acc.setdefault(k, []).append(v)
-print(os.environ.get("VRGDG_HIP_LIB", "default"), which, "pieces=" + os.environ.get("VRGDG_CM_PIECES", "auto"), {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})
+print(os.environ.get("VRGDG_HIP_LIB", "default"), which, "pieces=" + os.environ.get("VRGDG_CM_PIECES", "auto"), "variant=" + os.environ.get("VRGDG_VARIANT", "0"), {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})
