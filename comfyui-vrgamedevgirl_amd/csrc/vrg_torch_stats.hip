@@ -271,36 +271,78 @@ struct TsRound {
 // the Welford update chains of a wave are issue bound next to a second wave's (170 cycles per update with two waves per SIMD).
 struct TsRows { Welf w[3][8]; float m[3][8]; };
 
-template <int PART, int TS_DEPTH, bool ROWS = false>
-static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
-                                     Welf* lds_w, int t0 = 0, TsRows* rows_out = nullptr) {
+// The Welford update's division by the running count, delta / n, is what makes its chain long: the backend's IEEE sequence is nine
+// dependent instructions (v_div_scale, v_rcp_f32, five FMAs, v_div_fmas, v_div_fixup) of the thirteen per update, ~190 cycles per
+// update measured.  n is the same for every accumulator of a thread and known before the data arrives, so rn = 1.0f / n (IEEE, correctly
+// rounded) is formed OFF the chain and the quotient by Markstein's sequence  q = delta * rn;  e = fma(-n, q, delta);  q' = fma(e, rn, q)
+// -- three dependent operations -- which returns the correctly rounded quotient RN(delta / n) whenever rn is the correctly rounded
+// reciprocal and nothing under- or overflows (Markstein 1990; Cornea / Harrison / Tang: exceptions only for divisors with an all-ones
+// significand, which a count below 2^24 - 1 never is).  Nothing can under- or overflow for 2^-100 <= |delta| <= 2^100 or delta == 0; a
+// thread that ever sees another delta (or a NaN) raises `bad`, and a workgroup with a raised flag throws its accumulators away and
+// repeats the frame with the IEEE division (ts_accumulate<..., false>): the result is the IEEE one for every input, the common case
+// pays three instructions next to -- not on -- the chain.  tests: every statistics test compares with torch's own kernels; the
+// fallback is forced by test_device_statistics_markstein_fallback (subnormal-range frames).
+struct TsAcc {
+    float ma[3][4];
+    Welf wa[3][2];
+    int cnt;
+};
+
+static __device__ __forceinline__ bool ts_delta_safe(float d) {
+    const float a = __builtin_fabsf(d);
+    return ((a >= 0x1p-100f) & (a <= 0x1p+100f)) | (d == 0.0f);
+}
+
+template <bool FUSED, bool FAST>
+static __device__ __forceinline__ void ts_welf_update(Welf& a, float x, float nf1, float rn, bool& bad) {
+    const float delta = x - a.mean;
+    float q;
+    if (FAST) {
+        bad = bad | !ts_delta_safe(delta);
+        const float q0 = delta * rn;
+        const float e = __builtin_fmaf(-nf1, q0, delta);
+        q = __builtin_fmaf(e, rn, q0);
+    } else {
+        q = delta / nf1;
+    }
+    const float mean1 = a.mean + q;
+    const float d2 = x - mean1;
+    a.m2 = FUSED ? __builtin_fmaf(delta, d2, a.m2) : a.m2 + delta * d2;
+    a.mean = mean1;
+}
+
+// The thread loop of one frame part: every full round, then the last partial one.  Returns the `bad` flag of the FAST form.
+template <int PART, int TS_DEPTH, bool FAST>
+static __device__ __forceinline__ bool ts_accumulate(const float* __restrict__ base, int64_t n, int t, TsAcc& A) {
     typedef TsRound<PART> R;
     constexpr int NC = R::NC, C0 = PART == -1 ? 0 : (PART == 3 ? 0 : PART);
-    float* lds_m = reinterpret_cast<float*>(lds_w);
-    const int t = t0 + (int)threadIdx.x;
     const int64_t nvm = n / 4, nvw = n / 2;
-    float ma[3][4];
-    Welf wa[NC][2];
+    bool bad = false;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ma[c][i] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { wa[c][0] = WelfOp::ident(); wa[c][1] = WelfOp::ident(); }
+        for (int i = 0; i < 4; ++i) A.ma[c][i] = 0.0f;
+        A.wa[c][0] = WelfOp::ident(); A.wa[c][1] = WelfOp::ident();
+    }
+    A.cnt = 0;
 
     auto mean_vec = [&](const f32x4& a0, const f32x4& a1, const f32x4& a2) {
         const float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ma[c][i] = ma[c][i] + e[i * 3 + c];
+            for (int c = 0; c < 3; ++c) A.ma[c][i] = A.ma[c][i] + e[i * 3 + c];
     };
-    auto welf_vec = [&](const float* e) {              // e[pixel][channel], NC channels
+    auto welf_vec = [&](const float* e) {              // e[pixel][channel], NC channels: one update of accumulator 0 and of accumulator 1
+        const int n1 = A.cnt + 1;
+        const float nf1 = (float)n1;
+        const float rn = FAST ? 1.0f / nf1 : 0.0f;     // IEEE; depends on the count only, not on the data
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            wa[c][0] = WelfOp::reduce<false>(wa[c][0], e[c]);
-            wa[c][1] = WelfOp::reduce<true>(wa[c][1], e[NC + c]);
+            ts_welf_update<false, FAST>(A.wa[c][0], e[c], nf1, rn, bad);          // accumulator 0: unfused in libtorch_hip.so's main loop
+            ts_welf_update<true, FAST>(A.wa[c][1], e[NC + c], nf1, rn, bad);
         }
+        A.cnt = n1;
     };
     // full rounds (every thread has one mean vector and two Welford vectors), TS_DEPTH rounds of loads in flight
     const int64_t rounds = nvm / 512;
@@ -333,6 +375,35 @@ static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, 
             for (int c = 0; c < NC; ++c) { e[c] = q[C0 + c]; e[NC + c] = q[3 + C0 + c]; }
             welf_vec(e);
         }
+    // the counts as WelfordOps keeps them (int n and float nf; every accumulator of the thread took the same number of updates)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        A.wa[c][0].n = A.cnt; A.wa[c][0].nf = (float)A.cnt;
+        A.wa[c][1].n = A.cnt; A.wa[c][1].nf = (float)A.cnt;
+    }
+    return bad;
+}
+
+#ifndef VRG_TS_MARKSTEIN
+#define VRG_TS_MARKSTEIN 1
+#endif
+
+template <int PART, int TS_DEPTH, bool ROWS = false>
+static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
+                                     Welf* lds_w, int t0 = 0, TsRows* rows_out = nullptr) {
+    typedef TsRound<PART> R;
+    constexpr int NC = R::NC, C0 = PART == -1 ? 0 : (PART == 3 ? 0 : PART);
+    float* lds_m = reinterpret_cast<float*>(lds_w);
+    const int t = t0 + (int)threadIdx.x;
+    TsAcc A;
+    if (VRG_TS_MARKSTEIN && R::WELF) {
+        const bool bad = ts_accumulate<PART, TS_DEPTH, true>(base, n, t, A);
+        if (__syncthreads_or(bad ? 1 : 0)) ts_accumulate<PART, TS_DEPTH, false>(base, n, t, A);      // a delta outside the proven range: the IEEE division
+    } else {
+        ts_accumulate<PART, TS_DEPTH, false>(base, n, t, A);
+    }
+    float (&ma)[3][4] = A.ma;
+    Welf (&wa)[3][2] = A.wa;
     const int tl = (int)threadIdx.x;                   // index within this workgroup (== t unless ROWS)
     if constexpr (R::MEAN) {
 #pragma unroll

@@ -403,7 +403,7 @@ def test_bench_two_rank_flow_on_one_gpu_with_gloo(dev):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dist_backend"] == "gloo" and len(line["per_rank_ms_per_step"]) == 2
     assert line["value"] > 0 and line["scaling"] == "weak" and line["config"]["frames_per_gpu"] == 8
-    assert line["fast_variant"]["value"] > line["value"]
+    assert line["fast_variant"]["value"] > 0            # (which of the two is faster is not a property of two processes sharing one GPU)
 
 
 def test_stats_allreduce_entry_point_over_rccl(pkg, ops, dev):
@@ -2004,3 +2004,22 @@ def test_device_statistics_forms_agree_with_torch(pkg, ops, dev, F, H, W, b):
                                                  nbytes, _hip.current_stream()), "vrg_lab_stats_torch_ws_f32")
         assert _same_bits_or_nan(got, want), (with_scratch, (got - want).abs().max())
     assert _same_bits_or_nan(ops.lab_stats_device(lab, b), want)
+
+
+@pytest.mark.parametrize("F,b,scale", [(3, 1, 1e-33), (6, 2, 1e-36), (66, 1, 1e-33), (40, 1, 3e37), (4, 1, 1.0)])
+def test_device_statistics_markstein_fallback(pkg, ops, dev, F, b, scale):
+    """The whole-frame statistics kernels divide by the running count with Markstein's sequence (reciprocal off the dependent chain),
+    proven equal to the IEEE quotient for 2^-100 <= |delta| <= 2^100; a workgroup that meets another delta repeats its frame with the
+    IEEE division.  Frames of tiny values (every delta below 2^-100), of huge ones (deltas beyond 2^100, m2 overflowing to Inf -> NaN
+    like torch's) and a frame with a NaN pixel force that path: still torch's bits."""
+    lab = ((_rand((F, 8, 3840, 3), 800 + F) - 0.3) * scale).to(dev)
+    if scale == 1.0:
+        lab[1, 3, 17, 2] = float("nan")
+        lab[2, 0, 0, 0] = float("inf")
+    want = _torch_reductions(lab, b)
+    assert _same_bits_or_nan(ops.lab_stats_device(lab, b), want)
+    import ctypes as C
+    from comfyui_vrgamedevgirl_amd import _hip
+    got = torch.empty((F, 3, 2), device=dev)          # and the forms that take no scratch buffer
+    _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(lab), F, 8, 3840, b, _hip.ptr(got), ops._f32(1e-5), _hip.current_stream()), "stats")
+    assert _same_bits_or_nan(got, want)
