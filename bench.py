@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (CPU tensors in and out, PCIe inclusive) node rates of the line's `host_fed` key")
     ap.add_argument("--pieces", type=int, default=None, help="frame ranges the two-pass chain is pipelined over (pass 2 of piece i next to pass 1 of "
                                                            "piece i+1 on a second stream); default: ops.default_overlap_pieces; 1 = sequential passes")
+    ap.add_argument("--stats-pieces", type=int, default=None, help="frame ranges of pass 1 whose statistics reductions run on the high-priority side stream "
+                                                                 "next to pass 1 of the following range; default: ops.default_stats_pieces; 1 = one range")
     ap.add_argument("--same-data", action="store_true", help="frames are a function of their ABSOLUTE index in the job (rank r holds frames "
                                                              "[r*frames, (r+1)*frames) of one job-wide batch), so that runs with different GPU counts process "
                                                              "the same data; default: an independent batch per rank")
@@ -321,7 +323,7 @@ def main():
 
     ref_events = []
 
-    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats, pieces=args.pieces):
+    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats, pieces=args.pieces, stats_pieces=args.stats_pieces):
         ref_ms = ref_ev = None
         if "colormatch" in stages:
             if ops._cm_stats(cm_stats, cm_math, dev) == "device":
@@ -348,7 +350,7 @@ def main():
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
                              cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
-        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws, overlap_pieces=pieces)
+        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws, overlap_pieces=pieces, stats_pieces=stats_pieces)
 
     def barrier():
         if dist.is_initialized():
@@ -419,11 +421,11 @@ def main():
     n_pieces_used = max(launches_per_step.values()) if launches_per_step else 1
     exclusive_ms = None
     if "colormatch" in stages and n_pieces_used > 1:
-        step(pieces=1)
+        step(pieces=1, stats_pieces=1)
         barrier()
         ex_events = []
         for _ in range(2):
-            step(ex_events, pieces=1)
+            step(ex_events, pieces=1, stats_pieces=1)
         barrier()
         acc = {}
         for name, a, b, nf in ex_events:
@@ -544,9 +546,10 @@ def main():
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": launches_per_step,
                          "exclusive_passes_ms": exclusive_ms,
                          "overlap_note": (None if exclusive_ms is None else
-                                          f"the step is pipelined over {n_pieces_used} frame ranges: pass 2 (and the statistics reductions) of piece i run on a "
-                                          "second stream next to pass 1 of piece i+1, so `passes_ms` / `avg_launch_ms` are launch durations WHILE the other pass "
-                                          "shares the CUs (their sum exceeds ms_per_step); `exclusive_passes_ms` = the same kernels run one after the other"),
+                                          f"pass 1 runs as {launches_per_step.get('stats', 1)} frame ranges; the statistics reductions (`tstats`) of range i run on the "
+                                          "high-priority side stream next to pass 1 of range i+1, so their launch durations overlap pass 1's (the sum of `passes_ms` "
+                                          "exceeds ms_per_step) and only the last range's reductions are on the critical path; `exclusive_passes_ms` = the same kernels "
+                                          "run one after the other in one range"),
                          "issue": issue},
         }
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":

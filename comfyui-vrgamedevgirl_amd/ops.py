@@ -908,10 +908,80 @@ def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
     return out
 
 
+def default_stats_pieces(frames: int, frame_elems: int) -> int:
+    """Into how many frame ranges pass 1 of the two-pass colour-match chain is cut so that the statistics reductions of range i run --
+    on the high-priority side stream -- next to pass 1 of range i + 1 (0 / 1 = one range).  VRGDG_CM_STATS_PIECES overrides.  The
+    reductions are a handful of latency-bound workgroups per frame (csrc/vrg_torch_stats.hip); a high-priority queue gets them
+    dispatched beside the thousands of workgroups of pass 1 (the same mechanism hides the reference frame's statistics), so only the
+    last range's reductions stay on the critical path.  Ranges of about 32 4K frames: small enough for the last one to be short, large
+    enough for pass 1's launches to stay efficient."""
+    env = os.environ.get("VRGDG_CM_STATS_PIECES", "").strip()
+    if env:
+        return max(int(env), 0)
+    mpix = frames * frame_elems / 3.0 / 1e6
+    if mpix < 2 * 265.0:                   # fewer than two 32-frame 4K ranges: nothing to hide
+        return 0
+    return int(min(16, mpix // 265.0))
+
+
+def _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_events):
+    """Device-statistics two-pass chain with the statistics reductions off the critical path: pass 1 range by range on the caller's
+    stream; the reductions of range i on the high-priority side stream, behind an event, next to pass 1 of range i + 1; then pass 2 over
+    the whole batch in one launch.  Same kernels, same arguments per frame range, same results as the one-range form."""
+    F, H, W, _ = x.shape
+    fe = H * W * 3
+    lib = _hip.lib()
+    main = torch.cuda.current_stream()
+    side = _side_stream(x.device)
+    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
+    _device_stats_selfcheck(x.device)
+    keep = []
+    for f0, nf in pieces:
+        d1 = _chain_desc(spec, plan, keep, x)
+        if plan is not None:
+            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
+        if kernel_events is not None:
+            s0, s1 = HipEvent(), HipEvent()
+            s0.record()
+        _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
+                                              C.byref(d1), None, None, _hip.current_stream()), "vrg_chain_stats_lab_f32")
+        if kernel_events is not None:
+            s1.record()
+            kernel_events.append(("stats", s0, s1, nf))
+        done1 = torch.cuda.Event()
+        done1.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(done1)
+            if kernel_events is not None:
+                t0, t1 = HipEvent(), HipEvent()
+                t0.record()
+            lab_stats_device(lab_full[f0:f0 + nf], spec.cm_chunk, out=img_ms_full[f0:f0 + nf])
+            if kernel_events is not None:
+                t1.record()
+                kernel_events.append(("tstats", t0, t1, nf))
+    main.wait_stream(side)                      # the last range's reductions (and, on the same stream, the reference frame's statistics)
+    if spec.cm_ref_event is not None:
+        main.wait_event(spec.cm_ref_event)
+    d2 = _chain_desc(spec, plan, keep, x)
+    d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+    d2.img_ms = img_ms_full.data_ptr()
+    if kernel_events is not None:
+        e0, e1 = HipEvent(), HipEvent()
+        e0.record()
+    _hip.check(lib.vrg_fused_chain_f32(_hip.ptr(lab_full), _hip.ptr(out), F, H, W, C.byref(d2), _hip.current_stream()), "vrg_fused_chain_f32")
+    if kernel_events is not None:
+        e1.record()
+        kernel_events.append(("apply", e0, e1, F))
+    for t in (lab_full, img_ms_full):
+        t.record_stream(side)
+    return out
+
+
 @_on_device
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
-                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True, overlap_pieces: Optional[int] = None) -> torch.Tensor:
+                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True, overlap_pieces: Optional[int] = None,
+                stats_pieces: Optional[int] = None) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
     pass).  Bit-identical to applying the stand-alone operators in that order.
 
@@ -984,6 +1054,10 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         # Software pipeline over frame ranges (see _fused_chain_pipelined / default_overlap_pieces): only when the batch is one run of
         # equal RNG chunks and equal statistics calls, so that every piece is made of whole chunks and whole calls
         n_pieces = default_overlap_pieces(F, fe) if overlap_pieces is None else int(overlap_pieces)
+        n_stats = 0 if n_pieces > 1 else (default_stats_pieces(F, fe) if stats_pieces is None else int(stats_pieces))
+        overlap_stats = n_stats > 1
+        if overlap_stats:
+            n_pieces = n_stats
         if n_pieces > 1 and len(segments) == 1 and isinstance(spec.cm_chunk, int):
             plan = segments[0][2]
             unit = spec.cm_chunk * (plan.chunk_frames if plan is not None else 1) // math.gcd(spec.cm_chunk, plan.chunk_frames if plan is not None else 1)
@@ -995,6 +1069,8 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
                 n_pieces = min(n_pieces, units)
                 per = (units + n_pieces - 1) // n_pieces * unit
                 pieces = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
+                if overlap_stats:
+                    return _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_events)
                 return _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events)
         for f0, nf, plan in segments:
             keep = []

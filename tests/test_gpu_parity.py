@@ -1943,6 +1943,15 @@ def test_pipelined_pieces_equal_the_one_piece_chain(ops, dev, F, chunk, bs, n_re
     again = ops.fused_chain(x, spec, overlap_pieces=pieces, kernel_events=ev, out=torch.empty_like(x), lab_workspace=torch.empty_like(x))
     assert_bit_equal(again, want, "pipelined, caller-supplied buffers, timed")
     assert {n for n, *_ in ev} == {"stats", "tstats", "apply"} and all(a.elapsed_ms(b) >= 0 for _, a, b, _ in ev)
+    # the other schedule over the same ranges: only the statistics reductions leave the caller's stream (high-priority side stream,
+    # next to pass 1 of the following range), pass 2 is one launch over the batch
+    ev = []
+    torch.manual_seed(9)
+    got = ops.fused_chain(x, spec, stats_pieces=pieces, kernel_events=ev)
+    torch.cuda.synchronize()
+    assert gen.get_offset() == off_want
+    assert_bit_equal(got, want, f"statistics of {pieces} ranges overlapped with pass 1 vs one range")
+    assert sum(1 for n, *_ in ev if n == "apply") == 1 and sum(1 for n, *_ in ev if n == "tstats") >= 2
 
 
 def test_node_path_over_several_gpu_lanes_equals_one_device(pkg, dev, monkeypatch):
