@@ -11,6 +11,8 @@
 // lane, so strips and segments need no special cases; the last strip of a row and the last segment of a frame START EARLIER
 // instead of ending short (they overlap their neighbours and store the same values twice).  Same per-pixel functions as every
 // other kernel (chain_apply_stages, stencil_value): bit-identical results.
+#include <stdlib.h>
+
 #include "vrg_chain_stages.hpp"
 
 namespace vrg {
@@ -36,13 +38,20 @@ __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in,
                                                       int32_t segs_y, uint32_t total_waves, ChainK D) {
     VRG_CM_MATH(PT, (STAGES & VRG_STAGE_COLORMATCH) != 0, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     // XCD-aware placement as in k_chain_tile: workgroup b runs on XCD b % 8; give every XCD one contiguous run of work
+    // Persistent form (gridDim.x smaller than the number of wave groups): every workgroup walks its XCD's run of groups with a stride
+    // of gridDim.x / 8 -- a few workgroups per CU that stay resident next to ANOTHER kernel's workgroups (ops: pass 2 of one frame range
+    // on the high-priority stream beside pass 1 of the next range).
     const uint32_t groups = (total_waves + 3u) / 4u;
     const uint32_t per_xcd = (groups + 7u) / 8u;
-    const uint32_t grp = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || grp >= groups) return;
-    const uint32_t wv = grp * 4u + (threadIdx.x >> 6);
-    if (wv >= total_waves) return;
     const int lane = threadIdx.x & 63;
+    const bool zero = D.zero_border != 0;
+    const int64_t ppf = (int64_t)H * W;
+    const float n0[3] = {0.0f, 0.0f, 0.0f};
+    for (uint32_t slot = blockIdx.x >> 3; slot < per_xcd; slot += (gridDim.x >> 3)) {
+    const uint32_t grp = (blockIdx.x & 7u) * per_xcd + slot;
+    if (grp >= groups) break;
+    const uint32_t wv = grp * 4u + (threadIdx.x >> 6);
+    if (wv >= total_waves) break;
     const uint32_t strip = wv % (uint32_t)strips_x;
     const uint32_t rest = wv / (uint32_t)strips_x;
     const uint32_t seg = rest % (uint32_t)segs_y;
@@ -55,12 +64,9 @@ __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in,
     const bool x_in = x >= 0 && x < W;
     const int32_t xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
     const bool stores = lane >= 1 && lane <= APPLY_COLS && x_in;                 // (x_in: frames narrower than a strip)
-    const bool zero = D.zero_border != 0;
-    const int64_t ppf = (int64_t)H * W;
     const px3* fin = in + f * ppf;
     px3* fout = out + f * ppf;
     const FrameCtx FC = frame_ctx<STAGES>(D, f);
-    const float n0[3] = {0.0f, 0.0f, 0.0f};
 
     auto load = [&](int32_t y) {                                                  // raw pixel of row y (clamped), this lane's column
         const int32_t yc = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
@@ -106,6 +112,19 @@ __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in,
         q = load(y + 4);
         emit(y + 2, r2, r0, r1);
     }
+    }       // persistent walk
+}
+
+static int apply_march_persistent_blocks(uint32_t blocks) {
+    // VRGDG_APPLY_PERSISTENT = workgroups per CU of the persistent form (0 = one workgroup per wave group, the default); read per call
+    const char* e = getenv("VRGDG_APPLY_PERSISTENT");
+    if (!e || !*e) return (int)blocks;
+    const int per_cu = atoi(e);
+    if (per_cu <= 0) return (int)blocks;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return (int)blocks;
+    const uint32_t want = (uint32_t)(((cus * per_cu + 7) / 8) * 8);
+    return (int)(want < blocks ? want : blocks);
 }
 
 template <int STAGES>
@@ -125,7 +144,7 @@ static int launch_apply_march_t(const float* in, float* out, int64_t frames, int
         if (STAGES & VRG_STAGE_COLORMATCH) d.cm.img_ms += f0 * 6;
         const uint32_t total = (uint32_t)(per_frame * nf);
         const uint32_t groups = (total + 3u) / 4u;
-        const uint32_t blocks = ((groups + 7u) / 8u) * 8u;
+        const uint32_t blocks = (uint32_t)apply_march_persistent_blocks(((groups + 7u) / 8u) * 8u);
         hipLaunchKernelGGL((k_apply_march<STAGES>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
                            reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
