@@ -11,8 +11,6 @@
 // lane, so strips and segments need no special cases; the last strip of a row and the last segment of a frame START EARLIER
 // instead of ending short (they overlap their neighbours and store the same values twice).  Same per-pixel functions as every
 // other kernel (chain_apply_stages, stencil_value): bit-identical results.
-#include <stdlib.h>
-
 #include "vrg_chain_stages.hpp"
 
 namespace vrg {
@@ -38,9 +36,8 @@ __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in,
                                                       int32_t segs_y, uint32_t total_waves, ChainK D) {
     VRG_CM_MATH(PT, (STAGES & VRG_STAGE_COLORMATCH) != 0, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
     // XCD-aware placement as in k_chain_tile: workgroup b runs on XCD b % 8; give every XCD one contiguous run of work
-    // Persistent form (gridDim.x smaller than the number of wave groups): every workgroup walks its XCD's run of groups with a stride
-    // of gridDim.x / 8 -- a few workgroups per CU that stay resident next to ANOTHER kernel's workgroups (ops: pass 2 of one frame range
-    // on the high-priority stream beside pass 1 of the next range).
+    // (a launch with fewer workgroups than wave groups walks them with a stride of gridDim.x / 8 per XCD: the persistent form, used
+    // by an experiment that ran pass 2 beside pass 1 -- slower, ops.default_stats_pieces -- and kept because it costs nothing)
     const uint32_t groups = (total_waves + 3u) / 4u;
     const uint32_t per_xcd = (groups + 7u) / 8u;
     const int lane = threadIdx.x & 63;
@@ -115,18 +112,6 @@ __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in,
     }       // persistent walk
 }
 
-static int apply_march_persistent_blocks(uint32_t blocks) {
-    // VRGDG_APPLY_PERSISTENT = workgroups per CU of the persistent form (0 = one workgroup per wave group, the default); read per call
-    const char* e = getenv("VRGDG_APPLY_PERSISTENT");
-    if (!e || !*e) return (int)blocks;
-    const int per_cu = atoi(e);
-    if (per_cu <= 0) return (int)blocks;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return (int)blocks;
-    const uint32_t want = (uint32_t)(((cus * per_cu + 7) / 8) * 8);
-    return (int)(want < blocks ? want : blocks);
-}
-
 template <int STAGES>
 static int launch_apply_march_t(const float* in, float* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, hipStream_t st) {
     const int32_t strips_x = (W + APPLY_COLS - 1) / APPLY_COLS, segs_y = (H + APPLY_ROWS - 1) / APPLY_ROWS;
@@ -144,7 +129,7 @@ static int launch_apply_march_t(const float* in, float* out, int64_t frames, int
         if (STAGES & VRG_STAGE_COLORMATCH) d.cm.img_ms += f0 * 6;
         const uint32_t total = (uint32_t)(per_frame * nf);
         const uint32_t groups = (total + 3u) / 4u;
-        const uint32_t blocks = (uint32_t)apply_march_persistent_blocks(((groups + 7u) / 8u) * 8u);
+        const uint32_t blocks = ((groups + 7u) / 8u) * 8u;
         hipLaunchKernelGGL((k_apply_march<STAGES>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
                            reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;

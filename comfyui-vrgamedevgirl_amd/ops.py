@@ -908,72 +908,15 @@ def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
     return out
 
 
-def _fused_chain_p2_overlap(x, out, spec, plan, lab_full, pieces, kernel_events, per_cu):
-    """EXPERIMENT (VRGDG_CM_P2_OVERLAP): like _fused_chain_stats_overlap, but pass 2 of range i also goes to the high-priority side
-    stream, in its persistent form (`per_cu` workgroups per CU that walk the range's tiles), so that a few pass-2 workgroups sit on
-    every CU next to pass 1 of range i + 1: pass 1 is bound by the gather address path with the vector ALUs 64 % busy, pass 2 by the
-    vector ALUs.  The last range's pass 2 runs as an ordinary full grid."""
-    F, H, W, _ = x.shape
-    fe = H * W * 3
-    lib = _hip.lib()
-    main = torch.cuda.current_stream()
-    side = _side_stream(x.device)
-    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
-    _device_stats_selfcheck(x.device)
-    keep = []
-    side.wait_stream(main)
-    for i, (f0, nf) in enumerate(pieces):
-        d1 = _chain_desc(spec, plan, keep, x)
-        if plan is not None:
-            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
-        if kernel_events is not None:
-            s0, s1 = HipEvent(), HipEvent()
-            s0.record()
-        _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
-                                              C.byref(d1), None, None, _hip.current_stream()), "vrg_chain_stats_lab_f32")
-        if kernel_events is not None:
-            s1.record()
-            kernel_events.append(("stats", s0, s1, nf))
-        done1 = torch.cuda.Event()
-        done1.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(done1)
-            if i == 0 and spec.cm_ref_event is not None:
-                side.wait_event(spec.cm_ref_event)
-            if kernel_events is not None:
-                t0, t1 = HipEvent(), HipEvent()
-                t0.record()
-            lab_stats_device(lab_full[f0:f0 + nf], spec.cm_chunk, out=img_ms_full[f0:f0 + nf])
-            if kernel_events is not None:
-                t1.record()
-                kernel_events.append(("tstats", t0, t1, nf))
-            d2 = _chain_desc(spec, plan, keep, x)
-            d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
-            d2.img_ms = img_ms_full.data_ptr() + f0 * 24
-            last = i == len(pieces) - 1
-            os.environ["VRGDG_APPLY_PERSISTENT"] = "0" if last else str(per_cu)
-            if kernel_events is not None:
-                e0, e1 = HipEvent(), HipEvent()
-                e0.record()
-            _hip.check(lib.vrg_fused_chain_f32(C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), C.c_void_p(out.data_ptr() + f0 * fe * 4), nf, H, W,
-                                              C.byref(d2), _hip.current_stream()), "vrg_fused_chain_f32")
-            os.environ["VRGDG_APPLY_PERSISTENT"] = "0"
-            if kernel_events is not None:
-                e1.record()
-                kernel_events.append(("apply", e0, e1, nf))
-    main.wait_stream(side)
-    for t in (x, out, lab_full, img_ms_full):
-        t.record_stream(side)
-    return out
-
-
 def default_stats_pieces(frames: int, frame_elems: int) -> int:
     """Into how many frame ranges pass 1 of the two-pass colour-match chain is cut so that the statistics reductions of range i run --
     on the high-priority side stream -- next to pass 1 of range i + 1 (0 / 1 = one range: the default).  VRGDG_CM_STATS_PIECES
     overrides.  Measured on the MI355X (profiles/r03_stats_overlap_sweep.log) and NOT adopted: 256 x 4K frames 56.4 ms in one range,
     61.0 / 66.4 / 65.9 / 74.2 in 2 / 4 / 8 / 16 -- next to pass 1's seven waves per SIMD the reductions' dependent chains are starved
-    of issue slots (a range's reductions 12 ms instead of 2.6) and pass 1 itself slows by a quarter (43.7 instead of 33.7 ms).  Only
-    the reference frame's handful of workgroups is worth a second stream."""
+    of issue slots (a range's reductions 12 ms instead of 2.6) and pass 1 itself slows by a quarter (43.7 instead of 33.7 ms).  A third
+    schedule -- pass 2 of range i as a PERSISTENT kernel (1 / 2 / 3 workgroups per CU walking the range's strips) on the high-priority
+    stream beside pass 1 of range i + 1 -- was built and measured too: 62.4 - 85.3 ms (profiles/r03_persistent_pass2_overlap_sweep.log);
+    removed.  Only the reference frame's handful of workgroups is worth a second stream."""
     env = os.environ.get("VRGDG_CM_STATS_PIECES", "").strip()
     if env:
         return max(int(env), 0)
@@ -1125,8 +1068,6 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
                 n_pieces = min(n_pieces, units)
                 per = (units + n_pieces - 1) // n_pieces * unit
                 pieces = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
-                if overlap_stats and os.environ.get("VRGDG_CM_P2_OVERLAP", "").strip() not in ("", "0"):
-                    return _fused_chain_p2_overlap(x, out, spec, plan, lab_full, pieces, kernel_events, int(os.environ["VRGDG_CM_P2_OVERLAP"]))
                 if overlap_stats:
                     return _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_events)
                 return _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events)
