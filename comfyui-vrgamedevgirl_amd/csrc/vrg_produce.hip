@@ -67,10 +67,11 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : (STATS ? VRG_PRODUCE_WAVES : VR
     const uint32_t per_chunk = P.K * P.NB;
     const uint32_t G = P.G;
     uint32_t chunk, k, ib;
+    uint32_t bx = blockIdx.x;
     if (!TWO_PART) {
         // one workgroup per (chunk, k, run); runs that cross a frame boundary are left to the TWO_PART launch
-        chunk = blockIdx.x / per_chunk;
-        const uint32_t rem = blockIdx.x - chunk * per_chunk;
+        chunk = bx / per_chunk;
+        const uint32_t rem = bx - chunk * per_chunk;
         k = rem / P.NB;
         ib = rem - k * P.NB;
     } else {
