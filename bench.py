@@ -172,10 +172,13 @@ def live_traffic(timeout_s=150):
         wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
         vi = sum(sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) for k, v in per_px.items() if match(k) and "SQ_INSTS_VALU" in v)
         return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1)}
-    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k), "tstats": bpp(lambda k: "k_tstats_frame" in k),
+    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_apply_march<20" in k or "k_chain_tile<20" in k),
+           "tstats": bpp(lambda k: "k_tstats_frame" in k or "k_tstats_rows<" in k),
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")
+    # the staged form runs the three kernels' device code as roles of one launch per stage: per pixel of the chain, their sum
+    res["stage"] = {k: round(sum(res[p][k] for p in ("stats", "tstats", "apply")), 2) for k in ("read", "written", "total", "valu_lane_instr")}
     return res
 
 
@@ -431,12 +434,16 @@ def main():
         for name, a, b, nf in ex_events:
             acc.setdefault(name, []).append(a.elapsed_ms(b))
         exclusive_ms = {k: round(sum(v) / 2, 4) for k, v in acc.items()}
-    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}                      # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
+    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12, "stage": 36}         # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px); the
+                                                                             # stage launches of a step together ARE the chain: 36 B/px
     kern_names = {"stats": ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it "
                             "by k_tstats_frame)" if "grain" in stages else
                             "k_lab_partials, Lab-only form (rgb->Lab pass 1, stores the Lab image; the statistics are reduced from it by k_tstats_frame)"),
                   "tstats": "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)",
-                  "apply": "k_chain_tile<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, LDS tile)" if "colormatch" in stages
+                  "stage": "k_stage (one launch per pipeline stage over 32-frame ranges; its workgroups run pass 1 = grain->LUT->Lab of range s, the torch-order "
+                           "statistics of range s-1 and pass 2 = match->Lab->RGB->unsharp of range s-2: the device code of k_produce_lab, k_tstats_rows and "
+                           "k_apply_march as roles of one grid)",
+                  "apply": "k_apply_march<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, register-resident wave march)" if "colormatch" in stages
                   else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
                         else "k_chain_tile / k_chain_pointwise (fused apply pass)")}
     dom = max(pass_ms, key=pass_ms.get)
@@ -487,7 +494,7 @@ def main():
         rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
         peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
         # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
-        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
+        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20", ("chain4_4k", "stage"): "k_stage",
                 ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
         ipp = live_ipp if live_ipp else next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
         src = ("a rocprofv3 --pmc SQ_INSTS_VALU pass on this box right after the timed region (own process, 16x4K frames)" if live_ipp
@@ -546,10 +553,10 @@ def main():
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": launches_per_step,
                          "exclusive_passes_ms": exclusive_ms,
                          "overlap_note": (None if exclusive_ms is None else
-                                          f"pass 1 runs as {launches_per_step.get('stats', 1)} frame ranges; the statistics reductions (`tstats`) of range i run on the "
-                                          "high-priority side stream next to pass 1 of range i+1, so their launch durations overlap pass 1's (the sum of `passes_ms` "
-                                          "exceeds ms_per_step) and only the last range's reductions are on the critical path; `exclusive_passes_ms` = the same kernels "
-                                          "run one after the other in one range"),
+                                          f"the step runs as {n_pieces_used} stage launches (`stage`: pass 1 / statistics / pass 2 of three consecutive frame ranges as "
+                                          "workgroup roles of one grid, csrc/vrg_stage.hip); `exclusive_passes_ms` = the same device code as three kernels one after "
+                                          "the other over the whole batch (ops.fused_chain(..., overlap_pieces=1))"
+                                          if "stage" in pass_ms else "see ops.fused_chain: pieces"),
                          "issue": issue},
         }
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":

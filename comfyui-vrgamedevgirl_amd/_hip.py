@@ -53,6 +53,15 @@ class AdjustDesc(C.Structure):
                 ("div_mode", C.c_int32)]
 
 
+class StageDesc(C.Structure):
+    """vrg_stage_desc"""
+    _fields_ = [("height", C.c_int32), ("width", C.c_int32),
+                ("p1_in", C.c_void_p), ("p1_lab", C.c_void_p), ("p1_frames", C.c_int64), ("p1_desc", C.POINTER(ChainDesc)),
+                ("stats_lab", C.c_void_p), ("stats_frames", C.c_int64), ("stats_chunk_frames", C.c_int32), ("stats_eps", C.c_float),
+                ("stats_mean_std", C.c_void_p), ("stats_scratch", C.c_void_p), ("stats_scratch_bytes", C.c_int64),
+                ("p2_lab", C.c_void_p), ("p2_out", C.c_void_p), ("p2_frames", C.c_int64), ("p2_desc", C.POINTER(ChainDesc))]
+
+
 _F3 = C.c_float * 3
 _P = C.c_void_p
 _SIGNATURES = {
@@ -101,6 +110,8 @@ _SIGNATURES = {
     "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
     "vrg_chain_stats_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc)]),
+    "vrg_chain_stage_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "vrg_chain_stage_f32": (C.c_int, [C.POINTER(StageDesc), _P]),
     "vrg_chain_stats_lab_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
 }
 

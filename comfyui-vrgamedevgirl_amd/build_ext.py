@@ -20,10 +20,10 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
 STAMP = LIB_PATH + ".stamp"
 
-SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_adjust.hip",
+SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_stage.hip", "vrg_adjust.hip",
            "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip")
 HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
-           "vrg_ziv_log_table.inc")
+           "vrg_ziv_log_table.inc", "vrg_produce_body.hpp", "vrg_apply_body.hpp", "vrg_tstats_body.hpp")
 
 # -ffp-contract=off : the reference performs one rounding per op; FMAs are written explicitly where
 #                     torch's own device code has them (Box-Muller).
@@ -37,7 +37,7 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # at 1.8x a plain one on gfx950 (profiles/r02_valu_issue_rate_long.json), so that is a loss: the device-exact colour-match
 # passes run 11-14 % faster without it, grain -> LUT 3 % (A/B: profiles/r02_ab_slp_vectorize.log).  The wave-march kernel
 # is the opposite (grain -> sharpen 26 % slower without SLP) and keeps the default.
-EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",)}
+EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",), "vrg_stage.hip": ("-fno-slp-vectorize",)}
 
 
 def _hipcc() -> str:

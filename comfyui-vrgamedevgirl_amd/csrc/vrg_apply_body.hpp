@@ -1,0 +1,107 @@
+// vrg_apply_body.hpp -- the workgroup body of the apply march (see vrg_apply_march.hip for the design), as a device function shared by
+// k_apply_march and the fused stage kernel (vrg_stage.hip).
+#pragma once
+#include "vrg_chain_stages.hpp"
+
+namespace vrg {
+
+#ifndef VRG_APPLY_ROWS
+#define VRG_APPLY_ROWS 60     /* rows per strip segment, a multiple of 3 (the row registers rotate by name) */
+#endif
+constexpr int APPLY_ROWS = VRG_APPLY_ROWS;
+constexpr int APPLY_COLS = 62;                    // output columns per wave
+static_assert(APPLY_ROWS % 3 == 0, "APPLY_ROWS must be a multiple of 3");
+
+__device__ __forceinline__ float am_prev(float v) {   // value held by lane-1 (lane 0: unused)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float am_next(float v) {   // value held by lane+1 (lane 63: unused)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+struct AmRow { float l[3], c[3], r[3]; };               // one processed row: left tap, own value, right tap per channel
+
+// The workgroup body of k_apply_march, callable from other kernels (the fused stage kernel, vrg_stage.hip): `vblock` / `vgrid` = the
+// workgroup's index in / the size of the apply grid, `PT` = the colour-match arithmetic object (tables staged in LDS by the caller).
+template <int STAGES, class MATH>
+__device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid, const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
+                                                 int32_t strips_x, int32_t segs_y, uint32_t total_waves, const ChainK& D, const MATH& PT) {
+    // XCD-aware placement as in k_chain_tile: workgroup b runs on XCD b % 8; give every XCD one contiguous run of work
+    // (a launch with fewer workgroups than wave groups walks them with a stride of vgrid / 8 per XCD: the persistent form, used
+    // by an experiment that ran pass 2 beside pass 1 -- slower, ops.default_stats_pieces -- and kept because it costs nothing)
+    const uint32_t groups = (total_waves + 3u) / 4u;
+    const uint32_t per_xcd = (groups + 7u) / 8u;
+    const int lane = threadIdx.x & 63;
+    const bool zero = D.zero_border != 0;
+    const int64_t ppf = (int64_t)H * W;
+    const float n0[3] = {0.0f, 0.0f, 0.0f};
+    for (uint32_t slot = vblock >> 3; slot < per_xcd; slot += (vgrid >> 3)) {
+    const uint32_t grp = (vblock & 7u) * per_xcd + slot;
+    if (grp >= groups) break;
+    const uint32_t wv = grp * 4u + (threadIdx.x >> 6);
+    if (wv >= total_waves) break;
+    const uint32_t strip = wv % (uint32_t)strips_x;
+    const uint32_t rest = wv / (uint32_t)strips_x;
+    const uint32_t seg = rest % (uint32_t)segs_y;
+    const int64_t f = rest / (uint32_t)segs_y;
+    int32_t x0 = (int32_t)strip * APPLY_COLS, y0 = (int32_t)seg * APPLY_ROWS;
+    if (W >= APPLY_COLS) x0 = x0 < W - APPLY_COLS ? x0 : W - APPLY_COLS;          // last strip: overlap instead of a ragged end
+    if (H >= APPLY_ROWS) y0 = y0 < H - APPLY_ROWS ? y0 : H - APPLY_ROWS;          // last segment: likewise
+    const int32_t rows = H >= APPLY_ROWS ? APPLY_ROWS : H;
+    const int32_t x = x0 - 1 + lane;                                             // the column this lane evaluates
+    const bool x_in = x >= 0 && x < W;
+    const int32_t xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+    const bool stores = lane >= 1 && lane <= APPLY_COLS && x_in;                 // (x_in: frames narrower than a strip)
+    const px3* fin = in + f * ppf;
+    px3* fout = out + f * ppf;
+    const FrameCtx FC = frame_ctx<STAGES>(D, f);
+
+    auto load = [&](int32_t y) {                                                  // raw pixel of row y (clamped), this lane's column
+        const int32_t yc = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        return fin[(int64_t)yc * W + xc];
+    };
+    auto process = [&](const px3& v, int32_t y) {                                 // pre stages + the row's left / right taps
+        AmRow r;
+        const float xi[3] = {v.r, v.g, v.b};
+        float o[3];
+        chain_apply_stages<STAGES>(D, FC, xi, n0, o, PT);
+        const bool inside = x_in && y >= 0 && y < H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            r.c[c] = (zero && !inside) ? 0.0f : o[c];                             // replicate border = the clamped coordinate's own value
+            r.l[c] = am_prev(r.c[c]);
+            r.r[c] = am_next(r.c[c]);
+        }
+        return r;
+    };
+    auto emit = [&](int32_t y, const AmRow& a, const AmRow& b, const AmRow& c) {
+        float res[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float p[3][3] = {{a.l[ch], a.c[ch], a.r[ch]}, {b.l[ch], b.c[ch], b.r[ch]}, {c.l[ch], c.c[ch], c.r[ch]}};
+            res[ch] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
+        }
+        if (stores && y < y0 + rows) fout[(int64_t)y * W + x] = px3{res[0], res[1], res[2]};
+    };
+
+    AmRow r0 = process(load(y0 - 1), y0 - 1);
+    AmRow r1 = process(load(y0), y0);
+    AmRow r2;
+    const int32_t y1 = y0 + rows;
+    px3 q = load(y0 + 1);
+    for (int32_t y = y0; y < y1; y += 3) {                                        // three steps per trip: r0, r1, r2 rotate by name
+        r2 = process(q, y + 1);
+        q = load(y + 2);
+        emit(y, r0, r1, r2);
+        r0 = process(q, y + 2);
+        q = load(y + 3);
+        emit(y + 1, r1, r2, r0);
+        r1 = process(q, y + 3);
+        q = load(y + 4);
+        emit(y + 2, r2, r0, r1);
+    }
+    }       // persistent walk
+}
+
+
+}  // namespace vrg

@@ -908,6 +908,71 @@ def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
     return out
 
 
+def default_stage_frames(frames: int, frame_elems: int) -> int:
+    """Frames per range of the staged form of the two-pass colour-match chain (0 = not staged).  VRGDG_CM_STAGE_FRAMES overrides.
+    The staged form (csrc/vrg_stage.hip) runs pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 as roles of ONE
+    launch per stage: it needs at least three ranges to overlap anything, ranges small enough for a short pipeline head and tail and
+    large enough for the statistics role's chains (~1.6 ms for up to 32 4K frames) to fit inside a stage."""
+    env = os.environ.get("VRGDG_CM_STAGE_FRAMES", "").strip()
+    if env:
+        return max(int(env), 0)
+    mpix_frame = frame_elems / 3.0 / 1e6
+    per = max(1, int(round(265.0 / max(mpix_frame, 1e-9))))          # about 32 4K frames' worth of pixels
+    return per if frames >= 3 * per else 0
+
+
+def _fused_chain_staged(x, out, spec, plan, lab_full, ranges, kernel_events):
+    """grain -> (LUT) -> colour match -> sharpen with the device statistics as a software pipeline over `ranges` (>= 2 frame ranges of
+    whole RNG chunks / statistics calls / reference groups): stage s = ONE launch (vrg_chain_stage_f32) whose workgroups run pass 1 of
+    range s, the torch-order statistics of range s-1 and pass 2 of range s-2.  Returns False -- nothing launched -- when the library
+    cannot stage this chain (frame geometry, ...): the caller then takes the sequential form."""
+    F, H, W, _ = x.shape
+    fe = H * W * 3
+    lib = _hip.lib()
+    st = _hip.current_stream()
+    N = len(ranges)
+    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
+    most = max(nf for _, nf in ranges)
+    nbytes = int(lib.vrg_chain_stage_scratch_bytes(most))
+    scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=x.device)
+    _device_stats_selfcheck(x.device)
+    keep = [img_ms_full, scratch]
+    for s in range(N + 2):
+        sd = _hip.StageDesc()
+        sd.height, sd.width = H, W
+        if s < N:
+            f0, nf = ranges[s]
+            d1 = _chain_desc(spec, plan, keep, x)
+            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
+            sd.p1_in, sd.p1_lab, sd.p1_frames = x.data_ptr() + f0 * fe * 4, lab_full.data_ptr() + f0 * fe * 4, nf
+            sd.p1_desc = C.pointer(d1)
+        if 1 <= s <= N:
+            f0, nf = ranges[s - 1]
+            sd.stats_lab, sd.stats_frames, sd.stats_chunk_frames, sd.stats_eps = lab_full.data_ptr() + f0 * fe * 4, nf, int(spec.cm_chunk), _f32(1e-5)
+            sd.stats_mean_std = img_ms_full.data_ptr() + f0 * 24
+            sd.stats_scratch, sd.stats_scratch_bytes = scratch.data_ptr(), nbytes
+        if 2 <= s <= N + 1:
+            f0, nf = ranges[s - 2]
+            if s == 2 and spec.cm_ref_event is not None:
+                torch.cuda.current_stream().wait_event(spec.cm_ref_event)
+            d2 = _chain_desc(spec, plan, keep, x)
+            d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
+            d2.img_ms = img_ms_full.data_ptr() + f0 * 24
+            sd.p2_lab, sd.p2_out, sd.p2_frames = lab_full.data_ptr() + f0 * fe * 4, out.data_ptr() + f0 * fe * 4, nf
+            sd.p2_desc = C.pointer(d2)
+        if kernel_events is not None:
+            e0, e1 = HipEvent(), HipEvent()
+            e0.record()
+        rc = lib.vrg_chain_stage_f32(C.byref(sd), st)
+        if rc == 2 and s == 0:                   # VRG_ERR_UNSUPPORTED before anything ran
+            return False
+        _hip.check(rc, "vrg_chain_stage_f32")
+        if kernel_events is not None:
+            e1.record()
+            kernel_events.append(("stage", e0, e1, (ranges[s][1] if s < N else 0)))
+    return True
+
+
 def default_stats_pieces(frames: int, frame_elems: int) -> int:
     """Into how many frame ranges pass 1 of the two-pass colour-match chain is cut so that the statistics reductions of range i run --
     on the high-priority side stream -- next to pass 1 of range i + 1 (0 / 1 = one range: the default).  VRGDG_CM_STATS_PIECES
@@ -980,7 +1045,7 @@ def _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_even
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
                 lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True, overlap_pieces: Optional[int] = None,
-                stats_pieces: Optional[int] = None) -> torch.Tensor:
+                stats_pieces: Optional[int] = None, stage_frames: Optional[int] = None) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
     pass).  Bit-identical to applying the stand-alone operators in that order.
 
@@ -1054,6 +1119,23 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
         # equal RNG chunks and equal statistics calls, so that every piece is made of whole chunks and whole calls
         n_pieces = default_overlap_pieces(F, fe) if overlap_pieces is None else int(overlap_pieces)
         n_stats = 0 if n_pieces > 1 else (default_stats_pieces(F, fe) if stats_pieces is None else int(stats_pieces))
+        # The staged form (one launch per pipeline stage, csrc/vrg_stage.hip): chains grain -> (LUT) -> colour match -> sharpen over
+        # one run of equal RNG chunks and equal statistics calls, default arithmetic, when no other schedule was asked for
+        per_stage = 0
+        if n_pieces <= 1 and n_stats <= 1 and overlap_pieces is None and stats_pieces is None:
+            per_stage = default_stage_frames(F, fe) if stage_frames is None else int(stage_frames)
+        if (per_stage > 0 and len(segments) == 1 and segments[0][2] is not None and isinstance(spec.cm_chunk, int) and spec.sharpen is not None and
+                _cm_math(spec.cm_math) == _hip.CM_MATH_DEVICE and (spec.variant & 0xff) in (0, 2)):
+            plan = segments[0][2]
+            unit = spec.cm_chunk * plan.chunk_frames // math.gcd(spec.cm_chunk, plan.chunk_frames)
+            R = int(spec.colormatch[0].shape[0])
+            if R != 1:
+                unit = unit * R // math.gcd(unit, R)
+            per = max(unit, per_stage // unit * unit)
+            if F % unit == 0 and F >= 2 * per:
+                ranges = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
+                if _fused_chain_staged(x, out, spec, plan, lab_full, ranges, kernel_events):
+                    return out
         overlap_stats = n_stats > 1
         if overlap_stats:
             n_pieces = n_stats

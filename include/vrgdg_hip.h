@@ -291,6 +291,31 @@ int vrg_adjust_u8(const uint8_t* in, uint8_t* out, float* tmp, int64_t frames, i
                   const vrg_adjust_desc* desc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One stage of the headline chain's software pipeline over frame ranges (csrc/vrg_stage.hip): ONE launch whose workgroups take
+ * one of three roles -- pass 1 (grain -> LUT -> Lab) of a frame range, the torch-order statistics of the Lab image of the previous
+ * range, pass 2 (colour match from Lab -> 3x3 stencil) of the range before that -- so that the three share a CU's different
+ * bottlenecks (gather address path / vector ALUs / dependent-chain latency).  A host walks s = 0 .. ranges + 1 and hands stage s
+ * pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 (any of them may be empty: *_frames = 0; a stage with
+ * statistics only is VRG_ERR_UNSUPPORTED -- use vrg_lab_stats_torch_ws_f32).  Each role is the same device code as its stand-alone
+ * entry point (vrg_chain_stats_lab_f32 with stats = NULL, vrg_lab_stats_torch_ws_f32, vrg_fused_chain_f32 with
+ * COLORMATCH | FROM_LAB | SHARPEN): results are bit-identical to calling those one after the other.
+ *   p1_desc: stages GRAIN [| LUT], device colour-match arithmetic; p1_frames a multiple of the RNG chunk.
+ *   stats_*: `stats_frames` frames of the Lab image, `stats_chunk_frames` frames per reference call (dividing stats_frames; video-sized
+ *            frames only -- VRG_ERR_UNSUPPORTED otherwise), result in stats_mean_std [frames][3][2]; scratch of
+ *            vrg_chain_stage_scratch_bytes(stats_frames) bytes, 16-byte aligned.
+ *   p2_desc: stages COLORMATCH | FROM_LAB | SHARPEN with img_ms / ref_ms of the p2 frames.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vrg_stage_desc {
+    int32_t height, width;
+    const float* p1_in; float* p1_lab; int64_t p1_frames; const vrg_chain_desc* p1_desc;
+    const float* stats_lab; int64_t stats_frames; int32_t stats_chunk_frames; float stats_eps; float* stats_mean_std;
+    void* stats_scratch; int64_t stats_scratch_bytes;
+    const float* p2_lab; float* p2_out; int64_t p2_frames; const vrg_chain_desc* p2_desc;
+} vrg_stage_desc;
+int64_t vrg_chain_stage_scratch_bytes(int64_t stats_frames);
+int vrg_chain_stage_f32(const vrg_stage_desc* stage, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Introspection
  * ------------------------------------------------------------------------------------------- */
 int vrg_abi_version(void);

@@ -2032,3 +2032,38 @@ def test_device_statistics_markstein_fallback(pkg, ops, dev, F, b, scale):
     got = torch.empty((F, 3, 2), device=dev)          # and the forms that take no scratch buffer
     _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(lab), F, 8, 3840, b, _hip.ptr(got), ops._f32(1e-5), _hip.current_stream()), "stats")
     assert _same_bits_or_nan(got, want)
+
+
+@pytest.mark.parametrize("F,chunk,bs,n_ref,per,lut", [(12, 2, 1, 1, 4, True), (12, 2, 3, 1, 6, True), (16, 4, 2, 1, 4, False), (24, 4, 6, 3, 12, True),
+                                                      (20, 4, 1, 1, 8, True), (8, 1, 1, 1, 1, True)])
+def test_staged_pipeline_equals_the_sequential_chain(ops, dev, F, chunk, bs, n_ref, per, lut):
+    """The staged form of grain -> (LUT) -> colour match -> sharpen (csrc/vrg_stage.hip): one launch per pipeline stage whose workgroups run
+    pass 1 of frame range s, the torch-order statistics of range s-1 and pass 2 of range s-2.  Every role is the device code of its
+    stand-alone kernel, ranges are whole RNG chunks / statistics calls / reference groups: output bits and the generator afterwards equal
+    the sequential form's -- for every block shape of the statistics ((256,2) / (128,4) / (64,8)), with and without a LUT stage, a ragged
+    last range, single-frame ranges, and a reference batch."""
+    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
+    x = _rand((F, 96, 128, 3), 411).to(dev)
+    ref = _rand((n_ref, 30, 40, 3), 412).to(dev)
+    ref_ms = ops.reference_stats(ref)
+    spec = ops.ChainSpec(grain=(0.05, 0.4, chunk), lut=(dlut, 8.0) if lut else None, colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.6, False), cm_chunk=bs)
+    gen = torch.cuda.default_generators[dev.index]
+    torch.manual_seed(19)
+    want = ops.fused_chain(x, spec, overlap_pieces=1)                       # sequential passes
+    off_want = gen.get_offset()
+    ev = []
+    torch.manual_seed(19)
+    got = ops.fused_chain(x, spec, stage_frames=per, kernel_events=ev)
+    torch.cuda.synchronize()
+    assert gen.get_offset() == off_want
+    n_ranges = -(-F // per)
+    assert [n for n, *_ in ev] == ["stage"] * (n_ranges + 2), [n for n, *_ in ev]       # really staged (not the fallback)
+    assert_bit_equal(got, want, f"staged pipeline, {n_ranges} ranges of {per} frames, vs sequential passes")
+    # and against the oracle composition (colour match evaluated by torch on the device)
+    torch.manual_seed(19)
+    o = R.fast_film_grain(x.cpu(), 0.05, 0.4, chunk, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    if lut:
+        o = R.apply_lut_with_strength(o, data, 8.0)
+    if n_ref == 1:
+        o = R.unsharp(R.color_match(o.to(dev), ref, 0.9, bs).cpu(), 0.6, False)
+        assert_bit_equal(got, o, "staged pipeline vs the oracle composition")
