@@ -909,16 +909,18 @@ def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
 
 
 def default_stage_frames(frames: int, frame_elems: int) -> int:
-    """Frames per range of the staged form of the two-pass colour-match chain (0 = not staged).  VRGDG_CM_STAGE_FRAMES overrides.
-    The staged form (csrc/vrg_stage.hip) runs pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 as roles of ONE
-    launch per stage: it needs at least three ranges to overlap anything, ranges small enough for a short pipeline head and tail and
-    large enough for the statistics role's chains (~1.6 ms for up to 32 4K frames) to fit inside a stage."""
+    """Frames per range of the staged form of the two-pass colour-match chain (0 = not staged: the default).  VRGDG_CM_STAGE_FRAMES
+    overrides.  The staged form (csrc/vrg_stage.hip) runs pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 as
+    workgroup roles of ONE launch per stage.  Measured on the MI355X (profiles/r03_staged_pipeline_first.log, r03_staged_pipeline_pmc.log):
+    it hides most of the statistics' latency (a stage with pass 1 + statistics: 5.3 ms against 4.5 + 1.6) but pass 2 is NOT absorbed by
+    pass 1 -- a stage with all three roles takes 7.6 ms against 4.5 for pass 1 alone: pass 2 costs 2.25 ms inside the launch, 2.42 ms as
+    a kernel of its own.  96 x 4K frames: 22.6 ms staged, 23.7 sequential; 256 frames: 59.4 staged, 56.6 sequential (the short ranges
+    cost pass 1 its seven waves per SIMD and its tail).  Both passes run at ~80 % of the vector-ALU issue rate once their instruction
+    mix is weighted (transcendentals, 64-bit multiplies, compare / select pairs): there is no idle ALU time to share."""
     env = os.environ.get("VRGDG_CM_STAGE_FRAMES", "").strip()
     if env:
         return max(int(env), 0)
-    mpix_frame = frame_elems / 3.0 / 1e6
-    per = max(1, int(round(265.0 / max(mpix_frame, 1e-9))))          # about 32 4K frames' worth of pixels
-    return per if frames >= 3 * per else 0
+    return 0
 
 
 def _fused_chain_staged(x, out, spec, plan, lab_full, ranges, kernel_events):
