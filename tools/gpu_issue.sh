@@ -5,7 +5,7 @@ TAG=${1:-issue}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/issue_${TAG}
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS --output-format csv -d $OUT/p -o p -- python $GRAFT_REPO_ROOT/tools/prof_driver.py issue > $OUT/run.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 --output-format csv -d $OUT/p -o p -- python $GRAFT_REPO_ROOT/tools/prof_driver.py issue > $OUT/run.log 2>&1
 cd $OUT; python - <<'PY'
 import csv, glob, collections, json
 rows = collections.OrderedDict()

@@ -32,8 +32,8 @@ def bpp(match):
     return {"read": round(f, 2), "written": round(w, 2), "total": round(f + w, 2)}
 cal = out.get(next((k for k in out if "k_lut3d" in k), ""), {})
 summary = {"fetch_correction": 2.0, "calibration_k_lut3d_read_bytes_per_px_raw": cal.get("FETCH_SIZE", {}).get("per_pixel", 0) * 1024,
-           "stats": bpp(lambda k: "k_produce_lab<3" in k or "k_lab_partials<3" in k), "apply": bpp(lambda k: "k_chain_tile<20" in k),
-           "tstats": bpp(lambda k: "k_tstats_frame" in k),
+           "stats": bpp(lambda k: "k_produce_lab<3" in k or "k_lab_partials<3" in k), "apply": bpp(lambda k: "k_apply_march<20" in k or "k_chain_tile<20" in k),
+           "tstats": bpp(lambda k: "k_tstats_frame" in k or "k_tstats_rows<" in k),
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k or "k_chain_tile<3," in k or "k_chain_tile<3>" in k)}
 json.dump({"pixels_per_launch": px, "kernels": out, "summary": summary}, open("traffic.json", "w"), indent=1)
 print(summary)
