@@ -149,36 +149,39 @@ def live_traffic(timeout_s=150):
     per_px = {}
     px = 16 * 2160 * 3840
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
-            out = os.path.join(tmp, counter)
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64")):
+            out = os.path.join(tmp, counters[0])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--",
+            subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "p", "--",
                             sys.executable, os.path.join(ROOT, "tools", "prof_driver.py"), "traffic"],
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if "vrg" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                            # FETCH_SIZE / WRITE_SIZE count KB; SQ_INSTS_VALU counts wave64 instructions (x64 lanes)
-                            scale = 64.0 if counter == "SQ_INSTS_VALU" else 1024.0
-                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(counter, []).append(float(r["Counter_Value"]) * scale / px)
+                        if "vrg" in r["Kernel_Name"] and r["Counter_Name"] in counters:
+                            # FETCH_SIZE / WRITE_SIZE count KB; the SQ_INSTS_* count wave64 instructions (x64 lanes)
+                            scale = 64.0 if r["Counter_Name"].startswith("SQ_") else 1024.0
+                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]) * scale / px)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
     def bpp(match):
         rd = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 2.0 for k, v in per_px.items() if match(k) and "FETCH_SIZE" in v)
         wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
-        vi = sum(sum(v["SQ_INSTS_VALU"]) / len(v["SQ_INSTS_VALU"]) for k, v in per_px.items() if match(k) and "SQ_INSTS_VALU" in v)
-        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1)}
+        def avg(c):
+            return sum(sum(v[c]) / len(v[c]) for k, v in per_px.items() if match(k) and c in v)
+        vi, tr, i64 = avg("SQ_INSTS_VALU"), avg("SQ_INSTS_VALU_TRANS_F32"), avg("SQ_INSTS_VALU_INT64")
+        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1),
+                "valu_trans": round(tr, 1), "valu_int64": round(i64, 1)}
     res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_apply_march<20" in k or "k_chain_tile<20" in k),
            "tstats": bpp(lambda k: "k_tstats_frame" in k or "k_tstats_rows<" in k),
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")
     # the staged form runs the three kernels' device code as roles of one launch per stage: per pixel of the chain, their sum
-    res["stage"] = {k: round(sum(res[p][k] for p in ("stats", "tstats", "apply")), 2) for k in ("read", "written", "total", "valu_lane_instr")}
+    res["stage"] = {k: round(sum(res[p][k] for p in ("stats", "tstats", "apply")), 2) for k in ("read", "written", "total", "valu_lane_instr", "valu_trans", "valu_int64")}
     return res
 
 
@@ -453,7 +456,7 @@ def main():
     bytes_per_px_chain = 36 if "colormatch" in stages else 24
     # HBM traffic of the dominant pass from the PMC run committed under profiles/ (rocprofv3 cannot run inside this
     # process): bytes per pixel measured there x the pixels of one launch here
-    traffic, traffic_note, live_ipp = None, None, None
+    traffic, traffic_note, live_ipp, live_classes = None, None, None, (None, None)
     key = dom if "colormatch" in stages else "chain3_apply"
     if rank == 0 and world == 1 and not args.no_live_traffic and args.workload in ("chain4_4k", "chain3_4k"):
         try:
@@ -461,6 +464,7 @@ def main():
             torch.cuda.empty_cache()
             summ = live_traffic()
             live_ipp = summ.get(key, {}).get("valu_lane_instr") or None
+            live_classes = (summ.get(key, {}).get("valu_trans"), summ.get(key, {}).get("valu_int64"))
             if summ.get(key, {}).get("total"):
                 traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
                 traffic_note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on this box right after the timed region (separate "
@@ -500,8 +504,17 @@ def main():
         src = ("a rocprofv3 --pmc SQ_INSTS_VALU pass on this box right after the timed region (own process, 16x4K frames)" if live_ipp
                else f"profiles/{iname} (SQ_INSTS_VALU, not collected in this process)")
         rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
+        weighted = None
+        if live_ipp and live_classes[0] is not None:
+            # issue cost of the measured classes relative to a plain fp32 / integer op (profiles/r02_valu_issue_rate_long.json):
+            # transcendental 3.45x, 64-bit integer multiply-add 1.8x (compare + select pairs, 1.65x, have no counter: not included)
+            w_ipp = ipp + 2.45 * live_classes[0] + 0.8 * live_classes[1]
+            w_rate = w_ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
+            weighted = {"lane_instr_per_px": round(w_ipp, 1), "of_which_transcendental": live_classes[0], "of_which_int64": live_classes[1],
+                        "achieved": round(w_rate, 2), "frac_of_measured_peak_66p5": round(w_rate / peak_t, 4),
+                        "frac_of_guide_peak_78p6": round(w_rate / 78.6, 4), "unweighted_frac_of_guide_peak_78p6": round(rate_t / 78.6, 4)}
         issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
-                 "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4),
+                 "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4), "weighted": weighted,
                  "note": f"lane-instructions per pixel from {src} x this run's pixel rate; "
                          f"peak = v_fma_f32 at 8 waves/SIMD over >= 17 ms launches (profiles/{rname}); unweighted: v_pk_* / fp64 / "
                          "v_mad_u64_u32 issue at 1.8x, compare+select pairs 1.65x, transcendentals 3.45x a plain op"}

@@ -242,6 +242,15 @@ int ts_rows_finish(const void* rows, int64_t frames, int bh, float factor, float
 constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
+#ifndef VRG_TS_ROWS_DEPTH       /* rounds of loads in flight per thread: half-block form / four-workgroup form / whole-frame form */
+#define VRG_TS_ROWS_DEPTH 2
+#endif
+#ifndef VRG_TS_SPLIT_DEPTH
+#define VRG_TS_SPLIT_DEPTH 2
+#endif
+#ifndef VRG_TS_WHOLE_DEPTH
+#define VRG_TS_WHOLE_DEPTH 1
+#endif
 #ifndef VRG_TS_ROWS_MAX_FRAMES
 #define VRG_TS_ROWS_MAX_FRAMES 32
 #endif
@@ -272,7 +281,7 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
         if (frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsRows) && cm.bh == cw.bh && cm.bh <= 8 && 256 % cm.bw == 0 &&
             (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
             TsRows* rows = reinterpret_cast<TsRows*>(scratch);
-            hipLaunchKernelGGL((k_tstats_rows<2>), dim3((unsigned)(64 * ((frames + 7) / 8))), dim3(256), 0, st, lab, n, frames, cm.bw, cm.bh, rows);
+            hipLaunchKernelGGL((k_tstats_rows<VRG_TS_ROWS_DEPTH>), dim3((unsigned)(64 * ((frames + 7) / 8))), dim3(256), 0, st, lab, n, frames, cm.bw, cm.bh, rows);
             hipLaunchKernelGGL(k_tstats_rows_finish, dim3((unsigned)((frames * 6 + 63) / 64)), dim3(64), 0, st, rows, frames, cm.bh, factor, eps, out);
             VRG_CHECK_LAUNCH();
             return VRG_OK;
@@ -281,7 +290,7 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
         const int depth = split ? 2 : 1;
         const dim3 grid(split ? (unsigned)(32 * ((frames + 7) / 8)) : (unsigned)frames);
 #define TS_LAUNCH(S, D) hipLaunchKernelGGL((k_tstats_frame<S, D>), grid, dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out)
-        if (depth == 2) TS_LAUNCH(true, 2); else TS_LAUNCH(false, 1);
+        if (depth == 2) TS_LAUNCH(true, VRG_TS_SPLIT_DEPTH); else TS_LAUNCH(false, VRG_TS_WHOLE_DEPTH);
 #undef TS_LAUNCH
     } else {
         // all planes of all calls in one launch: plane -> (frame, channel), position in its call from frame % b
