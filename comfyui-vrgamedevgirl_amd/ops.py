@@ -915,8 +915,9 @@ def default_stage_frames(frames: int, frame_elems: int) -> int:
     it hides most of the statistics' latency (a stage with pass 1 + statistics: 5.3 ms against 4.5 + 1.6) but pass 2 is NOT absorbed by
     pass 1 -- a stage with all three roles takes 7.6 ms against 4.5 for pass 1 alone: pass 2 costs 2.25 ms inside the launch, 2.42 ms as
     a kernel of its own.  96 x 4K frames: 22.6 ms staged, 23.7 sequential; 256 frames: 59.4 staged, 56.6 sequential (the short ranges
-    cost pass 1 its seven waves per SIMD and its tail).  Both passes run at ~80 % of the vector-ALU issue rate once their instruction
-    mix is weighted (transcendentals, 64-bit multiplies, compare / select pairs): there is no idle ALU time to share."""
+    cost pass 1 its seven waves per SIMD and its tail).  Weighted for their instruction mix (transcendentals, 64-bit multiplies, compare /
+    select pairs) the passes run at 70-73 % and 79-82 % of the vector-ALU issue rate: what pass 1 leaves idle are single slots between
+    dependent instructions, which pass 2's long dependent chains do not fill."""
     env = os.environ.get("VRGDG_CM_STAGE_FRAMES", "").strip()
     if env:
         return max(int(env), 0)
