@@ -230,8 +230,18 @@ def cpu_baseline(stages, cpu_frames, H, W, lut_cpu, per_node=False):
                 y = fns[st](y)
         return y
 
-    dt = _median_time(chain)
+    # torch's default on a 256-thread host is 128 intra-op threads: on 2 frames that mostly measures its threading overhead, so a
+    # one-run probe picks the better of the default and 32 threads before the timed runs (`cores` = the count actually used)
+    default_threads = torch.get_num_threads()
+    probe = {}
+    for nt in sorted({default_threads, min(32, default_threads)}):
+        torch.set_num_threads(nt)
+        probe[nt] = _median_time(chain, warmup=1 if not probe else 0, reps=1)
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    dt = _median_time(chain, warmup=0)
     out = {"value": round(mpix / dt, 2), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": kind,
+           "thread_probe_s": {str(k): round(v, 2) for k, v in probe.items()},
            "sample": f"{cpu_frames} frames {W}x{H}, chain {'+'.join(stages)} via {what}; warm-up 1, median of 3 = {dt:.2f} s; "
                      f"os.cpu_count()={os.cpu_count()}, torch.get_num_threads()={torch.get_num_threads()} (numpy unsharp is single-threaded)"}
     if per_node:

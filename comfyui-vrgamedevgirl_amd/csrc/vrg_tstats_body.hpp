@@ -143,9 +143,12 @@ struct TsRows { Welf w[3][8]; float m[3][8]; };
 // dependent instructions (v_div_scale, v_rcp_f32, five FMAs, v_div_fmas, v_div_fixup) of the thirteen per update, ~190 cycles per
 // update measured.  n is the same for every accumulator of a thread and known before the data arrives, so rn = 1.0f / n (IEEE, correctly
 // rounded) is formed OFF the chain and the quotient by Markstein's sequence  q = delta * rn;  e = fma(-n, q, delta);  q' = fma(e, rn, q)
-// -- three dependent operations -- which returns the correctly rounded quotient RN(delta / n) whenever rn is the correctly rounded
-// reciprocal and nothing under- or overflows (Markstein 1990; Cornea / Harrison / Tang: exceptions only for divisors with an all-ones
-// significand, which a count below 2^24 - 1 never is).  Nothing can under- or overflow for 2^-100 <= |delta| <= 2^100 or delta == 0; a
+// -- three dependent operations.  That sequence is the correctly rounded quotient for most but not all divisors (Brisebarre / Muller /
+// Raina 2004 characterise the exceptions), so equality with delta / n is established BY ENUMERATION instead: it commutes with the sign
+// of delta and with scaling delta by a power of two while nothing leaves the normal range, hence 2^23 significands per count are all
+// inputs, and vrg_selftest_welford_division sweeps every count up to TS_MARKSTEIN_MAX_COUNT = 2^20 x every significand: zero mismatches
+// (profiles/r03_welford_division_sweep.json; larger frames take the IEEE division).  Nothing leaves the normal range for
+// 2^-100 <= |delta| <= 2^100 or delta == 0; a
 // thread that ever sees another delta (or a NaN) raises `bad`, and a workgroup with a raised flag throws its accumulators away and
 // repeats the frame with the IEEE division (ts_accumulate<..., false>): the result is the IEEE one for every input, the common case
 // pays three instructions next to -- not on -- the chain.  tests: every statistics test compares with torch's own kernels; the
@@ -255,6 +258,9 @@ static __device__ __forceinline__ bool ts_accumulate(const float* __restrict__ b
 #ifndef VRG_TS_MARKSTEIN
 #define VRG_TS_MARKSTEIN 1
 #endif
+// Counts up to which q' == delta / n is established by enumeration (vrg_selftest_welford_division over every count x every fp32
+// significand: tests/test_gpu_parity.py sweeps a sample of counts, tools/welford_division_sweep.py all of them -- profiles/).
+constexpr int64_t TS_MARKSTEIN_MAX_COUNT = 1 << 20;
 
 template <int PART, int TS_DEPTH, bool ROWS = false>
 static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, int bw, int bh, float factor, float eps, float* __restrict__ o6,
@@ -264,7 +270,7 @@ static __device__ void ts_frame_part(const float* __restrict__ base, int64_t n, 
     float* lds_m = reinterpret_cast<float*>(lds_w);
     const int t = t0 + (int)threadIdx.x;
     TsAcc A;
-    if (VRG_TS_MARKSTEIN && R::WELF) {
+    if (VRG_TS_MARKSTEIN && R::WELF && n / 1024 + 2 <= TS_MARKSTEIN_MAX_COUNT) {       // (an accumulator takes at most n / 1024 + 1 updates)
         const bool bad = ts_accumulate<PART, TS_DEPTH, true>(base, n, t, A);
         if (__syncthreads_or(bad ? 1 : 0)) ts_accumulate<PART, TS_DEPTH, false>(base, n, t, A);      // a delta outside the proven range: the IEEE division
     } else {

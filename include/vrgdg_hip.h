@@ -331,6 +331,10 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* Device self-test: the trimmed correctly-rounded square root of the Box-Muller radius (csrc/vrg_pixel_math.hpp
  * sqrt_normal_range) against the backend's IEEE sqrt for all 2^32 Philox words; counts1[0] = mismatches (expected 0). */
 int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
+/* Device self-test: the Welford update's division by the running count as the statistics kernels evaluate it (reciprocal + two FMAs,
+ * csrc/vrg_tstats_body.hpp) against the IEEE quotient, for the counts n_first .. n_first + n_count - 1 (< 2^24) x all 2^23 fp32
+ * significands; mismatches1[0] (device, zeroed by the caller) += mismatches (expected 0). */
+int vrg_selftest_welford_division(unsigned long long* mismatches1, uint32_t n_first, uint32_t n_count, void* stream);
 /* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
  * out128[64+i] = value held by lane i+1, for lane values 0..63. */
 int vrg_selftest_lanes(float* out128, void* stream);

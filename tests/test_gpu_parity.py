@@ -2067,3 +2067,52 @@ def test_staged_pipeline_equals_the_sequential_chain(ops, dev, F, chunk, bs, n_r
     if n_ref == 1:
         o = R.unsharp(R.color_match(o.to(dev), ref, 0.9, bs).cpu(), 0.6, False)
         assert_bit_equal(got, o, "staged pipeline vs the oracle composition")
+
+
+def test_first_use_of_the_per_process_caches_from_several_host_threads(pkg, ops, dev):
+    """The small per-process caches (side streams, the device-statistics self-check, the HIP event pool, the LUT cache) are created on first
+    use; several host threads hitting that first use at the same moment must neither fail nor change a result."""
+    import threading
+    from comfyui_vrgamedevgirl_amd import nodes, VRGDG_IV_Adjustments as iv
+    x = _rand((5, 48, 64, 3), 931)
+    ref = _rand((1, 20, 30, 3), 932)
+
+    def work():
+        a = nodes.ColorMatchToReference().match_color(x, ref, 0.9, 2)[0]
+        b = iv.VRGDG_LUTS().apply_lut(x, "AMD_TealOrange_33.cube", "auto", 10.0)[0]
+        e0, e1 = ops.HipEvent(), ops.HipEvent()
+        e0.record(); e1.record()
+        assert e0.elapsed_ms(e1) >= 0.0
+        return a, b
+
+    want = work()
+    with ops._STATE_LOCK:
+        ops._SIDE_STREAMS.clear(); ops._PIPE_STREAMS.clear(); ops._TS_CHECKED.clear(); ops.HipEvent._pool.clear()
+    iv.VRGDG_LUTS._LUT_CACHE = {}
+    got, errors = [None] * 6, []
+    gate = threading.Barrier(6)
+
+    def run(i):
+        try:
+            gate.wait()
+            got[i] = work()
+        except Exception as exc:
+            errors.append(exc)
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for g in got:
+        assert torch.equal(g[0], want[0]) and torch.equal(g[1], want[1])
+
+
+def test_welford_division_by_the_count_is_the_ieee_quotient(pkg, dev):
+    """delta / n as the whole-frame statistics kernels evaluate it (rn = 1.0f / n off the chain, q = delta * rn, e = fma(-n, q, delta),
+    q + e * rn) equals the IEEE quotient for every fp32 significand of delta -- i.e. for every delta of the guarded range -- for the
+    counts 1 .. 20,000 (a 4K frame reaches 8,101, an 8K frame 32,401; tools/welford_division_sweep.py sweeps all counts up to 2^20) and a
+    sample of larger ones."""
+    from comfyui_vrgamedevgirl_amd import _hip
+    mis = torch.zeros(1, dtype=torch.int64, device=dev)
+    for n0, cnt in ((1, 20000), (32000, 800), (65500, 100), (1048000, 576)):
+        _hip.check(_hip.lib().vrg_selftest_welford_division(_hip.ptr(mis), n0, cnt, _hip.current_stream()), "vrg_selftest_welford_division")
+    assert int(mis.item()) == 0
