@@ -75,6 +75,7 @@ _SIGNATURES = {
     "vrg_selftest_divconst": (C.c_int, [_P, _P]),
     "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
+    "vrg_selftest_div_sigma": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "vrg_selftest_welford_division": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),

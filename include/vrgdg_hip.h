@@ -331,6 +331,11 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* Device self-test: the trimmed correctly-rounded square root of the Box-Muller radius (csrc/vrg_pixel_math.hpp
  * sqrt_normal_range) against the backend's IEEE sqrt for all 2^32 Philox words; counts1[0] = mismatches (expected 0). */
 int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
+/* Device self-test: the colour-match transfer's division by the per-frame sigma as the device policy evaluates it (reciprocal + two
+ * corrections, csrc/vrg_pixel_math.hpp div_uniform_ieee) against the IEEE quotient, for the fp32 significands sigma_first ..
+ * sigma_first + sigma_count - 1 (< 2^23) of sigma x all 2^23 significands of the numerator; counts1[0] (device, zeroed by the caller)
+ * += mismatches (expected 0). */
+int vrg_selftest_div_sigma(unsigned long long* counts1, uint32_t sigma_first, uint32_t sigma_count, void* stream);
 /* Device self-test: the Welford update's division by the running count as the statistics kernels evaluate it (reciprocal + two FMAs,
  * csrc/vrg_tstats_body.hpp) against the IEEE quotient, for the counts n_first .. n_first + n_count - 1 (< 2^24) x all 2^23 fp32
  * significands; mismatches1[0] (device, zeroed by the caller) += mismatches (expected 0). */

@@ -2116,3 +2116,17 @@ def test_welford_division_by_the_count_is_the_ieee_quotient(pkg, dev):
     for n0, cnt in ((1, 20000), (32000, 800), (65500, 100), (1048000, 576)):
         _hip.check(_hip.lib().vrg_selftest_welford_division(_hip.ptr(mis), n0, cnt, _hip.current_stream()), "vrg_selftest_welford_division")
     assert int(mis.item()) == 0
+
+
+def test_division_by_the_per_frame_sigma_is_the_ieee_quotient(pkg, dev):
+    """(lab - mu) / sigma of the colour-match transfer with the device policy: reciprocal (IEEE, loop invariant) + two corrections
+    (vrg_pixel_math.hpp div_uniform_ieee) == the IEEE quotient for every significand of the numerator, for the first 3,000 significands of
+    sigma, 3,000 around the all-ones end and 3,000 spread over the rest (tools/div_sigma_sweep.py runs all 2^23 x 2^23 pairs)."""
+    from comfyui_vrgamedevgirl_amd import _hip
+    mis = torch.zeros(1, dtype=torch.int64, device=dev)
+    lib = _hip.lib()
+    _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), 0, 3000, _hip.current_stream()), "vrg_selftest_div_sigma")
+    _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), (1 << 23) - 3000, 3000, _hip.current_stream()), "vrg_selftest_div_sigma")
+    for s in range(0, 1 << 23, (1 << 23) // 3000):
+        _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), s + 1234, 1, _hip.current_stream()), "vrg_selftest_div_sigma")
+    assert int(mis.item()) == 0
