@@ -30,11 +30,18 @@ def _apply_effects_batch(images, settings, frame_start=0):
     use_gpu_flag = bool(settings.get("use_gpu", True))
     batch = images if images.is_cuda else images.to(compute_device())
     batch = batch.to(torch.float32)
-    if settings.get("sharpen_enabled", True):
-        batch = _apply_unsharp(batch, float(settings.get("sharpen_strength", 0.5)), use_gpu_flag)
-    if settings.get("grain_enabled", False):
-        batch = _apply_seeded_grain(batch, float(settings.get("grain_intensity", 0.04)),
-                                    float(settings.get("saturation_mix", 0.5)), int(settings.get("seed", 42)), int(frame_start))
+    sharpen, grain = bool(settings.get("sharpen_enabled", True)), bool(settings.get("grain_enabled", False))
+    strength, intensity = float(settings.get("sharpen_strength", 0.5)), float(settings.get("grain_intensity", 0.04))
+    if sharpen and grain and strength > 0 and intensity > 0:
+        # both effects: one pass over the frames (the same bits as the two helpers below, one after the other)
+        batch = ops.sharpen_then_seeded_grain(batch, strength, use_gpu_flag, intensity, float(settings.get("saturation_mix", 0.5)),
+                                              int(settings.get("seed", 42)), int(frame_start))
+    else:
+        if sharpen:
+            batch = _apply_unsharp(batch, strength, use_gpu_flag)
+        if grain:
+            batch = _apply_seeded_grain(batch, intensity, float(settings.get("saturation_mix", 0.5)), int(settings.get("seed", 42)),
+                                        int(frame_start))
     return batch.detach() if images.is_cuda else batch.detach().cpu()
 
 

@@ -12,6 +12,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRGDG_HIP_LIB") or os.path.join(PKG_DIR, "libvrgdg_hip.so")   # override: A/B builds (tools/ab_libs.sh)
 
 VRG_OK = 0
+VRG_ERR_BAD_ARG = 1
+VRG_ERR_UNSUPPORTED = 2
 BORDER_REPLICATE, BORDER_ZERO = 0, 1
 STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
@@ -75,7 +77,6 @@ _SIGNATURES = {
     "vrg_selftest_divconst": (C.c_int, [_P, _P]),
     "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
     "vrg_selftest_lanes": (C.c_int, [_P, _P]),
-    "vrg_selftest_div_sigma": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "vrg_selftest_welford_division": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
     "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
@@ -83,6 +84,8 @@ _SIGNATURES = {
     "vrg_debug_copy_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
+    "vrg_sharpen_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                        C.POINTER(NoiseDesc), _P]),
     "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(NoiseDesc), _P]),
     "vrg_grain_injected_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P]),

@@ -38,15 +38,6 @@ __global__ __launch_bounds__(256) void k_selftest_bm_radius(unsigned long long* 
     if (!(got == want) || !(x >= 0.0f)) atomicAdd(&counts[0], 1ull);
 }
 
-// Exhaustive device check of div_uniform_ieee (the colour-match transfer's division by the per-frame sigma) against the IEEE quotient:
-// one thread per (significand of sigma, significand of d); counts[0] += mismatches (must stay 0).
-__global__ __launch_bounds__(256) void k_selftest_div_sigma(unsigned long long* counts, uint32_t sigma_first) {
-    const float sigma = f32_from_bits(0x3f800000u | ((sigma_first + blockIdx.y) & 0x007fffffu));
-    const float d = f32_from_bits(0x3f800000u | (blockIdx.x * 256u + threadIdx.x));
-    const float y = 1.0f / sigma;
-    if (!(div_uniform_ieee(d, sigma, y) == d / sigma)) atomicAdd(counts, 1ull);
-}
-
 // ---- micro-benchmark of LUT record fetch patterns (timing only; results are checksums, not pixels) ----------
 //  mode 0: every lane reads its own 96-B record as 6 x 16 B                       (what k_lut3d does)
 //  mode 1: every lane reads half of its record (3 x 16 B)                          (is the L1 request rate the bound?)
@@ -196,8 +187,8 @@ __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ i
     if (i >= n) return;
     if (op >= 16) {          // 16 / 17: ocml's ln x = hi + lo (epln, as transcribed); 18 / 19: dev_pow_ziv's table log
         float a, b;
-        float eh, dj;
-        if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh, dj);
+        float eh;
+        if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh);
         out[i] = (op & 1) ? b : a;
     } else if (op >= 12) {
         // the Lab transforms' powers as they are called there (dev_pow_ziv with each call site's domain): op 12 sRGB -> linear
@@ -425,16 +416,6 @@ int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float
         default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
     }
     VRG_CHECK_LAUNCH();
-    return VRG_OK;
-}
-
-int vrg_selftest_div_sigma(unsigned long long* counts1, uint32_t sigma_first, uint32_t sigma_count, void* stream) {
-    if (!counts1 || sigma_count == 0 || (uint64_t)sigma_first + sigma_count > (1ull << 23)) return VRG_ERR_BAD_ARG;
-    for (uint32_t done = 0; done < sigma_count; done += 32768u) {
-        const uint32_t now = sigma_count - done < 32768u ? sigma_count - done : 32768u;
-        hipLaunchKernelGGL(vrg::k_selftest_div_sigma, dim3(1u << 15, now), dim3(256), 0, (hipStream_t)stream, counts1, sigma_first + done);
-        VRG_CHECK_LAUNCH();
-    }
     return VRG_OK;
 }
 

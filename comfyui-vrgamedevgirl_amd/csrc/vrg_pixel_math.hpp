@@ -783,15 +783,9 @@ VRG_HD float dev_pow(float x, float y) { return dev_pow_t<DEV_POW_ANY>(x, y); }
 // dev_pow_t.  tests/test_gpu_parity.py compares this function with torch.pow for EVERY fp32 base of [lo, hi] for each of the
 // three exponents, so inside the fast path's domain equality is established by enumeration, outside it by construction.
 // ------------------------------------------------------------------------------------------
-#if defined(VRG_ZIV_BITS7)          /* A/B only: the 128-entry table of round 2 */
-#include "vrg_ziv_log_table7.inc"
-#else
 #include "vrg_ziv_log_table.inc"
-#endif
 
-constexpr int ZIV_INDEX_BITS = VRG_ZIV_INDEX_BITS;               // 9: 512 intervals of m, |r| <= 2^-8.7
-constexpr int ZIV_TABLE_WORDS = (1 << ZIV_INDEX_BITS) * 4;
-static_assert(ZIV_INDEX_BITS == 9 || ZIV_INDEX_BITS == 7, "ziv_log's series is cut for |r| <= 2^-8.7 (2^-6.6 with the A/B table)");
+constexpr int ZIV_TABLE_WORDS = 128 * 4;
 
 VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
     for (int i = first; i < ZIV_TABLE_WORDS; i += stride) dst[i] = f32_from_bits(VRG_ZIV_LOGT[i >> 2][i & 3]);
@@ -800,31 +794,24 @@ VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
 // (Lh, Ll) = ln x for a normal positive x; T = the table in LDS.  The pair is NOT normalised (Lh is not the rounded head: |Ll| can
 // reach 2^-20 |Lh|): its only consumer is the double-word product y * (Lh + Ll) of ziv_try, which does not need that, and the
 // three operations of the final renormalisation are saved.  Both two-sums use the three-operation form where its ordering
-// condition holds for every argument: |e ln2 + T_j| >= |r - r^2/2| whenever the former is not zero (asserted for every (e, j) by
-// tools/make_ziv_log_table.py), and |r| >= r^2/2.  log1p(r) = r - r^2/2 + r^3/3 - r^4/4: the next term is below 2^-45.8
-// (2^-38 of ln x where ln x is small: there r = m - 1), an order under ocml's own error, which is what the interval has to cover.
-// Dj_out = the table's fourth word: the half-width of the interval for this table entry (see ziv_delta).
-VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out, float& Dj_out) {
+// condition holds for every argument: |e ln2 + T_j| >= |r - r^2/2| whenever the former is not zero (e != 0: >= 0.28; e == 0: the
+// table's smallest non-zero |T_j| is 0.0078 against max |r| 0.0051 in those intervals -- asserted for every (e, j) by
+// tools/make_ziv_log_table.py), and |r| >= r^2/2.
+VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out) {
     const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
     const float ef = (float)(d >> 23);
     const uint32_t off = (uint32_t)d & 0x007fffffu;
     const float m = f32_from_bits(off + 0x3f2aaaabu);                // [2/3, 4/3)
-    const float* t = T + ((off >> (23 - ZIV_INDEX_BITS)) << 2);
+    const float* t = T + ((off >> 16) << 2);
     const float c = t[0], th = t[1], tl = t[2];
-    Dj_out = t[3];
-    const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (9-bit c)
+    const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (7-bit c)
     const float Eh = ef * f32_from_bits(0x3f317200u);                // e * ln2 head (15 bits: exact product)
     const float h = r * r;
     const float l = __builtin_fmaf(r, r, -h);                        // r^2 = h + l
-    float P;
-    if (ZIV_INDEX_BITS == 9) {
-        P = __builtin_fmaf(r, -0.25f, (float)(1.0 / 3.0));
-    } else {
-        P = __builtin_fmaf(r, (float)(-1.0 / 6.0), 0.2f);
-        P = __builtin_fmaf(r, P, -0.25f);
-        P = __builtin_fmaf(r, P, (float)(1.0 / 3.0));
-    }
-    const float tail = __builtin_fmaf(-0.5f, l, (h * r) * P);        // -l/2 + r^3/3 - r^4/4
+    float P = __builtin_fmaf(r, (float)(-1.0 / 6.0), 0.2f);
+    P = __builtin_fmaf(r, P, -0.25f);
+    P = __builtin_fmaf(r, P, (float)(1.0 / 3.0));
+    const float tail = __builtin_fmaf(-0.5f, l, (h * r) * P);        // -l/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
     const float s1 = Eh + th;                                        // |Eh| >= 0.69 > |th|, or Eh = 0: fast two-sum
     const float e1 = th - (s1 - Eh);
     const float s2 = __builtin_fmaf(-0.5f, h, r);                    // r - h/2 (h/2 is exact): |r| >= |h/2|, fast two-sum
@@ -846,30 +833,21 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 // EVERY fp32 of [0.0031308, 4] (tools/ziv_log_accuracy.py, profiles/): 2^-34.73 max(|e ln2|, |ln x|) and 2^-36.00 absolute --
 // almost all of it ocml's own error (its epln is good to 2^-34.7, the table log to 2^-37.3).  The bounds below are those
 // maxima times 1.25 (the +-delta additions and ocml's own last roundings are five orders of magnitude smaller).
-#ifndef VRG_ZIV_DELTA_TABLE
-#define VRG_ZIV_DELTA_TABLE 0
-#endif
-VRG_HD float ziv_delta(float y, float Lh, float Eh, float Dj) {
-#if VRG_ZIV_DELTA_TABLE
-    (void)Lh; (void)Eh;
-    return y * Dj;
-#else
-    (void)Dj;
+VRG_HD float ziv_delta(float y, float Lh, float Eh) {
     const float a = __builtin_fabsf(Lh), b = __builtin_fabsf(Eh);
     const float rel = (a > b ? a : b) * (y * f32_from_bits(0x2e420300u));          // 2^-34.4
     const float ab = y * f32_from_bits(0x2d9d9624u);                                // 2^-35.7
     return rel < ab ? rel : ab;
-#endif
 }
 
 // The fast route alone: returns the candidate and whether the rounding test (and the domain test) passed.
 VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float& out) {
-    float Lh, Ll, Eh, Dj;
-    ziv_log(x, T, Lh, Ll, Eh, Dj);
+    float Lh, Ll, Eh;
+    ziv_log(x, T, Lh, Ll, Eh);
     const float p17 = y * Lh;
     const float p24 = __builtin_fmaf(y, Lh, -p17);
     const float p44 = __builtin_fmaf(y, Ll, p24);
-    const float delta = ziv_delta(y, Lh, Eh, Dj);
+    const float delta = ziv_delta(y, Lh, Eh);
     const float up = p44 + delta, dn = p44 - delta;
     const float php = p17 + up;
     const float phm = p17 + dn;
@@ -1120,35 +1098,7 @@ VRG_HD float recip_newton(float s) {
 #endif
 }
 VRG_HD float cm_div_sigma(float d, float sigma, const PowTables&) { return div_const(d, sigma, recip_newton(sigma)); }
-
-// The IEEE quotient d / sigma for a divisor that is a per-frame value: y = 1.0f / sigma (IEEE, correctly rounded) is loop invariant,
-// and with it  q0 = d*y; q1 = fma(fma(-sigma, q0, d), y, q0); q2 = fma(fma(-sigma, q1, d), y, q1)  is the correctly rounded quotient:
-// q1 is a faithful rounding of d / sigma (q0 is within two ulps, the first correction removes all but ~2^-23 ulp of that before its
-// rounding), and one more correction of a faithful quotient with the correctly rounded reciprocal rounds correctly (Markstein's
-// theorem).  Not taken on trust: the sequence commutes with the signs and with scaling either operand by a power of two while nothing
-// leaves the normal range, so the 2^23 x 2^23 pairs of significands are ALL inputs of the guarded range, and tools/div_sigma_sweep.py
-// runs all 7.0e13 of them through vrg_selftest_div_sigma on the device (profiles/r03_div_sigma_sweep.json: zero mismatches; the GPU
-// suite repeats it for a sample of divisors).  Five plain multiply-adds instead of the backend's ~10 instructions plus v_rcp_f32.
-// Guard: 2^-60 <= |d|, sigma <= 2^60 (or d == 0) for every active lane of the wave, else the IEEE division.
-VRG_HD float div_uniform_ieee(float d, float sigma, float y) {
-    const float q0 = d * y;
-    const float e0 = __builtin_fmaf(-sigma, q0, d);
-    const float q1 = __builtin_fmaf(e0, y, q0);
-    const float e1 = __builtin_fmaf(-sigma, q1, d);
-    return __builtin_fmaf(e1, y, q1);
-}
-VRG_HD bool div_uniform_in_range(float v) {
-    const float a = __builtin_fabsf(v);
-    return (a >= 0x1p-60f) & (a <= 0x1p+60f);
-}
-VRG_HD float cm_div_sigma(float d, float sigma, const DevMath&) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VRG_NO_DIVSIGMA_FASTPATH)
-    const float y = 1.0f / sigma;
-    const bool proven = (div_uniform_in_range(d) | (d == 0.0f)) & div_uniform_in_range(sigma);
-    if (__builtin_amdgcn_ballot_w64(!proven) == 0) return div_uniform_ieee(d, sigma, y);
-#endif
-    return d / sigma;
-}
+VRG_HD float cm_div_sigma(float d, float sigma, const DevMath&) { return d / sigma; }
 
 template <class MATH>
 VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, float sigma_ref, float K, float T, const MATH& M) {

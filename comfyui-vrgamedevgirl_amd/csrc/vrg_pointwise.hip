@@ -174,6 +174,166 @@ __global__ __launch_bounds__(256) void k_grain(const void* __restrict__ in_, voi
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Unsharp -> per-frame-seeded grain in one pass (the stand-alone enhancer's order, VRGDG_StandaloneVideoEnhancerNodes.py:278-294):
+// 24 B/px of HBM traffic instead of the 48 of the two kernels.  The GRAIN geometry leads -- a block is the same 1024 Philox
+// subsequences x 4 sibling element runs (G apart) as in k_grain, so the noise still costs one Philox call per four elements for
+// every frame size -- and the stencil follows it: a thread's four consecutive floats of a run are one float4 of the row-major
+// frame, so each wave holds 64 consecutive vectors of each run and builds the 3x3 neighbourhoods exactly like the flat march of
+// vrg_stencil.hip (left / right taps by DPP wave shifts from the neighbouring lanes, lanes 0 and 63 from one extra load), only
+// without the vertical register reuse: the rows above and below are other blocks' centre rows and come from L2 (the workgroups of
+// one XCD walk consecutive segments, so the three rows of a segment are resident in that XCD's L2 when it needs them).  A wave may
+// straddle a row end (any W with W*3 % 4 == 0): row / column are per lane, the row-end rule is a per-lane select.
+// Needs W % 4 == 0, W*3/4 >= 256, one frame per noise chunk, 16-byte aligned frames; otherwise the entry point reports
+// VRG_ERR_UNSUPPORTED and the caller runs the two kernels.  Same arithmetic as both (stencil_value, grain_element): bit-identical.
+// ----------------------------------------------------------------------------------------------
+typedef float sg4 __attribute__((ext_vector_type(4)));
+struct SgRaw { sg4 own[3], halo[3]; };
+
+__device__ __forceinline__ float sg_shr(float old, float v) {    // value of lane-1; lane 0 keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float sg_shl(float old, float v) {    // value of lane+1; lane 63 keeps `old`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void k_sharpen_grain(const float* __restrict__ in, float* __restrict__ out, NoiseK nk, int32_t H, int32_t n4,
+                                                        uint32_t groups_per_frame, uint32_t total_blocks, float strength, float I, float S,
+                                                        float T) {
+    __shared__ float sn[4][GRAIN_N + 8];
+    // workgroup b runs on XCD b % 8: every XCD gets one contiguous run of (frame, call, segment) blocks
+    const uint32_t per_xcd = (total_blocks + 7u) >> 3;
+    const uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || b >= total_blocks) return;
+    const uint32_t G = nk.G;
+    const uint32_t segs = (G + GRAIN_N - 1) / GRAIN_N;
+    const uint32_t bpf = segs * groups_per_frame;
+    const uint32_t frame = b / bpf;
+    const uint32_t rem = b - frame * bpf;
+    const uint32_t k = rem / segs;
+    const uint32_t idx_base = (rem - k * segs) * GRAIN_N;
+    const uint32_t valid_n = (G - idx_base) < (uint32_t)GRAIN_N ? (G - idx_base) : (uint32_t)GRAIN_N;      // a multiple of 256: whole waves
+    const uint32_t tid = threadIdx.x, t4 = tid * GRAIN_IPT;
+    const int lane = (int)(tid & 63u);
+    const uint64_t seed = chunk_seed(nk, frame);
+    const uint64_t off = chunk_offset(nk, frame);
+    const uint64_t ctr = (off >> 2) + k;
+    const uint32_t nvec = (uint32_t)H * (uint32_t)n4;                 // float4 vectors per frame (< 2^29)
+    const sg4* fin = reinterpret_cast<const sg4*>(in) + (int64_t)frame * nvec;
+    sg4* fout = reinterpret_cast<sg4*>(out) + (int64_t)frame * nvec;
+    const uint32_t vec0 = (4u * G * k + idx_base) >> 2;               // first vector of sibling run 0 (4 G k < frame elements < 2^31)
+
+    // the three rows around this thread's vector of sibling run ii, requested in one go (branch-free: lanes that need no halo vector
+    // re-read their own, lanes past the frame end read its last row)
+    auto request = [&](int ii, SgRaw& q, uint32_t& v_out, int32_t& y_out, int32_t& col_out) {
+        const uint32_t vb = vec0 + (G >> 2) * (uint32_t)ii;           // block-uniform
+        const uint32_t yb = vb / (uint32_t)n4;
+        int32_t col = (int32_t)(vb - yb * (uint32_t)n4 + tid);
+        int32_t y = (int32_t)yb;
+        if (col >= n4) { col -= n4; y += 1; }                          // n4 >= 256: at most one row end inside a block
+        v_out = vb + tid;
+        y = y < H ? y : H - 1;
+        const int32_t yu = y > 0 ? y - 1 : 0, yd = y < H - 1 ? y + 1 : H - 1;
+        const int32_t hc = (lane == 0 && col > 0) ? col - 1 : ((lane == 63 && col + 1 < n4) ? col + 1 : col);
+        const int32_t ys[3] = {yu, y, yd};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const sg4* row = fin + (int64_t)ys[r] * n4;
+            q.own[r] = row[col];
+            q.halo[r] = row[hc];
+        }
+        y_out = y;
+        col_out = col;
+    };
+
+    SgRaw q;
+    uint32_t v;
+    int32_t y, col;
+    request(0, q, v, y, col);                                         // in flight under the Philox rounds
+
+    float nz[GRAIN_IPT][4];
+#pragma unroll
+    for (int j = 0; j < GRAIN_IPT; ++j) {
+        const u32x4 r = philox_for(seed, idx_base + t4 + j, ctr);
+        const f32x2 a = box_muller(r.x, r.y);
+        const f32x2 bb = box_muller(r.z, r.w);
+        nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = bb.x; nz[j][3] = bb.y;
+    }
+    if (t4 < valid_n) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(&sn[ii][4 + t4]) = make_float4(nz[0][ii], nz[1][ii], nz[2][ii], nz[3][ii]);
+    }
+    const int64_t fe = (int64_t)nvec * 4;
+    const int64_t group_base = (int64_t)4 * G * k + idx_base;
+    if (tid < 8) {                                                    // the green normals just outside the block's four runs
+        const int ii = (int)(tid >> 1);
+        const int right = (int)(tid & 1);
+        const int64_t li = group_base + (int64_t)G * ii + (right ? (int64_t)valid_n : -1);
+        float nv = 0.0f;
+        if (li >= 0 && li < fe) nv = torch_randn_element(seed, off, G, (uint64_t)li);
+        sn[ii][right ? 4 + valid_n : 3] = nv;
+    }
+    __syncthreads();
+    if (t4 >= valid_n) return;                                        // whole waves
+
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        if (vec0 + (G >> 2) * (uint32_t)ii >= nvec) continue;         // block-uniform: this run starts past the frame
+        if (ii > 0) request(ii, q, v, y, col);
+        const bool first = col == 0, last = col == n4 - 1;
+        // wave-uniform: does any lane of this wave sit at a row end / (zero border) on the frame's first or last row?  2 waves in 45 at 4K
+        const bool row_end_here = __builtin_amdgcn_ballot_w64(first || last) != 0;
+        const bool frame_edge_here = ZERO && __builtin_amdgcn_ballot_w64(y == 0 || y == H - 1) != 0;
+        float o[3][4], pl[3][3], nr[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float ow[4] = {q.own[r].x, q.own[r].y, q.own[r].z, q.own[r].w};
+            float hw[4] = {q.halo[r].x, q.halo[r].y, q.halo[r].z, q.halo[r].w};
+            if (ZERO && r != 1 && frame_edge_here) {                  // avg_pool2d(padding=1): the rows outside the frame are zeros
+                const bool outside = (r == 0 && y == 0) || (r == 2 && y == H - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ow[i] = outside ? 0.0f : ow[i]; hw[i] = outside ? 0.0f : hw[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[r][i] = ow[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pl[r][i] = sg_shr(hw[1 + i], ow[1 + i]);              // floats -3 + i of this vector = the previous vector's tail
+                nr[r][i] = sg_shl(hw[i], ow[i]);                      // floats 4 + i = the next vector's head
+            }
+            if (row_end_here) {                                       // row ends: replicate the end pixel, or zero
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    pl[r][i] = first ? (ZERO ? 0.0f : ow[i]) : pl[r][i];
+                    nr[r][i] = last ? (ZERO ? 0.0f : ow[1 + i]) : nr[r][i];
+                }
+            }
+        }
+        float x[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float p[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                p[r][0] = kk >= 3 ? o[r][kk >= 3 ? kk - 3 : 0] : pl[r][kk < 3 ? kk : 0];
+                p[r][1] = o[r][kk];
+                p[r][2] = kk < 1 ? o[r][kk < 1 ? kk + 3 : 0] : nr[r][kk >= 1 ? kk - 1 : 0];
+            }
+            x[kk] = stencil_value(0, p, strength, ZERO ? 1 : 0);
+        }
+        int c = (int)((4u * v) % 3u);                                 // channel of the vector's first float (frame-local element 4 v)
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ng = sn[ii][4 + t4 + j + 1 - c];              // c == 1: itself
+            res[j] = grain_element(x[j], nz[j][ii], ng, c, I, S, T);
+            c = (c == 2) ? 0 : c + 1;
+        }
+        if (v < nvec) fout[v] = sg4{res[0], res[1], res[2], res[3]};
+    }
+}
+
 // Noise-injection form: out = grain(x, noise) with caller-supplied normals (one pixel per thread).
 __global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ in, const px3* __restrict__ nz,
                                                          px3* __restrict__ out, int64_t pixels, float I, float S, float T) {
@@ -354,6 +514,40 @@ static int launch_grain_any(const void* in, void* out, int64_t frames, int32_t h
 int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, float intensity, float sat,
                   float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
     return launch_grain_any(in, out, frames, height, width, intensity, sat, one_minus_sat, nd, false, stream);
+}
+
+int vrg_sharpen_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width, float strength, int32_t border,
+                          float intensity, float sat, float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+    if (!in || !out || in == out || !nd || frames < 0 || height <= 0 || width <= 0 || border < 0 || border > 1 || nd->chunk_frames < 1 ||
+        nd->grid_threads == 0 || (nd->grid_threads % 256u) != 0)
+        return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    const int64_t frame_elems = (int64_t)height * width * 3;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
+    if (nd->chunk_frames != 1 || width % 4 != 0 || (int64_t)width * 3 / 4 < 256 || frame_elems > 0x7fffffffll || !aligned)
+        return VRG_ERR_UNSUPPORTED;                                   // the caller runs vrg_stencil3x3_f32 + vrg_grain_f32
+    const NoiseK nk = make_noise(nd, frame_elems);
+    const uint64_t groups = (uint64_t)((frame_elems + 4 * (int64_t)nk.G - 1) / (4 * (int64_t)nk.G));
+    const uint64_t per_frame = groups * ((nk.G + GRAIN_N - 1) / GRAIN_N);
+    const int64_t step = (int64_t)(0x7fffffffull / per_frame) - 1;   // frames per launch
+    if (step < 1) return VRG_ERR_UNSUPPORTED;
+    for (int64_t f0 = 0; f0 < frames; f0 += step) {
+        const int64_t nf = frames - f0 < step ? frames - f0 : step;
+        NoiseK nkk = nk;
+        nkk.chunk0 += f0;
+        const uint32_t total = (uint32_t)(per_frame * (uint64_t)nf);
+        const uint32_t blocks = ((total + 7u) / 8u) * 8u;
+        const float* src = in + f0 * frame_elems;
+        float* dst = out + f0 * frame_elems;
+        if (border == VRG_BORDER_ZERO)
+            hipLaunchKernelGGL((k_sharpen_grain<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, nkk, height, width * 3 / 4,
+                               (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+        else
+            hipLaunchKernelGGL((k_sharpen_grain<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, nkk, height, width * 3 / 4,
+                               (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+        VRG_CHECK_LAUNCH();
+    }
+    return VRG_OK;
 }
 
 // uint8 B,G,R frames, grain only: the shared-Philox kernel (one Philox call per four elements instead of the point-wise

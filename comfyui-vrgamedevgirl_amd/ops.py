@@ -268,6 +268,41 @@ def film_grain_seeded_frames(images: torch.Tensor, grain_intensity: float, satur
 
 
 @_on_device
+def sharpen_then_seeded_grain(images: torch.Tensor, sharpen_strength: float, zero_border: bool, grain_intensity: float,
+                              saturation_mix: float, seed: int, frame_start: int = 0) -> torch.Tensor:
+    """Unsharp, then per-frame-seeded grain: the effect order of the stand-alone enhancer's _apply_effects_batch
+    (VRGDG_StandaloneVideoEnhancerNodes.py:278-294) as ONE pass over the frames (vrg_sharpen_grain_f32: 24 B/px).  Frame sizes the
+    fused kernel does not take (width not a multiple of 4 or below 344) run the two kernels; the result is the same bits either way
+    (tests/test_gpu_parity.py::test_fused_sharpen_then_seeded_grain_equals_the_two_kernels)."""
+    x = _check_frames(images, channels=3)
+    F, H, W, _ = x.shape
+    if F == 0 or sharpen_strength <= 0 or grain_intensity <= 0:
+        y = stencil3x3(x, "unsharp", sharpen_strength, zero_border) if (F and sharpen_strength > 0) else x
+        return film_grain_seeded_frames(y, grain_intensity, saturation_mix, seed, frame_start) if (F and grain_intensity > 0) else y
+    fe = H * W * 3
+    I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
+    out = torch.empty_like(x)
+    lib = _hip.lib()
+    first = int(seed) + int(frame_start)
+    f = 0
+    while f < F:   # split where the 31-bit mask wraps (practically never)
+        s0 = (first + f) & 0x7FFFFFFF
+        run = min(F - f, 0x80000000 - s0)
+        d = NoisePlan(1, rng.per_frame_seeded(fe, s0, x.device)).desc()
+        st = lib.vrg_sharpen_grain_f32(C.c_void_p(x.data_ptr() + 4 * f * fe), C.c_void_p(out.data_ptr() + 4 * f * fe), run, H, W,
+                                       _f32(sharpen_strength), _hip.BORDER_ZERO if zero_border else _hip.BORDER_REPLICATE, I32, S32, T32,
+                                       C.byref(d), _hip.current_stream())
+        if st == _hip.VRG_ERR_UNSUPPORTED:
+            if f != 0:
+                raise RuntimeError("vrg_sharpen_grain_f32 refused a later run of a batch it had accepted")
+            return film_grain_seeded_frames(stencil3x3(x, "unsharp", sharpen_strength, zero_border), grain_intensity, saturation_mix,
+                                            seed, frame_start)
+        _hip.check(st, "vrg_sharpen_grain_f32")
+        f += run
+    return out
+
+
+@_on_device
 def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensity: float, saturation_mix: float) -> torch.Tensor:
     """Grain arithmetic with caller-supplied N(0,1) noise (same shape): the noise-injection parity form."""
     x = _check_frames(images, channels=3)

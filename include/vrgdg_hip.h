@@ -84,6 +84,15 @@ int vrg_grain_f32(const float* in, float* out, int64_t frames, int32_t height, i
                   float intensity, float sat, float one_minus_sat,
                   const vrg_noise_desc* noise, void* stream);
 
+/* f1  Unsharp, then per-frame-seeded grain, in ONE pass over the frames (24 B/px instead of 48): the effect order of the stand-alone
+ * enhancer, _apply_effects_batch = _apply_unsharp then _apply_seeded_grain (VRGDG_StandaloneVideoEnhancerNodes.py:233-294).
+ * out = vrg_grain_f32(vrg_stencil3x3_f32(in, VRG_OP_UNSHARP, border, strength), ...) bit for bit; `noise` as for vrg_grain_f32 with
+ * chunk_frames == 1 (one generator per frame).  in != out.  Returns VRG_ERR_UNSUPPORTED -- and the caller runs the two entry points
+ * above -- unless width % 4 == 0, width * 3 / 4 >= 256, chunk_frames == 1 and both pointers are 16-byte aligned. */
+int vrg_sharpen_grain_f32(const float* in, float* out, int64_t frames, int32_t height, int32_t width,
+                          float strength, int32_t border, float intensity, float sat, float one_minus_sat,
+                          const vrg_noise_desc* noise, void* stream);
+
 /* Same arithmetic with the N(0,1) noise supplied by the caller (device pointer, same shape as
  * `in`): the noise-injection form used to prove arithmetic parity against the CPU reference. */
 int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels,
@@ -331,11 +340,6 @@ int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
 /* Device self-test: the trimmed correctly-rounded square root of the Box-Muller radius (csrc/vrg_pixel_math.hpp
  * sqrt_normal_range) against the backend's IEEE sqrt for all 2^32 Philox words; counts1[0] = mismatches (expected 0). */
 int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
-/* Device self-test: the colour-match transfer's division by the per-frame sigma as the device policy evaluates it (reciprocal + two
- * corrections, csrc/vrg_pixel_math.hpp div_uniform_ieee) against the IEEE quotient, for the fp32 significands sigma_first ..
- * sigma_first + sigma_count - 1 (< 2^23) of sigma x all 2^23 significands of the numerator; counts1[0] (device, zeroed by the caller)
- * += mismatches (expected 0). */
-int vrg_selftest_div_sigma(unsigned long long* counts1, uint32_t sigma_first, uint32_t sigma_count, void* stream);
 /* Device self-test: the Welford update's division by the running count as the statistics kernels evaluate it (reciprocal + two FMAs,
  * csrc/vrg_tstats_body.hpp) against the IEEE quotient, for the counts n_first .. n_first + n_count - 1 (< 2^24) x all 2^23 fp32
  * significands; mismatches1[0] (device, zeroed by the caller) += mismatches (expected 0). */

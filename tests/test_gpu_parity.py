@@ -201,6 +201,61 @@ def test_seeded_per_frame_grain_is_batch_invariant_and_matches_oracle(pkg, ops, 
     assert_bit_equal(got, want, "effects batch")
 
 
+@pytest.mark.parametrize("zero_border", [False, True], ids=["replicate", "zero"])
+@pytest.mark.parametrize("shape", [(3, 37, 344, 3), (2, 64, 1024, 3), (2, 90, 500, 3), (2, 5, 4096, 3), (1, 1, 2048, 3), (2, 1080, 1920, 3),
+                                   (1, 2160, 3840, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_sharpen_then_seeded_grain_equals_the_two_kernels(pkg, ops, dev, shape, zero_border):
+    """vrg_sharpen_grain_f32 (the enhancer's sharpen -> per-frame-seeded grain order in one pass, grain geometry leading) against the
+    stencil kernel followed by the grain kernel -- each of which is held to the oracle elsewhere -- bit for bit: row ends inside a wave
+    (W*3/4 not a multiple of 64), runs that end inside the frame's last vector row, one-row frames, both border rules, 1080p and 4K;
+    and against the oracle itself for the small shapes."""
+    from comfyui_vrgamedevgirl_amd import _hip, rng
+    import ctypes as C
+    x = _rand(shape, 31).to(dev)
+    two = ops.film_grain_seeded_frames(ops.stencil3x3(x, "unsharp", 0.6, zero_border), 0.05, 0.4, 1234, 17)
+    got = ops.sharpen_then_seeded_grain(x, 0.6, zero_border, 0.05, 0.4, 1234, 17)
+    assert_bit_equal(got, two, "fused sharpen -> seeded grain")
+    # the fused kernel itself ran (the op falls back to the two kernels for sizes the kernel refuses)
+    out = torch.empty_like(x)
+    d = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 1234 + 17, dev)).desc()
+    st = _hip.lib().vrg_sharpen_grain_f32(_hip.ptr(x), _hip.ptr(out), shape[0], shape[1], shape[2], 0.6, 1 if zero_border else 0,
+                                          0.05, 0.4, float(np.float32(1.0 - 0.4)), C.byref(d), _hip.current_stream())
+    assert st == _hip.VRG_OK
+    assert_bit_equal(out, two, "vrg_sharpen_grain_f32")
+    if x.numel() < 1 << 20:
+        def noise_fn(fseed, shp):
+            g = torch.Generator(device=dev).manual_seed(fseed)
+            return torch.randn(shp, generator=g, device=dev).cpu()
+        want = R.seeded_grain(R.unsharp(x.cpu(), 0.6, zero_border).contiguous(), 0.05, 0.4, 1234, 17, noise_fn=noise_fn)
+        assert_bit_equal(got, want, "fused sharpen -> seeded grain vs oracle")
+        half = shape[0] // 2
+        if half:
+            split = torch.cat((ops.sharpen_then_seeded_grain(x[:half], 0.6, zero_border, 0.05, 0.4, 1234, 17),
+                               ops.sharpen_then_seeded_grain(x[half:], 0.6, zero_border, 0.05, 0.4, 1234, 17 + half)))
+            assert torch.equal(split, got)                    # the reference's batch-invariance property (its own test, :39-61)
+
+
+def test_fused_sharpen_grain_refuses_what_it_does_not_take(pkg, ops, dev):
+    """Widths that are not a multiple of 4 or below 344 pixels, several frames per noise chunk, in-place: the entry point says so
+    (VRG_ERR_UNSUPPORTED / VRG_ERR_BAD_ARG), and the operator still returns the reference's result through the two kernels."""
+    from comfyui_vrgamedevgirl_amd import _hip, rng
+    import ctypes as C
+    lib = _hip.lib()
+    for shp in ((2, 20, 56, 3), (2, 20, 346, 3)):
+        x = _rand(shp, 5).to(dev)
+        out = torch.empty_like(x)
+        d = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 3, dev)).desc()
+        args = (shp[0], shp[1], shp[2], 0.5, 0, 0.04, 0.5, 0.5, C.byref(d), _hip.current_stream())
+        assert lib.vrg_sharpen_grain_f32(_hip.ptr(x), _hip.ptr(out), *args) == _hip.VRG_ERR_UNSUPPORTED
+        assert lib.vrg_sharpen_grain_f32(_hip.ptr(x), _hip.ptr(x), *args) == _hip.VRG_ERR_BAD_ARG
+        got = ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 3, 0)
+        assert_bit_equal(got, ops.film_grain_seeded_frames(ops.stencil3x3(x, "unsharp", 0.5, False), 0.04, 0.5, 3, 0), "fallback")
+    x = _rand((2, 20, 512, 3), 5).to(dev)
+    d = ops.NoisePlan(2, rng.per_frame_seeded(x.numel(), 3, dev)).desc()
+    assert lib.vrg_sharpen_grain_f32(_hip.ptr(x), _hip.ptr(torch.empty_like(x)), 2, 20, 512, 0.5, 0, 0.04, 0.5, 0.5, C.byref(d),
+                                     _hip.current_stream()) == _hip.VRG_ERR_UNSUPPORTED
+
+
 def test_route_film_grain_tensor_seeded(pkg, dev):
     from comfyui_vrgamedevgirl_amd import VRGDG_LUTVideoTools as lvt
     x = _rand((2, 24, 40, 3), 14)
@@ -2115,18 +2170,4 @@ def test_welford_division_by_the_count_is_the_ieee_quotient(pkg, dev):
     mis = torch.zeros(1, dtype=torch.int64, device=dev)
     for n0, cnt in ((1, 20000), (32000, 800), (65500, 100), (1048000, 576)):
         _hip.check(_hip.lib().vrg_selftest_welford_division(_hip.ptr(mis), n0, cnt, _hip.current_stream()), "vrg_selftest_welford_division")
-    assert int(mis.item()) == 0
-
-
-def test_division_by_the_per_frame_sigma_is_the_ieee_quotient(pkg, dev):
-    """(lab - mu) / sigma of the colour-match transfer with the device policy: reciprocal (IEEE, loop invariant) + two corrections
-    (vrg_pixel_math.hpp div_uniform_ieee) == the IEEE quotient for every significand of the numerator, for the first 3,000 significands of
-    sigma, 3,000 around the all-ones end and 3,000 spread over the rest (tools/div_sigma_sweep.py runs all 2^23 x 2^23 pairs)."""
-    from comfyui_vrgamedevgirl_amd import _hip
-    mis = torch.zeros(1, dtype=torch.int64, device=dev)
-    lib = _hip.lib()
-    _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), 0, 3000, _hip.current_stream()), "vrg_selftest_div_sigma")
-    _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), (1 << 23) - 3000, 3000, _hip.current_stream()), "vrg_selftest_div_sigma")
-    for s in range(0, 1 << 23, (1 << 23) // 3000):
-        _hip.check(lib.vrg_selftest_div_sigma(_hip.ptr(mis), s + 1234, 1, _hip.current_stream()), "vrg_selftest_div_sigma")
     assert int(mis.item()) == 0

@@ -28,6 +28,10 @@ if which == "kernels":
              "lut33": lambda: ops.lut3d(x, lut, 10.0), "lut25": lambda: ops.lut3d(x, lut25, 10.0),
              "unsharp": lambda: ops.stencil3x3(x, "unsharp", 0.5, False), "sobel": lambda: ops.stencil3x3(x, "sobel", 0.5, False),
              "clarity": lambda: ops.adjust(x, t_cl, out=out),
+             "seeded grain": lambda: ops.film_grain_seeded_frames(x, 0.04, 0.5, 42, 0),
+             "unsharp>seeded grain (two kernels)": lambda: ops.film_grain_seeded_frames(ops.stencil3x3(x, "unsharp", 0.5, False), 0.04, 0.5, 42, 0),
+             "unsharp>seeded grain (fused)": lambda: ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 42, 0),
+             "unsharp>seeded grain (fused, zero border)": lambda: ops.sharpen_then_seeded_grain(x, 0.5, True, 0.04, 0.5, 42, 0),
              "grain+lut": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0)), generator=gen, out=out),
              "grain+sharpen": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)), generator=gen, out=out),
              "chain3_25": lambda: ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut25, 10.0), sharpen=("unsharp", 0.5, False)), generator=gen, out=out)}

@@ -39,6 +39,7 @@ if which == "traffic":
     lab_ws = torch.empty_like(x)
     ops.fused_chain(x, specs["chain4"], generator=gen, out=out, lab_workspace=lab_ws)
     ops.fused_chain(x, specs["chain3"], generator=gen, out=out)
+    ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 42, 0)      # k_sharpen_grain: 12 + 12 B/px if the row re-reads stay in L2
     torch.cuda.synchronize()
     print("done traffic")
     sys.exit(0)
@@ -65,6 +66,7 @@ if which == "issue":
     ops.film_grain(x, 0.04, 0.5, chunk_frames=4, generator=gen)
     ops.lut3d(x, lut, 10.0)
     ops.stencil3x3(x, "unsharp", 0.5, False)
+    ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 42, 0)
     ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"clarity": 40, "contrast": 12})), out=out)
     ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"sharpen": 40, "contrast": 12})), out=out)
     ops.adjust(x, ops.adjust_terms(LVT._normalize_adjust_settings({"temperature": 20, "exposure": 10, "contrast": 12, "saturation": 8,

@@ -18,7 +18,7 @@ load_package()
 from comfyui_vrgamedevgirl_amd import _hip  # noqa: E402
 
 
-def measure(lo=0.0031308, hi=4.0, dev=None, per_cell=False):
+def measure(lo=0.0031308, hi=4.0, dev=None):
     dev = dev or torch.device("cuda", 0)
 
     def dbg(x, op):
@@ -29,8 +29,6 @@ def measure(lo=0.0031308, hi=4.0, dev=None, per_cell=False):
     a, b = int(np.float32(lo).view(np.int32)), int(np.float32(hi).view(np.int32))
     w = {"ocml_rel": 0.0, "ocml_abs": 0.0, "table_rel": 0.0, "table_abs": 0.0, "distance_rel_to_max_eln2_lnx": 0.0, "distance_abs": 0.0}
     n = 0
-    B = 9                                                    # table index bits (csrc/vrg_ziv_log_table.inc)
-    cell = torch.zeros(32 << B, dtype=torch.float64, device=dev)      # max distance per (e + 16, table interval j)
     for s in range(a, b + 1, 1 << 25):
         x = torch.arange(s, min(b + 1, s + (1 << 25)), dtype=torch.int64, device=dev).to(torch.int32).view(torch.float32)
         n += x.numel()
@@ -44,15 +42,9 @@ def measure(lo=0.0031308, hi=4.0, dev=None, per_cell=False):
             w[name + "_rel"] = max(w[name + "_rel"], float(torch.where(t != 0, err / t.abs().clamp_min(1e-300), torch.zeros_like(err)).max()))
             w[name + "_abs"] = max(w[name + "_abs"], float(err.max()))
         d = (lo_ - lz).abs()
-        dd = x.view(torch.int32) - 0x3F2AAAAB
-        key = (((dd >> 23) + 16).long() << B) | ((dd & 0x7FFFFF) >> (23 - B)).long()
-        cell.scatter_reduce_(0, key, d, reduce="amax")
         w["distance_rel_to_max_eln2_lnx"] = max(w["distance_rel_to_max_eln2_lnx"], float((d / scale).max()))
         w["distance_abs"] = max(w["distance_abs"], float(d.max()))
-    out = {"domain": [lo, hi], "inputs": n, "index_bits": B}
-    if per_cell:
-        out["distance_per_e_and_interval"] = {str(e - 16): [float(v) for v in cell[e << B:(e + 1) << B].tolist()]
-                                               for e in range(32) if float(cell[e << B:(e + 1) << B].max()) > 0}
+    out = {"domain": [lo, hi], "inputs": n}
     out.update({k + "_log2": float(np.log2(v)) for k, v in w.items()})
     out.update({k: v for k, v in w.items()})
     return out
@@ -60,7 +52,7 @@ def measure(lo=0.0031308, hi=4.0, dev=None, per_cell=False):
 
 if __name__ == "__main__":
     lo, hi = (float(sys.argv[1]), float(sys.argv[2])) if len(sys.argv) > 2 else (0.0031308, 4.0)
-    res = measure(lo, hi, per_cell=True)
+    res = measure(lo, hi)
     print({k: (round(v, 3) if isinstance(v, float) and k.endswith("_log2") else v) for k, v in res.items() if k.endswith("_log2") or k in ("domain", "inputs")})
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/ziv_log_accuracy.json", "w") as fh:
