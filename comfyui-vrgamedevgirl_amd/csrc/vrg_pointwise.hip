@@ -247,10 +247,13 @@ __global__ __launch_bounds__(256) void k_sharpen_grain(const float* __restrict__
         col_out = col;
     };
 
-    SgRaw q;
-    uint32_t v;
-    int32_t y, col;
-    request(0, q, v, y, col);                                         // in flight under the Philox rounds
+#ifndef VRG_SG_PIPE
+#define VRG_SG_PIPE 0         /* 1: request run ii + 1's rows before run ii is computed (81 instead of 58 VGPRs); measured equal (6.71 / 6.82 against 6.75 / 6.80 ms per 128 4K frames, profiles/r03_sharpen_grain_fused_issue.log): the kernel does not wait on its loads */
+#endif
+    SgRaw qq[2];
+    uint32_t vv[2];
+    int32_t yy[2], cc[2];
+    request(0, qq[0], vv[0], yy[0], cc[0]);                           // in flight under the Philox rounds
 
     float nz[GRAIN_IPT][4];
 #pragma unroll
@@ -279,8 +282,13 @@ __global__ __launch_bounds__(256) void k_sharpen_grain(const float* __restrict__
 
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
+        const int cur = VRG_SG_PIPE ? (ii & 1) : 0;
+        if (!VRG_SG_PIPE && ii > 0) request(ii, qq[0], vv[0], yy[0], cc[0]);
+        if (VRG_SG_PIPE && ii < 3) request(ii + 1, qq[(ii + 1) & 1], vv[(ii + 1) & 1], yy[(ii + 1) & 1], cc[(ii + 1) & 1]);   // clamped: in bounds even past the frame
         if (vec0 + (G >> 2) * (uint32_t)ii >= nvec) continue;         // block-uniform: this run starts past the frame
-        if (ii > 0) request(ii, q, v, y, col);
+        const SgRaw& q = qq[cur];
+        const uint32_t v = vv[cur];
+        const int32_t y = yy[cur], col = cc[cur];
         const bool first = col == 0, last = col == n4 - 1;
         // wave-uniform: does any lane of this wave sit at a row end / (zero border) on the frame's first or last row?  2 waves in 45 at 4K
         const bool row_end_here = __builtin_amdgcn_ballot_w64(first || last) != 0;
