@@ -127,10 +127,35 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
 #pragma unroll
             for (int c = 0; c < 3; ++c) { s1[m][part][c] = 0.0; s2[m][part][c] = 0.0; }
 
+#ifndef VRG_PR_PIPE
+#define VRG_PR_PIPE 1     /* Lab-only form: 1 = pixels requested before the noise synthesis, 2 = and the LUT gathers pipelined, 3 = two siblings before, two after the barrier */
+#endif
+    constexpr bool PIPE = VRG_PR_PIPE && !STATS && (STAGES & VRG_STAGE_GRAIN) && !(STAGES & VRG_STAGE_COLORMATCH);
+    constexpr bool HAS_LUT = (STAGES & VRG_STAGE_LUT) != 0;
     for (int sub = 0; sub < PR_SUBS; ++sub) {
         const uint32_t I = run0 + (uint32_t)sub * PR_SUB;            // first subsequence of this sub-range
         if (I >= G) break;                                           // uniform
         const uint32_t valid_n = (G - I) < (uint32_t)PR_SUB ? (G - I) : (uint32_t)PR_SUB;
+        // PIPE: the four siblings' pixels are requested BEFORE the noise synthesis (branch-free: a lane without a pixel re-reads the
+        // chunk's first one), so that they arrive under its ~550 instructions instead of being waited for after the barrier
+        px3 pre_px[4];
+        auto place = [&](int m, int& p0, int64_t& e0) {              // this thread's pixel of sibling m: position in the sub-range, element, has one?
+            const int64_t a = q0 + (int64_t)G * m + I;               // first element of the sibling's sub-range (uniform)
+            const int shift = (int)((3u - (uint32_t)a % 3u) % 3u);   // re-alignment to the pixel grid (chunk elements fit 31 bits)
+            p0 = shift + 3 * tid;
+            e0 = a + p0;
+            return p0 < (int)valid_n && e0 + 2 < P.numel;
+        };
+        auto request = [&](int m) {
+            int p0;
+            int64_t e0;
+            const bool ok = place(m, p0, e0);
+            pre_px[m] = load_px_stream(reinterpret_cast<const px3*>(cin + (ok ? e0 : 0)));
+        };
+        if (PIPE) {
+#pragma unroll
+            for (int m = 0; m < (VRG_PR_PIPE == 3 ? 2 : 4); ++m) request(m);
+        }
         // ---- noise of the sub-range into LDS: 3 Philox calls per thread, 12 normals
         {
             float nz[3][4];
@@ -154,6 +179,41 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
             }
         }
         __syncthreads();
+        if (PIPE) {
+            // ---- one pixel per thread and sibling, software-pipelined: the LUT gathers of sibling m + 1 are issued BEFORE the Lab
+            // arithmetic of sibling m (six powers, ~400 instructions) and land under it; one LutFetch is live at a time (its registers
+            // are free again once sibling m is interpolated), so the pipeline costs no occupancy.  Branch-free up to the store: lanes
+            // without a pixel work on the re-read one and skip only the store.
+            LutFetch F;
+            float gr[3];
+            auto issue = [&](int m) {
+                const float x[3] = {pre_px[m].r, pre_px[m].g, pre_px[m].b};
+                int p0;
+                int64_t e0;
+                if (!place(m, p0, e0)) p0 = 0;
+                const float n[3] = {sn[m][p0], sn[m][p0 + 1], sn[m][p0 + 2]};
+                grain_pixel(x, n, D.I, D.S, D.T, gr);
+                if (HAS_LUT) lut_fetch_issue(D.lut, gr, F);
+            };
+            if (VRG_PR_PIPE == 3) { request(2); request(3); }         // land under the Lab arithmetic of siblings 0 and 1
+            if (VRG_PR_PIPE == 2) issue(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float y[3], pre[3], lab[3];
+                if (VRG_PR_PIPE != 2) issue(m);
+                if (HAS_LUT) {
+                    lut_fetch_finish(F, y);
+                    lut_blend(D.lut, gr, y, pre);
+                } else {
+                    pre[0] = gr[0]; pre[1] = gr[1]; pre[2] = gr[2];
+                }
+                if (VRG_PR_PIPE == 2 && m < 3) issue(m + 1);
+                rgb_to_lab(pre, lab, PT);
+                int p0;
+                int64_t e0;
+                if (place(m, p0, e0) && clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
+            }
+        } else
         // ---- one pixel per thread and sibling
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
