@@ -23,7 +23,15 @@ struct AmRow { float l[3], c[3], r[3]; };               // one processed row: le
 
 // The workgroup body of k_apply_march, callable from other kernels (the fused stage kernel, vrg_stage.hip): `vblock` / `vgrid` = the
 // workgroup's index in / the size of the apply grid, `PT` = the colour-match arithmetic object (tables staged in LDS by the caller).
-template <int STAGES, class MATH>
+// GENERAL = false (frames of at least APPLY_COLS x APPLY_ROWS pixels and less than 2 GiB): the loop has NO conditional block -- the
+// two halo lanes of a wave "store" through a buffer descriptor at an offset past the frame, which the hardware drops -- so the
+// compiler's memory counter stays exact (a store inside an exec-masked block merges to `s_waitcnt vmcnt(0)` at the join), and the
+// next row is requested BEFORE the current row's ~450 instructions of colour transfer instead of after them: the request lands under
+// that arithmetic where it used to be waited for ~100 instructions after its issue (one exposed L2 / HBM latency per row and wave).
+#ifndef VRG_APPLY_EARLY_LOAD
+#define VRG_APPLY_EARLY_LOAD 1
+#endif
+template <int STAGES, class MATH, bool GENERAL = true>
 __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid, const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
                                                  int32_t strips_x, int32_t segs_y, uint32_t total_waves, const ChainK& D, const MATH& PT) {
     // XCD-aware placement as in k_chain_tile: workgroup b runs on XCD b % 8; give every XCD one contiguous run of work
@@ -38,7 +46,10 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
     for (uint32_t slot = vblock >> 3; slot < per_xcd; slot += (vgrid >> 3)) {
     const uint32_t grp = (vblock & 7u) * per_xcd + slot;
     if (grp >= groups) break;
-    const uint32_t wv = grp * 4u + (threadIdx.x >> 6);
+    // the wave's index is the same in all its lanes: say so (readfirstlane), and the strip / segment / frame arithmetic, the row
+    // loop's bounds and the row addresses live in SGPRs -- a row loop the compiler takes for divergent runs under an exec mask and
+    // merges its memory counters to `vmcnt(0)` at the loop header
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(grp * 4u + (threadIdx.x >> 6)));
     if (wv >= total_waves) break;
     const uint32_t strip = wv % (uint32_t)strips_x;
     const uint32_t rest = wv / (uint32_t)strips_x;
@@ -54,6 +65,12 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
     const bool stores = lane >= 1 && lane <= APPLY_COLS && x_in;                 // (x_in: frames narrower than a strip)
     const px3* fin = in + f * ppf;
     px3* fout = out + f * ppf;
+    __amdgpu_buffer_rsrc_t frame_rsrc;
+    if (!GENERAL) {                                                              // wave-uniform frame base for the descriptor (SGPRs)
+        const uint64_t fb = reinterpret_cast<uint64_t>(fout);
+        const uint64_t fbu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fb);
+        frame_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fbu), 0, (int)(ppf * 12), 0x00020000);
+    }
     const FrameCtx FC = frame_ctx<STAGES>(D, f);
 
     auto load = [&](int32_t y) {                                                  // raw pixel of row y (clamped), this lane's column
@@ -81,7 +98,13 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
             const float p[3][3] = {{a.l[ch], a.c[ch], a.r[ch]}, {b.l[ch], b.c[ch], b.r[ch]}, {c.l[ch], c.c[ch], c.r[ch]}};
             res[ch] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
         }
-        if (stores && y < y0 + rows) fout[(int64_t)y * W + x] = px3{res[0], res[1], res[2]};
+        if (GENERAL) {
+            if (stores && y < y0 + rows) fout[(int64_t)y * W + x] = px3{res[0], res[1], res[2]};
+        } else {
+            typedef unsigned u3 __attribute__((ext_vector_type(3)));
+            const uint32_t voff = stores ? (uint32_t)(y * W + x) * 12u : 0x80000000u;       // halo lanes: out of range, dropped
+            __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])}, frame_rsrc, (int)voff, 0, 0);
+        }
     };
 
     AmRow r0 = process(load(y0 - 1), y0 - 1);
@@ -89,16 +112,30 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
     AmRow r2;
     const int32_t y1 = y0 + rows;
     px3 q = load(y0 + 1);
-    for (int32_t y = y0; y < y1; y += 3) {                                        // three steps per trip: r0, r1, r2 rotate by name
-        r2 = process(q, y + 1);
-        q = load(y + 2);
-        emit(y, r0, r1, r2);
-        r0 = process(q, y + 2);
-        q = load(y + 3);
-        emit(y + 1, r1, r2, r0);
-        r1 = process(q, y + 3);
-        q = load(y + 4);
-        emit(y + 2, r2, r0, r1);
+    if (!GENERAL && VRG_APPLY_EARLY_LOAD) {
+        for (int32_t y = y0; y < y1; y += 3) {                                    // three steps per trip: r0, r1, r2 rotate by name
+            const px3 a = load(y + 2);                                            // lands under process(q)
+            r2 = process(q, y + 1);
+            emit(y, r0, r1, r2);
+            const px3 b = load(y + 3);
+            r0 = process(a, y + 2);
+            emit(y + 1, r1, r2, r0);
+            q = load(y + 4);
+            r1 = process(b, y + 3);
+            emit(y + 2, r2, r0, r1);
+        }
+    } else {
+        for (int32_t y = y0; y < y1; y += 3) {
+            r2 = process(q, y + 1);
+            q = load(y + 2);
+            emit(y, r0, r1, r2);
+            r0 = process(q, y + 2);
+            q = load(y + 3);
+            emit(y + 1, r1, r2, r0);
+            r1 = process(q, y + 3);
+            q = load(y + 4);
+            emit(y + 2, r2, r0, r1);
+        }
     }
     }       // persistent walk
 }

@@ -15,11 +15,11 @@
 
 namespace vrg {
 
-template <int STAGES>
+template <int STAGES, bool GENERAL>
 __global__ __launch_bounds__(256) void k_apply_march(const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W, int32_t strips_x,
                                                       int32_t segs_y, uint32_t total_waves, ChainK D) {
     VRG_CM_MATH(PT, (STAGES & VRG_STAGE_COLORMATCH) != 0, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
-    apply_march_body<STAGES>(blockIdx.x, gridDim.x, in, out, H, W, strips_x, segs_y, total_waves, D, PT);
+    apply_march_body<STAGES, decltype(PT), GENERAL>(blockIdx.x, gridDim.x, in, out, H, W, strips_x, segs_y, total_waves, D, PT);
 }
 
 template <int STAGES>
@@ -40,8 +40,17 @@ static int launch_apply_march_t(const float* in, float* out, int64_t frames, int
         const uint32_t total = (uint32_t)(per_frame * nf);
         const uint32_t groups = (total + 3u) / 4u;
         const uint32_t blocks = ((groups + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL((k_apply_march<STAGES>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
-                           reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
+        // frames of at least one strip x one segment and below 2 GiB: the form without conditional blocks (vrg_apply_body.hpp)
+#ifdef VRG_APPLY_FORCE_GENERAL      /* A/B only */
+        if (false)
+#else
+        if (W >= APPLY_COLS && H >= APPLY_ROWS && ppf * 12 < ((int64_t)1 << 31))
+#endif
+            hipLaunchKernelGGL((k_apply_march<STAGES, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
+                               reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
+        else
+            hipLaunchKernelGGL((k_apply_march<STAGES, true>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
+                               reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
         if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
     }
     return VRG_OK;
