@@ -158,7 +158,6 @@ __global__ __launch_bounds__(256) void k_stencil_flat(const float* __restrict__ 
     const uint32_t grp = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= per_xcd || grp >= groups) return;
     const uint32_t wv = grp * 4u + (threadIdx.x >> 6);      // (through readfirstlane -- strip / segment arithmetic in SGPRs -- measured 1-3 % slower here: profiles/r03_flat_stencil_scalar_index_ab.log)
-     // wave-uniform: strip / segment / frame, the row loop and the row bases in SGPRs
     if (wv >= total_waves) return;
     const int lane = threadIdx.x & 63;
     const uint32_t strip = wv % (uint32_t)strips_x;
