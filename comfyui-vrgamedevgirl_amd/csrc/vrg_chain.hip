@@ -8,6 +8,7 @@
 //   * once per pixel inside the reduction (statistics of the grain->LUT output).
 // That makes every fused result bit-identical to running the stand-alone kernels back to back.
 #include "vrg_common.hpp"
+#include <type_traits>
 #include "vrg_chain_stages.hpp"
 
 namespace vrg {
@@ -35,6 +36,37 @@ __global__ __launch_bounds__(256) void k_chain_pointwise(const typename IO::elem
     float o[3];
     chain_pre<STAGES>(D, frame_ctx<STAGES>(D, f), p, x, o, PT);
     IO::store_stream(out + f * ppf + p, px3{o[0], o[1], o[2]});
+}
+
+// Colour-match chains on fp32 frames (no stencil behind them): FOUR pixels per thread, 1024 consecutive pixels per workgroup.  All
+// four requests are issued before the arithmetic tables are staged and land under the staging and the first pixels' ~450
+// instructions each; the table staging and its barrier are paid once per 1024 pixels instead of once per 256; the tail is handled
+// without an exec-masked block (re-read pixel, store dropped by the buffer descriptor's range check).  Frames below 2 GiB.
+template <int STAGES>
+__global__ __launch_bounds__(256) void k_chain_pointwise4(const px3* __restrict__ in, px3* __restrict__ out, int32_t ppf, ChainK D) {
+    const int64_t f = blockIdx.y;
+    const px3* fin = in + f * ppf;
+    const int32_t p0 = (int32_t)blockIdx.x * 1024 + (int32_t)threadIdx.x;
+    px3 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int32_t p = p0 + 256 * j;
+        v[j] = load_px_stream(fin + (p < ppf ? p : 0));
+    }
+    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
+    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(out + f * ppf), 0, ppf * 12, 0x00020000);
+    const FrameCtx FC = frame_ctx<STAGES>(D, f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int32_t p = p0 + 256 * j;
+        const bool valid = p < ppf;
+        const float x[3] = {v[j].r, v[j].g, v[j].b};
+        float o[3];
+        chain_pre<STAGES>(D, FC, valid ? p : 0, x, o, PT);
+        __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2])}, rs,
+                                              (int)(valid ? (uint32_t)p * 12u : 0x80000000u), 0, 0);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -257,6 +289,16 @@ static int launch_stats(const float* in, int64_t frames, int32_t H, int32_t W, c
     return VRG_OK;
 }
 
+// (a function template of its own so that k_chain_pointwise4 is only instantiated for fp32 frames and colour-match chains)
+template <int STAGES, class IO>
+static typename std::enable_if<std::is_same<IO, IoF32>::value && (STAGES & VRG_STAGE_COLORMATCH) && !(STAGES & VRG_STAGE_GRAIN)>::type
+launch_pointwise4(const px3* src, px3* dst, int64_t ppf, int64_t nf, const ChainK& d, hipStream_t st) {
+    hipLaunchKernelGGL((k_chain_pointwise4<STAGES>), dim3((uint32_t)((ppf + 1023) / 1024), (uint32_t)nf), dim3(256), 0, st, src, dst, (int32_t)ppf, d);
+}
+template <int STAGES, class IO>
+static typename std::enable_if<!(std::is_same<IO, IoF32>::value && (STAGES & VRG_STAGE_COLORMATCH) && !(STAGES & VRG_STAGE_GRAIN))>::type
+launch_pointwise4(const typename IO::elem*, typename IO::elem*, int64_t, int64_t, const ChainK&, hipStream_t) {}
+
 template <int STAGES, class IO = IoF32>
 static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, int32_t W, const ChainK& D, bool sharpen,
                         hipStream_t st) {
@@ -294,6 +336,12 @@ static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, in
             const uint32_t total = (uint32_t)(tpf * nf);
             const uint32_t blocks = ((total + 7u) / 8u) * 8u;
             hipLaunchKernelGGL((k_chain_tile<STAGES, IO>), dim3(blocks), dim3(256), 0, st, src, dst, H, W, tx, (int32_t)tpf, total, d);
+#ifndef VRG_NO_POINTWISE4           /* (macro: A/B only) */
+        } else if ((STAGES & VRG_STAGE_COLORMATCH) && !(STAGES & VRG_STAGE_GRAIN) && std::is_same<IO, IoF32>::value && ppf * 12 < ((int64_t)1 << 31)) {
+#else
+        } else if (false) {
+#endif
+            launch_pointwise4<STAGES, IO>(src, dst, ppf, nf, d, st);
         } else {
             hipLaunchKernelGGL((k_chain_pointwise<STAGES, IO>), dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st,
                                src, dst, (int32_t)ppf, d);

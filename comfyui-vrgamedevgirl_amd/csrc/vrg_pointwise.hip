@@ -466,6 +466,36 @@ __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict_
     store_px_stream(out + at, px3{o[0], o[1], o[2]});
 }
 
+// Frames below 2 GiB: four pixels per thread, as k_chain_pointwise4 (vrg_chain.hip) -- the four requests ahead of the table staging,
+// the staging and its barrier once per 1024 pixels, no exec-masked block (the tail's stores are dropped by the buffer range check).
+template <bool FAST>
+__global__ __launch_bounds__(256) void k_colormatch_apply4(const px3* __restrict__ in, px3* __restrict__ out, int32_t pixels_per_frame, CmK cm,
+                                                            DevMath dm) {
+    const int64_t f = blockIdx.y;
+    const px3* fin = in + f * pixels_per_frame;
+    const int32_t p0 = (int32_t)blockIdx.x * 1024 + (int32_t)threadIdx.x;
+    px3 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int32_t p = p0 + 256 * j;
+        v[j] = load_px_stream(fin + (p < pixels_per_frame ? p : 0));
+    }
+    VRG_CM_MATH(PT, true, FAST, dm);
+    typedef unsigned u3 __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(out + f * pixels_per_frame), 0, pixels_per_frame * 12, 0x00020000);
+    const float* ims = cm.img_ms + f * 6;
+    const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int32_t p = p0 + 256 * j;
+        const float x[3] = {v[j].r, v[j].g, v[j].b};
+        float o[3];
+        colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT);
+        __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2])}, rs,
+                                              (int)(p < pixels_per_frame ? (uint32_t)p * 12u : 0x80000000u), 0, 0);
+    }
+}
+
 }  // namespace vrg
 
 using namespace vrg;
@@ -634,7 +664,15 @@ int vrg_colormatch_apply_f32(const float* in, float* out, int64_t frames, int32_
         // ref frame index uses f % ref_frames relative to the call start; 32768 is a multiple of any
         // chunk size only if ref_frames divides it -- keep the mapping exact by offsetting explicitly.
         if (ref_frames != 1 && (f0 % ref_frames) != 0) return VRG_ERR_UNSUPPORTED;
-        if (cm_math == VRG_CM_MATH_FAST)
+        if (ppf * 12 < ((int64_t)1 << 31)) {
+            const dim3 g4((uint32_t)((ppf + 1023) / 1024), (uint32_t)nf);
+            if (cm_math == VRG_CM_MATH_FAST)
+                hipLaunchKernelGGL(k_colormatch_apply4<true>, g4, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const px3*>(in) + f0 * ppf,
+                                   reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c, host_dev_math());
+            else
+                hipLaunchKernelGGL(k_colormatch_apply4<false>, g4, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const px3*>(in) + f0 * ppf,
+                                   reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c, host_dev_math());
+        } else if (cm_math == VRG_CM_MATH_FAST)
             hipLaunchKernelGGL(k_colormatch_apply<true>, dim3(bx, (uint32_t)nf), dim3(256), 0, (hipStream_t)stream,
                                reinterpret_cast<const px3*>(in) + f0 * ppf, reinterpret_cast<px3*>(out) + f0 * ppf, (int32_t)ppf, c, host_dev_math());
         else
