@@ -29,18 +29,6 @@ __global__ __launch_bounds__(256, TWO_PART ? 1 : (STATS ? VRG_PRODUCE_WAVES : VR
     produce_lab_body<STAGES, TWO_PART, STATS>(blockIdx.x, in, lab_out, P, D, pivots, rec, rec_frame, sn, red, PT);
 }
 
-// Lab-only pass 1, wave form (vrg_produce_body.hpp): four independent wave-jobs per workgroup, LDS only for the arithmetic tables
-#ifndef VRG_PRODUCE_WAVE
-#define VRG_PRODUCE_WAVE 1
-#endif
-template <int STAGES>
-__global__ __launch_bounds__(256) void k_produce_lab_wave(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D, uint32_t jobs) {
-    VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
-    const uint32_t job = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    if (job >= jobs) return;
-    produce_lab_wave<STAGES>(job, in, lab_out, P, D, PT);
-}
-
 // Lab of every frame's first pixel after the pre stages: the pivot of that frame's shifted sums
 template <int STAGES>
 __global__ __launch_bounds__(64) void k_frame_pivots(const px3* __restrict__ in, int32_t ppf, int64_t frames, ChainK D, float* __restrict__ pivots) {
@@ -110,12 +98,6 @@ static int launch_produce_t(const float* in, float* lab_out, int64_t frames, int
     produce_geometry(D, frames, fe, P);
     const int64_t blocks = (int64_t)P.chunks * P.K * P.NB;
     if (blocks >= (1ll << 24) || frames % D.noise.chunk_frames) return VRG_ERR_UNSUPPORTED;
-    if (!stats && VRG_PRODUCE_WAVE) {          // Lab image only, wave form
-        const uint64_t jobs = (uint64_t)P.chunks * P.K * produce_wave_jobs_per_quarter(P.G);
-        if (jobs >= (1ull << 31)) return VRG_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_produce_lab_wave<STAGES>), dim3((uint32_t)((jobs + 3) / 4)), dim3(256), 0, st, in, lab_out, P, D, (uint32_t)jobs);
-        return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
-    }
     if (!stats) {                    // Lab image only
         hipLaunchKernelGGL((k_produce_lab<STAGES, false, false>), dim3((uint32_t)blocks), dim3(256), 0, st, in, lab_out, P, D, (const float*)nullptr,
                            (double*)nullptr, (int32_t*)nullptr);

@@ -276,102 +276,5 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
     }
 }
 
-// ----------------------------------------------------------------------------------------------
-// Lab-only pass 1, WAVE form (round 3): the same shared Philox calls and the same arithmetic as produce_lab_body<.., STATS = false>, but
-// nothing is shared between the waves of a workgroup -- no staged normals in LDS, no barrier per sub-range, no edge lanes running the
-// general per-element routine.  A wave-job is PW_STEPS steps of 64 lanes x 3 subsequences; lanes 0..62 own the pixel whose channel 0
-// falls into their three subsequences (per sibling run, after the run's re-alignment to the pixel grid by `shift` elements), lane 63
-// only provides noise: the one or two normals of a pixel that belong to the next lane's calls come over with a DPP wave shift, and
-// consecutive steps / jobs overlap by that one lane (3 of 192 subsequences recomputed, 1.6 %).  Only the wave that reaches the end of
-// a Philox quarter (one in 2,774 at 4K) takes the general routine for the normals beyond it.  The waves of a CU drift apart and
-// overlap each other's gathers and arithmetic instead of meeting at sixteen barriers per workgroup.
-// ----------------------------------------------------------------------------------------------
-#ifndef VRG_PW_STEPS
-#define VRG_PW_STEPS 8
-#endif
-constexpr int PW_STEPS = VRG_PW_STEPS;
-constexpr uint32_t PW_STRIDE = 63u * 3u;                     // subsequences a step advances by
-constexpr uint32_t PW_JOB = PW_STRIDE * PW_STEPS;            // subsequences a job advances by
-
-__device__ __forceinline__ float pw_lane_next(float v) {    // value held by lane+1 (lane 63: unused)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
-
-inline uint32_t produce_wave_jobs_per_quarter(uint32_t G) { return (G + PW_JOB - 1) / PW_JOB; }
-
-template <int STAGES, class MATH>
-__device__ __forceinline__ void produce_lab_wave(uint32_t job, const float* __restrict__ in, float* __restrict__ lab_out, const ProduceK& P, const ChainK& D,
-                                                 const MATH& PT) {
-    constexpr bool HAS_LUT = (STAGES & VRG_STAGE_LUT) != 0;
-    const uint32_t G = P.G;
-    const uint32_t jpq = (G + PW_JOB - 1) / PW_JOB;              // jobs per (chunk, call index)
-    const uint32_t per_chunk = P.K * jpq;
-    const uint32_t chunk = job / per_chunk;
-    if (chunk >= P.chunks) return;
-    const uint32_t rem = job - chunk * per_chunk;
-    const uint32_t k = rem / jpq;
-    const uint32_t I0 = (rem - k * jpq) * PW_JOB;                // first subsequence of the job
-    const int lane = (int)(threadIdx.x & 63u);
-    const int64_t q0 = (int64_t)4 * G * k;
-    const float* cin = in + (int64_t)chunk * P.numel;
-    float* clab = lab_out + (int64_t)chunk * P.numel;
-    const uint64_t seed = chunk_seed(D.noise, chunk);
-    const uint64_t off = chunk_offset(D.noise, chunk);
-    const uint64_t ctr = (off >> 2) + k;
-
-    for (int s = 0; s < PW_STEPS; ++s) {
-        const uint32_t I = I0 + PW_STRIDE * (uint32_t)s;         // first subsequence of the step (uniform)
-        if (I >= G) break;
-        // this lane's pixel of sibling m: channel 0 at subsequence I + p0
-        auto place = [&](int m, int& p0, int64_t& e0) {
-            const int64_t a = q0 + (int64_t)G * m + I;
-            const int shift = (int)((3u - (uint32_t)a % 3u) % 3u);
-            p0 = shift + 3 * lane;
-            e0 = a + p0;
-            return lane < 63 && I + (uint32_t)p0 < G && e0 + 2 < P.numel;
-        };
-        px3 px[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {                            // requested before the noise synthesis (branch-free)
-            int p0;
-            int64_t e0;
-            const bool ok = place(m, p0, e0);
-            px[m] = load_px_stream(reinterpret_cast<const px3*>(cin + (ok ? e0 : 0)));
-        }
-        float nz[3][4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const u32x4 r = philox_for(seed, I + 3u * (uint32_t)lane + (uint32_t)j, ctr);
-            const f32x2 a = box_muller(r.x, r.y);
-            const f32x2 b = box_muller(r.z, r.w);
-            nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = b.x; nz[j][3] = b.y;
-        }
-        const bool quarter_end = I + 192u + 2u > G;              // uniform: some normal of this step lies beyond the Philox quarter
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            int p0;
-            int64_t e0;
-            const bool ok = place(m, p0, e0);
-            const int shift = p0 - 3 * lane;                     // uniform
-            const float nx0 = pw_lane_next(nz[0][m]), nx1 = pw_lane_next(nz[1][m]);
-            float n[3];
-            if (shift == 0) { n[0] = nz[0][m]; n[1] = nz[1][m]; n[2] = nz[2][m]; }
-            else if (shift == 1) { n[0] = nz[1][m]; n[1] = nz[2][m]; n[2] = nx0; }
-            else { n[0] = nz[2][m]; n[1] = nx0; n[2] = nx1; }
-            if (quarter_end) {                                   // rare: the elements past the quarter are other calls' outputs
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (ok && I + (uint32_t)(p0 + c) >= G) n[c] = torch_randn_element(seed, off, G, (uint64_t)(e0 + c));
-            }
-            const float x[3] = {px[m].r, px[m].g, px[m].b};
-            float gr[3], pre[3], lab[3];
-            grain_pixel(x, n, D.I, D.S, D.T, gr);
-            if (HAS_LUT) lut_pixel(D.lut, gr, pre);
-            else { pre[0] = gr[0]; pre[1] = gr[1]; pre[2] = gr[2]; }
-            rgb_to_lab(pre, lab, PT);
-            if (ok) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
-        }
-    }
-}
 
 }  // namespace vrg
