@@ -243,7 +243,7 @@ constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
 #ifndef VRG_TS_ROWS_DEPTH       /* rounds of loads in flight per thread: half-block form / four-workgroup form / whole-frame form */
-#define VRG_TS_ROWS_DEPTH 2
+#define VRG_TS_ROWS_DEPTH 4
 #endif
 #ifndef VRG_TS_SPLIT_DEPTH
 #define VRG_TS_SPLIT_DEPTH 2
@@ -276,7 +276,10 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
     if (whole) {
         // measured on the MI355X (4K frames, ms): 1 frame 1.45 split / 3.57 whole; 64 frames 1.98 / 3.76; 128 frames 5.2 / 3.9 (four
         // readers per frame stop sharing their L2 lines); 256 frames 11.5 / 5.5 (the whole-frame form runs at 4.6 TB/s there).
-        // Two rounds of loads in flight help the latency-bound split form (1.45 vs 1.72 with four), none the HBM-bound one.
+        // Rounds of loads in flight (vrg_tstats_body.hpp, ts_accumulate): since the requests are branch-free (round 3) they really are in
+        // flight -- four for the half-block form (one 4K frame 1.39 ms against 1.71 with two, 1.89 with round 2's conditional loads), two
+        // for the four-workgroup form (64 frames 1.85 ms against 1.98; four: 2.75), the plain one-round loop for the HBM-bound whole-frame
+        // form (256 frames 4.4 ms; branch-free 5.5, two / four rounds 6.3 / 6.7): profiles/r03_stats_prefetch_depth_ab.log.
         // up to 32 frames (and a caller-supplied scratch buffer): eight half-block workgroups per frame, one wave per SIMD
         if (frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsRows) && cm.bh == cw.bh && cm.bh <= 8 && 256 % cm.bw == 0 &&
             (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
