@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round 3, GPU call AD: four-workgroup (split) statistics form, depth 2 branch-free vs depth 1 plain, at 48 / 64 / 96 frames.
+# Round 3, GPU call AE: LDS-tile kernel with branch-free preloaded tile + halo pixels (light chains), A/B on the kernel table.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-O=gpurun_out/r03ad; mkdir -p $O
+O=gpurun_out/r03ae; mkdir -p $O
 {
-  for lib in default split1 default split1; do
-    echo "=== $(date) frames $lib"
-    if [ $lib = default ]; then timeout 600 python tools/frames_table.py --out $O/ft_$lib.json --frames 48,64,96 2>&1 | grep "\[frames\]" | cut -c1-230
-    else VRGDG_HIP_LIB=tools/ab/lib_$lib.so timeout 600 python tools/frames_table.py --out $O/ft_$lib.json --frames 48,64,96 2>&1 | grep "\[frames\]" | cut -c1-230; fi
+  echo "=== $(date) pytest"; timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -k "uint8 or u8 or tile or route or chain or stencil or adjust or variant" 2>&1 | grep -E "passed|failed|error|^FAILED|^E  " | tail -12
+  for lib in default notp default notp; do
+    echo "=== $(date) diag $lib"
+    if [ $lib = default ]; then timeout 600 python tools/gpu_diag.py --frames 16 --iters 5 --out $O/diag_$lib.json 2>&1 | grep "diag\]" | grep -E "u8|tile|variant 1|uint8" | cut -c1-200
+    else VRGDG_HIP_LIB=tools/ab/lib_$lib.so timeout 600 python tools/gpu_diag.py --frames 16 --iters 5 --out $O/diag_$lib.json 2>&1 | grep "diag\]" | grep -E "u8|tile|variant 1|uint8" | cut -c1-200; fi
   done
 } > $O/round.log 2>&1
 cat $O/round.log
