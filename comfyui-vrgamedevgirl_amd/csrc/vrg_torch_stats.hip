@@ -307,9 +307,8 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
 }  // namespace vrg
 
 extern "C" int64_t vrg_lab_stats_torch_scratch_bytes(int64_t frames) {
-    if (frames <= 0) return 0;
-    const int64_t f = frames < vrg::TS_ROWS_MAX_FRAMES ? frames : vrg::TS_ROWS_MAX_FRAMES;       // only the small-batch form uses it
-    return f * (int64_t)sizeof(vrg::TsRows);
+    if (frames <= 0 || frames > vrg::TS_ROWS_MAX_FRAMES) return 0;       // only the small-batch (half-block) form uses a scratch buffer
+    return frames * (int64_t)sizeof(vrg::TsRows);
 }
 
 extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,

@@ -658,7 +658,7 @@ def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Option
         _device_stats_selfcheck(x.device)
     lib = _hip.lib()
     for f0, nf, c in _chunk_runs(F, chunks):
-        nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(nf)) if nf <= 32 else 0      # small batches: the half-block form wants a scratch buffer
+        nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(nf))      # small batches: the half-block form wants a scratch buffer (0: another form)
         scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=x.device) if nbytes else None
         _hip.check(lib.vrg_lab_stats_torch_ws_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c, C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps),
                                                  _hip.ptr(scratch) if scratch is not None else None, nbytes, _hip.current_stream()),

@@ -165,9 +165,10 @@ int vrg_lab_stats_finalize(const double* stats, float* mean_std, int64_t frames,
  * evaluated by torch on the device (tests/test_gpu_parity.py). */
 int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
                             float* mean_std, float eps, void* stream);
-/* The same with a caller-supplied scratch buffer (16-byte aligned, vrg_lab_stats_torch_scratch_bytes(frames) bytes; NULL = none): up to
- * 32 video-sized frames are then reduced by EIGHT half-block workgroups per frame (one wave per SIMD: the dependent Welford update
- * chains are issue bound next to a second wave) plus a finishing kernel -- 1.45 -> ~0.8 ms for one 4K frame.  Same result bits. */
+/* The same with a caller-supplied scratch buffer (16-byte aligned, vrg_lab_stats_torch_scratch_bytes(frames) bytes -- 0 when the batch is
+ * too large for the form that uses one; NULL = none): small batches of video-sized frames are then reduced by EIGHT half-block
+ * workgroups per frame (one wave per SIMD: the dependent Welford update chains are issue bound next to a second wave) plus a finishing
+ * kernel.  Same result bits. */
 int64_t vrg_lab_stats_torch_scratch_bytes(int64_t frames);
 int vrg_lab_stats_torch_ws_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
                                float* mean_std, float eps, void* scratch, int64_t scratch_bytes, void* stream);
