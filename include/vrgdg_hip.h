@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 4
+#define VRG_ABI_VERSION 5
 
 enum vrg_status {
     VRG_OK = 0,
