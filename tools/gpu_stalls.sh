@@ -7,8 +7,7 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
-           "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"; do
+           "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum"; do      # (a TA_BUSY_avr / TA_*_STALLED / GRBM_GUI_ACTIVE set aborted inside rocprofv3 on this image: left out)
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/set$i -o p -- python $GRAFT_REPO_ROOT/tools/prof_driver.py chain4 > $OUT/set$i.log 2>&1
 done
