@@ -43,6 +43,11 @@ def test_versions_and_error_strings(hip):
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8
     assert lib.vrg_lab_stats_scratch_bytes(-1) == 0
+    # the torch-order statistics want a scratch buffer only for the batches their half-block form takes (<= 32 frames): 0 = another form
+    per = lib.vrg_lab_stats_torch_scratch_bytes(1)
+    assert per > 0 and per % 16 == 0
+    assert lib.vrg_lab_stats_torch_scratch_bytes(32) == 32 * per
+    assert lib.vrg_lab_stats_torch_scratch_bytes(33) == 0 and lib.vrg_lab_stats_torch_scratch_bytes(0) == 0
 
 
 def test_argument_validation_without_device(hip):
@@ -58,6 +63,15 @@ def test_argument_validation_without_device(hip):
     assert lib.vrg_grain_f32(one, one, 1, 4, 4, 0.1, 0.5, 0.5, C.byref(bad), null) == 1
     nd2 = hip.NoiseDesc(seed0=1, chunk_frames=2, grid_threads=256)
     assert lib.vrg_grain_f32(one, one, 3, 4, 4, 0.1, 0.5, 0.5, C.byref(nd2), null) == 1         # ragged chunk
+    # fused sharpen -> per-frame-seeded grain: in place / null / bad border are argument errors, sizes it does not take "unsupported"
+    two = C.c_void_p(32)
+    assert lib.vrg_sharpen_grain_f32(one, one, 1, 8, 512, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd), null) == 1       # in == out
+    assert lib.vrg_sharpen_grain_f32(null, two, 1, 8, 512, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd), null) == 1
+    assert lib.vrg_sharpen_grain_f32(one, two, 1, 8, 512, 0.5, 2, 0.1, 0.5, 0.5, C.byref(nd), null) == 1       # border
+    assert lib.vrg_sharpen_grain_f32(one, two, 0, 8, 512, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd), null) == 0       # zero frames: no launch
+    assert lib.vrg_sharpen_grain_f32(one, two, 1, 8, 56, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd), null) == 2        # width below 344
+    assert lib.vrg_sharpen_grain_f32(one, two, 1, 8, 514, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd), null) == 2       # width % 4 != 0
+    assert lib.vrg_sharpen_grain_f32(one, two, 2, 8, 512, 0.5, 0, 0.1, 0.5, 0.5, C.byref(nd2), null) == 2      # several frames per noise chunk
     assert lib.vrg_lut3d_f32(one, one, 0, 3, one, 17, f3, g3, 1, 1.0, 0.0, null) == 0
     assert lib.vrg_lut3d_f32(one, one, 4, 2, one, 17, f3, g3, 1, 1.0, 0.0, null) == 1            # C < 3
     assert lib.vrg_lut3d_f32(one, one, 4, 3, one, 17, f3, g3, 7, 1.0, 0.0, null) == 1            # bad blend mode
