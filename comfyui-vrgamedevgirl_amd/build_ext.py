@@ -37,7 +37,12 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # at 1.8x a plain one on gfx950 (profiles/r02_valu_issue_rate_long.json), so that is a loss: the device-exact colour-match
 # passes run 11-14 % faster without it, grain -> LUT 3 % (A/B: profiles/r02_ab_slp_vectorize.log).  The wave-march kernel
 # is the opposite (grain -> sharpen 26 % slower without SLP) and keeps the default.
-EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",), "vrg_stage.hip": ("-fno-slp-vectorize",)}
+# per translation unit, each an A/B on one box: -fno-slp-vectorize for the colour-match units (profiles/r02_ab_slp_vectorize.log); the
+# "max-ilp" machine scheduler for the grain -> LUT -> sharpen march and the stand-alone stencils (chain 3 -3.4 %, sobel -6 %,
+# profiles/r03_sched_strategy_ab.log; the colour-match passes and the grain kernels are 1-5 % slower with it and keep the default)
+_MAX_ILP = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
+EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",), "vrg_stage.hip": ("-fno-slp-vectorize",),
+               "vrg_march.hip": _MAX_ILP, "vrg_stencil.hip": _MAX_ILP}
 
 
 def _hipcc() -> str:
