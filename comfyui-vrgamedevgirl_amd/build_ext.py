@@ -42,7 +42,8 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # profiles/r03_sched_strategy_ab.log; the colour-match passes and the grain kernels are 1-5 % slower with it and keep the default)
 _MAX_ILP = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
 EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",), "vrg_stage.hip": ("-fno-slp-vectorize",),
-               "vrg_march.hip": _MAX_ILP, "vrg_stencil.hip": _MAX_ILP}
+               "vrg_march.hip": _MAX_ILP, "vrg_stencil.hip": _MAX_ILP,
+               "vrg_pointwise.hip": ("-fno-slp-vectorize",)}       # grain / fused sharpen -> grain -1..-3 % (profiles/r03_sched_strategy_ab.log)
 
 
 def _hipcc() -> str:
