@@ -589,7 +589,7 @@ def main():
                 import host_fed
                 del x
                 torch.cuda.empty_cache()
-                line["host_fed"] = host_fed.measure(frames=8, reps=1)
+                line["host_fed"] = host_fed.measure(frames=8, reps=3)
             except Exception as exc:
                 line["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
         line["verified"] = None if verify is None else bool(verify.get("verified"))

@@ -86,6 +86,8 @@ _SIGNATURES = {
     "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
     "vrg_sharpen_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(NoiseDesc), _P]),
+    "vrg_sharpen_grain_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                       C.POINTER(NoiseDesc), _P]),
     "vrg_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float,
                                 C.POINTER(NoiseDesc), _P]),
     "vrg_grain_injected_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P]),

@@ -86,6 +86,74 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch(const px3* __restrict__ i
     if (p < pixels) out[p] = acc;
 }
 
+// Round 4 probes of the same record run (96 B per pixel, 48-byte records):
+//  mode 9 : ONE 16-byte request per lane (piece 0)            -- one line per lane-instruction, 1 lane-request per pixel
+//  mode 10: TWO requests per lane (pieces 0 and 5)            -- the L2 -> L1 line traffic of mode 0 with a third of its lane-requests
+//  mode 11: the six pieces of a lane's own run through LDS-DMA (global_load_lds_dwordx4: no VGPR destination), read back with ds_read_b128
+//  mode 12: quad-cooperative LDS-DMA: in round p = 0..3 the four lanes of a quad fetch the first 64 bytes of the run of the quad's
+//           pixel p (one 64-byte segment per quad and instruction), rounds 4 / 5 fetch the last 32 bytes of two pixels each; the LDS-DMA
+//           lays every round out lane-linear, so pixel 4q+j finds its pieces at [round j][4q + c] and [4 + j/2][4q + 2 (j&1) + c]
+//           -- the transposition costs no VALU and no VGPR.  Round stride 1040 B keeps the ds_read_b128 groups conflict-free.
+typedef const __attribute__((address_space(1))) void* dbg_gptr;
+typedef __attribute__((address_space(3))) void* dbg_lptr;
+constexpr int DBG_ROUND_BYTES = 1040;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dbg_lut_fetch_r4(const px3* __restrict__ in, float* __restrict__ out, int64_t pixels,
+                                                            const float* __restrict__ cells, int n) {
+    __shared__ __attribute__((aligned(16))) char slots[4][6][DBG_ROUND_BYTES];
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pc = p < pixels ? p : pixels - 1;
+    const px3 v = in[pc];
+    const float top = (float)(n - 1);
+    const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
+    const int nc = n - 1;
+    const int cell = (B.cell * nc + G.cell) * n + R.cell;
+    float acc = 0.0f;
+    if (MODE == 9 || MODE == 10) {
+        const f32x4* q = reinterpret_cast<const f32x4*>(cells + (size_t)cell * 12);
+        const f32x4 t = q[0];
+        acc += (t.x + t.y) + (t.z + t.w);
+        if (MODE == 10) { const f32x4 u = q[5]; acc += (u.x + u.y) + (u.z + u.w); }
+    } else {
+        const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int lane = threadIdx.x & 63, ql = lane & 3;
+        char* my = &slots[w][0][0];
+        if (MODE == 11) {
+            const float* q = cells + (size_t)cell * 12;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                __builtin_amdgcn_global_load_lds((dbg_gptr)(q + 4 * i), (dbg_lptr)(my + i * DBG_ROUND_BYTES), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(my + i * DBG_ROUND_BYTES + lane * 16);
+                acc += (t.x + t.y) + (t.z + t.w);
+            }
+        } else {
+#pragma unroll
+            for (int rnd = 0; rnd < 6; ++rnd) {
+                const int served = dbg_quad_bcast(cell, rnd);
+                const int chunk = rnd < 4 ? ql : 4 + (ql & 1);
+                __builtin_amdgcn_global_load_lds((dbg_gptr)(cells + (size_t)served * 12 + chunk * 4), (dbg_lptr)(my + rnd * DBG_ROUND_BYTES), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int q4 = lane & ~3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(my + ql * DBG_ROUND_BYTES + (q4 + c) * 16);
+                acc += (t.x + t.y) + (t.z + t.w);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(my + (4 + (ql >> 1)) * DBG_ROUND_BYTES + (q4 + 2 * (ql & 1) + c) * 16);
+                acc += (t.x + t.y) + (t.z + t.w);
+            }
+        }
+    }
+    if (p < pixels) out[p] = acc;
+}
+
 // Timing probe for the channel-split LUT: CH_LDS channels of the node table live in LDS (one float / float2 per node), the
 // other 3 - CH_LDS channels are gathered from a global record table with 4 * (3 - CH_LDS) floats per (b0, g0, r) record.
 // Persistent 1024-thread workgroups (one per CU next to the LDS table).  Values are checksums, not pixels.
@@ -380,9 +448,19 @@ int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float 
 }
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
-    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 8) return VRG_ERR_BAD_ARG;
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 12) return VRG_ERR_BAD_ARG;
     const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
     const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
+    if (mode >= 9) {
+        switch (mode) {
+            case 9: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<9>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 10: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 11: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<11>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<12>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+        }
+        VRG_CHECK_LAUNCH();
+        return VRG_OK;
+    }
     if (mode >= 7) {      // three channel passes through LDS, 8 (mode 7) or 16 (mode 8) pixels per thread
         const size_t lds = ((size_t)lut_size * lut_size * lut_size * 4 + 15) / 16 * 16;
         if (lds > 160 * 1024) return VRG_ERR_UNSUPPORTED;

@@ -342,6 +342,159 @@ __global__ __launch_bounds__(256) void k_sharpen_grain(const float* __restrict__
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same pass on DECODED frames: uint8 B,G,R in -> / 255 -> unsharp -> per-frame-seeded grain -> * 255 clip truncate -> uint8 B,G,R
+// out, i.e. _tensor_to_frames(_apply_effects_batch(_frames_to_tensor(frames))) of the stand-alone enhancer's render loop
+// (VRGDG_StandaloneVideoEnhancerNodes.py:311-324, 278-294, 417-421) in ONE kernel: 3 + 3 B/px of HBM traffic where the converter ->
+// fused fp32 kernel -> converter route moves 3 + 12 | 12 + 12 | 12 + 3.  Same geometry as k_sharpen_grain with BYTES in the place of
+// floats: element li = 3 p + c of the reference's fp32 R,G,B tensor is byte 3 p + 2 - c of the frame, so element and byte indices
+// cover the same ranges and a block's four sibling runs of 1024 elements are four runs of 1024 bytes = 256 dwords; a thread owns
+// one dword (four bytes) of each run.  The 3x3 window is built per channel in byte space (horizontal taps 3 bytes away: the
+// previous / next dword of the row come from the neighbouring lanes with ONE DPP wave shift of the raw dword each, lanes 0 / 63 from
+// one extra load), every tap is converted with the reference's own v / 255 (unit_from_u8); the grain of byte 3 p + j uses the
+// normal of element 3 p + 2 - j and the green normal of element 3 p + 1, both read from the block's staged normals (two halo
+// elements per side and run instead of one).  Arithmetic: unit_from_u8, stencil_value, grain_element, u8_from_unit -- the functions
+// the three-kernel route evaluates, in its order: byte-identical to it.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sg_shr_u(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t sg_shl_u(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+struct SgRawU8 { uint32_t own[3], halo[3]; };
+
+template <bool ZERO>
+__global__ __launch_bounds__(256) void k_sharpen_grain_u8(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, NoiseK nk, int32_t H,
+                                                           int32_t n4, uint32_t groups_per_frame, uint32_t total_blocks, float strength,
+                                                           float I, float S, float T) {
+    __shared__ float sn[4][GRAIN_N + 8];                              // [run][4 + element of the run]; halo elements at 2, 3 and 4 + valid_n, 5 + valid_n
+    const uint32_t per_xcd = (total_blocks + 7u) >> 3;
+    const uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || b >= total_blocks) return;
+    const uint32_t G = nk.G;
+    const uint32_t segs = (G + GRAIN_N - 1) / GRAIN_N;
+    const uint32_t bpf = segs * groups_per_frame;
+    const uint32_t frame = b / bpf;
+    const uint32_t rem = b - frame * bpf;
+    const uint32_t k = rem / segs;
+    const uint32_t idx_base = (rem - k * segs) * GRAIN_N;
+    const uint32_t valid_n = (G - idx_base) < (uint32_t)GRAIN_N ? (G - idx_base) : (uint32_t)GRAIN_N;      // a multiple of 256: whole waves
+    const uint32_t tid = threadIdx.x, t4 = tid * GRAIN_IPT;
+    const int lane = (int)(tid & 63u);
+    const uint64_t seed = chunk_seed(nk, frame);
+    const uint64_t off = chunk_offset(nk, frame);
+    const uint64_t ctr = (off >> 2) + k;
+    const uint32_t nvec = (uint32_t)H * (uint32_t)n4;                 // dwords per frame
+    const uint32_t* fin = in + (int64_t)frame * nvec;
+    uint32_t* fout = out + (int64_t)frame * nvec;
+    const uint32_t vec0 = (4u * G * k + idx_base) >> 2;
+
+    auto request = [&](int ii, SgRawU8& q, uint32_t& v_out, int32_t& y_out, int32_t& col_out) {
+        const uint32_t vb = vec0 + (G >> 2) * (uint32_t)ii;           // block-uniform
+        const uint32_t yb = vb / (uint32_t)n4;
+        int32_t col = (int32_t)(vb - yb * (uint32_t)n4 + tid);
+        int32_t y = (int32_t)yb;
+        if (col >= n4) { col -= n4; y += 1; }                          // n4 >= 256: at most one row end inside a block
+        v_out = vb + tid;
+        y = y < H ? y : H - 1;
+        const int32_t yu = y > 0 ? y - 1 : 0, yd = y < H - 1 ? y + 1 : H - 1;
+        const int32_t hc = (lane == 0 && col > 0) ? col - 1 : ((lane == 63 && col + 1 < n4) ? col + 1 : col);
+        const int32_t ys[3] = {yu, y, yd};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t* row = fin + (int64_t)ys[r] * n4;
+            q.own[r] = row[col];
+            q.halo[r] = row[hc];
+        }
+        y_out = y;
+        col_out = col;
+    };
+
+    SgRawU8 q;
+    uint32_t v;
+    int32_t y, col;
+    request(0, q, v, y, col);                                         // in flight under the Philox rounds
+
+    float nz[GRAIN_IPT][4];
+#pragma unroll
+    for (int j = 0; j < GRAIN_IPT; ++j) {
+        const u32x4 r = philox_for(seed, idx_base + t4 + j, ctr);
+        const f32x2 a = box_muller(r.x, r.y);
+        const f32x2 bb = box_muller(r.z, r.w);
+        nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = bb.x; nz[j][3] = bb.y;
+    }
+    if (t4 < valid_n) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(&sn[ii][4 + t4]) = make_float4(nz[0][ii], nz[1][ii], nz[2][ii], nz[3][ii]);
+    }
+    const int64_t fe = (int64_t)nvec * 4;
+    const int64_t group_base = (int64_t)4 * G * k + idx_base;
+    if (tid < 16) {                                                   // the two normals on either side of the block's four runs
+        const int ii = (int)(tid >> 2);
+        const int right = (int)((tid >> 1) & 1), d = (int)(tid & 1);
+        const int64_t li = group_base + (int64_t)G * ii + (right ? (int64_t)valid_n + d : -1 - d);
+        float nv = 0.0f;
+        if (li >= 0 && li < fe) nv = torch_randn_element(seed, off, G, (uint64_t)li);
+        sn[ii][right ? 4 + valid_n + d : 3 - d] = nv;
+    }
+    __syncthreads();
+    if (t4 >= valid_n) return;                                        // whole waves
+
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        if (ii > 0) request(ii, q, v, y, col);
+        if (vec0 + (G >> 2) * (uint32_t)ii >= nvec) continue;         // block-uniform: this run starts past the frame
+        const bool first = col == 0, last = col == n4 - 1;
+        const bool row_end_here = __builtin_amdgcn_ballot_w64(first || last) != 0;
+        const bool frame_edge_here = ZERO && __builtin_amdgcn_ballot_w64(y == 0 || y == H - 1) != 0;
+        float o[3][4], pl[3][3], nr[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            uint32_t ow = q.own[r], hw = q.halo[r];
+            if (ZERO && r != 1 && frame_edge_here) {                  // avg_pool2d(padding=1): the rows outside the frame are zeros (byte 0 -> 0.0f)
+                const bool outside = (r == 0 && y == 0) || (r == 2 && y == H - 1);
+                ow = outside ? 0u : ow;
+                hw = outside ? 0u : hw;
+            }
+            const uint32_t prev = sg_shr_u(hw, ow), next = sg_shl_u(hw, ow);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[r][i] = unit_from_u8((uint8_t)(ow >> (8 * i)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pl[r][i] = unit_from_u8((uint8_t)(prev >> (8 * (1 + i))));   // bytes -3 + i of this dword = the previous dword's tail
+                nr[r][i] = unit_from_u8((uint8_t)(next >> (8 * i)));         // bytes 4 + i = the next dword's head
+            }
+            if (row_end_here) {                                       // row ends: replicate the end pixel, or zero
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    pl[r][i] = first ? (ZERO ? 0.0f : o[r][i]) : pl[r][i];
+                    nr[r][i] = last ? (ZERO ? 0.0f : o[r][1 + i]) : nr[r][i];
+                }
+            }
+        }
+        int jj = (int)((4u * v) % 3u);                                // position of the dword's first byte in its pixel: 0 = B, 1 = G, 2 = R
+        uint32_t packed = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float p[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                p[r][0] = kk >= 3 ? o[r][kk >= 3 ? kk - 3 : 0] : pl[r][kk < 3 ? kk : 0];
+                p[r][1] = o[r][kk];
+                p[r][2] = kk < 1 ? o[r][kk < 1 ? kk + 3 : 0] : nr[r][kk >= 1 ? kk - 1 : 0];
+            }
+            const float x = stencil_value(0, p, strength, ZERO ? 1 : 0);
+            const float n_own = sn[ii][4 + t4 + kk + 2 - 2 * jj];     // element 3 p + 2 - jj of byte 3 p + jj
+            const float n_green = sn[ii][4 + t4 + kk + 1 - jj];       // element 3 p + 1
+            const float res = grain_element(x, n_own, n_green, 2 - jj, I, S, T);
+            packed |= (uint32_t)u8_from_unit(res) << (8 * kk);
+            jj = (jj == 2) ? 0 : jj + 1;
+        }
+        if (v < nvec) fout[v] = packed;
+    }
+}
+
 // Noise-injection form: out = grain(x, noise) with caller-supplied normals (one pixel per thread).
 __global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ in, const px3* __restrict__ nz,
                                                          px3* __restrict__ out, int64_t pixels, float I, float S, float T) {
@@ -582,6 +735,40 @@ int vrg_sharpen_grain_f32(const float* in, float* out, int64_t frames, int32_t h
                                (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
         else
             hipLaunchKernelGGL((k_sharpen_grain<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, nkk, height, width * 3 / 4,
+                               (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+        VRG_CHECK_LAUNCH();
+    }
+    return VRG_OK;
+}
+
+int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width, float strength, int32_t border,
+                         float intensity, float sat, float one_minus_sat, const vrg_noise_desc* nd, void* stream) {
+    if (!in || !out || in == out || !nd || frames < 0 || height <= 0 || width <= 0 || border < 0 || border > 1 || nd->chunk_frames < 1 ||
+        nd->grid_threads == 0 || (nd->grid_threads % 256u) != 0)
+        return VRG_ERR_BAD_ARG;
+    if (frames == 0) return VRG_OK;
+    const int64_t frame_elems = (int64_t)height * width * 3;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 4 == 0;
+    if (nd->chunk_frames != 1 || width % 4 != 0 || (int64_t)width * 3 / 4 < 256 || frame_elems > 0x7fffffffll || !aligned)
+        return VRG_ERR_UNSUPPORTED;                                   // the caller converts and runs the fp32 entry points
+    const NoiseK nk = make_noise(nd, frame_elems);
+    const uint64_t groups = (uint64_t)((frame_elems + 4 * (int64_t)nk.G - 1) / (4 * (int64_t)nk.G));
+    const uint64_t per_frame = groups * ((nk.G + GRAIN_N - 1) / GRAIN_N);
+    const int64_t step = (int64_t)(0x7fffffffull / per_frame) - 1;   // frames per launch
+    if (step < 1) return VRG_ERR_UNSUPPORTED;
+    for (int64_t f0 = 0; f0 < frames; f0 += step) {
+        const int64_t nf = frames - f0 < step ? frames - f0 : step;
+        NoiseK nkk = nk;
+        nkk.chunk0 += f0;
+        const uint32_t total = (uint32_t)(per_frame * (uint64_t)nf);
+        const uint32_t blocks = ((total + 7u) / 8u) * 8u;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in + f0 * frame_elems);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + f0 * frame_elems);
+        if (border == VRG_BORDER_ZERO)
+            hipLaunchKernelGGL((k_sharpen_grain_u8<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, nkk, height, width * 3 / 4,
+                               (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+        else
+            hipLaunchKernelGGL((k_sharpen_grain_u8<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, nkk, height, width * 3 / 4,
                                (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
         VRG_CHECK_LAUNCH();
     }

@@ -274,6 +274,8 @@ def sharpen_then_seeded_grain(images: torch.Tensor, sharpen_strength: float, zer
     (VRGDG_StandaloneVideoEnhancerNodes.py:278-294) as ONE pass over the frames (vrg_sharpen_grain_f32: 24 B/px).  Frame sizes the
     fused kernel does not take (width not a multiple of 4 or below 344) run the two kernels; the result is the same bits either way
     (tests/test_gpu_parity.py::test_fused_sharpen_then_seeded_grain_equals_the_two_kernels)."""
+    if isinstance(images, torch.Tensor) and images.dtype == torch.uint8:
+        return _sharpen_then_seeded_grain_u8(images, sharpen_strength, zero_border, grain_intensity, saturation_mix, seed, frame_start)
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
     if F == 0 or sharpen_strength <= 0 or grain_intensity <= 0:
@@ -298,6 +300,47 @@ def sharpen_then_seeded_grain(images: torch.Tensor, sharpen_strength: float, zer
             return film_grain_seeded_frames(stencil3x3(x, "unsharp", sharpen_strength, zero_border), grain_intensity, saturation_mix,
                                             seed, frame_start)
         _hip.check(st, "vrg_sharpen_grain_f32")
+        f += run
+    return out
+
+
+def _sharpen_then_seeded_grain_u8(frames_bgr, sharpen_strength, zero_border, grain_intensity, saturation_mix, seed, frame_start):
+    """Decoded uint8 B,G,R frames in and out: ``_tensor_to_frames(_apply_effects_batch(_frames_to_tensor(frames)))`` of the enhancer's
+    render loop (VRGDG_StandaloneVideoEnhancerNodes.py:417-421) as one kernel (vrg_sharpen_grain_u8, 3 + 3 B/px).  Frame sizes the
+    kernel refuses, or a call with one of the two effects off, take the converter -> fp32 -> converter route: the same bytes."""
+    x = _check_frames(frames_bgr, "frames", channels=3, dtype=torch.uint8)
+    F, H, W, _ = x.shape
+    if F == 0:
+        return x.clone()
+
+    def through_fp32():
+        y = frames_u8_to_f32(x)
+        if sharpen_strength > 0:
+            y = stencil3x3(y, "unsharp", sharpen_strength, zero_border)
+        if grain_intensity > 0:
+            y = film_grain_seeded_frames(y, grain_intensity, saturation_mix, seed, frame_start)
+        return f32_to_frames_u8(y)
+
+    if sharpen_strength <= 0 or grain_intensity <= 0:
+        return through_fp32()
+    fe = H * W * 3
+    I32, S32, T32 = _f32(grain_intensity), _f32(saturation_mix), _f32(1.0 - saturation_mix)
+    out = torch.empty_like(x)
+    lib = _hip.lib()
+    first = int(seed) + int(frame_start)
+    f = 0
+    while f < F:   # split where the 31-bit mask wraps (practically never)
+        s0 = (first + f) & 0x7FFFFFFF
+        run = min(F - f, 0x80000000 - s0)
+        d = NoisePlan(1, rng.per_frame_seeded(fe, s0, x.device)).desc()
+        st = lib.vrg_sharpen_grain_u8(C.c_void_p(x.data_ptr() + f * fe), C.c_void_p(out.data_ptr() + f * fe), run, H, W,
+                                      _f32(sharpen_strength), _hip.BORDER_ZERO if zero_border else _hip.BORDER_REPLICATE, I32, S32, T32,
+                                      C.byref(d), _hip.current_stream())
+        if st == _hip.VRG_ERR_UNSUPPORTED:
+            if f != 0:
+                raise RuntimeError("vrg_sharpen_grain_u8 refused a later run of a batch it had accepted")
+            return through_fp32()
+        _hip.check(st, "vrg_sharpen_grain_u8")
         f += run
     return out
 

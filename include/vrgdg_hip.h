@@ -93,6 +93,16 @@ int vrg_sharpen_grain_f32(const float* in, float* out, int64_t frames, int32_t h
                           float strength, int32_t border, float intensity, float sat, float one_minus_sat,
                           const vrg_noise_desc* noise, void* stream);
 
+/* f1 x f3  The same pass on DECODED frames, uint8 B,G,R in and out -- the stand-alone enhancer's render loop body
+ * _tensor_to_frames(_apply_effects_batch(_frames_to_tensor(frames))) (VRGDG_StandaloneVideoEnhancerNodes.py:311-324, 278-294,
+ * 417-421) as ONE kernel moving 3 + 3 B/px: v / 255 at the load, unsharp (border as above), per-frame-seeded grain,
+ * clip(x * 255, 0, 255) truncated to uint8 at the store.  out = vrg_f32rgb_to_u8bgr(vrg_sharpen_grain_f32(vrg_u8bgr_to_f32rgb(in)))
+ * byte for byte.  in != out.  VRG_ERR_UNSUPPORTED (the caller runs that three-kernel route) unless width % 4 == 0,
+ * width * 3 / 4 >= 256, chunk_frames == 1 and both pointers are 4-byte aligned. */
+int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width,
+                         float strength, int32_t border, float intensity, float sat, float one_minus_sat,
+                         const vrg_noise_desc* noise, void* stream);
+
 /* Same arithmetic with the N(0,1) noise supplied by the caller (device pointer, same shape as
  * `in`): the noise-injection form used to prove arithmetic parity against the CPU reference. */
 int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels,

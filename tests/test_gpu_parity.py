@@ -1259,6 +1259,10 @@ def test_u8_converters_match_reference_fixtures(pkg, ops, dev):
     for mod in (LVT, SVE):
         for tag in ("rand", "ramp"):
             t = mod._frames_to_tensor(list(z[f"{tag}.frames"]))
+            if mod is SVE:                       # the enhancer's loop keeps the decoded batch in uint8 and defers the / 255
+                assert isinstance(t, SVE.DecodedFrames) and t.is_cuda and t.u8.dtype == torch.uint8 and len(t) == len(z[f"{tag}.frames"])
+                _frames_eq(SVE._tensor_to_frames(t), z[f"{tag}.frames"], "deferred frames round trip")
+                t = t.float_tensor()
             assert t.is_cuda and t.dtype == torch.float32
             assert_bit_equal(t, _t(z[f"{tag}.tensor"]), f"frames_to_tensor {tag}")
         for tag in ("tens", "edge"):
@@ -1459,7 +1463,92 @@ def test_enhancer_loop_stays_on_gpu_between_uint8_edges(pkg, dev):
     want = R.seeded_grain(R.unsharp(R.frames_to_tensor(frames), 0.6, True).contiguous(), 0.05, 0.4, 9, 30, noise_fn=noise_fn)
     _frames_eq(out, R.tensor_to_frames(want), "enhancer loop")
     cpu_in = enh._apply_effects_batch(R.frames_to_tensor(frames), st, 30)         # CPU tensor in -> CPU tensor out, as in the reference
-    assert cpu_in.device.type == "cpu" and torch.equal(cpu_in, enhanced.cpu())
+    assert cpu_in.device.type == "cpu" and torch.equal(cpu_in, want)
+    # a batch the device refuses is halved like the reference's (:297-308): same bytes, smallest batch reported
+    calls = {"n": 0}
+    real = enh._apply_effects_batch
+
+    def flaky(images, settings, frame_start=0):
+        calls["n"] += 1
+        if len(images) > 2:
+            raise RuntimeError("HIP out of memory (simulated)")
+        return real(images, settings, frame_start)
+
+    enh._apply_effects_batch = flaky
+    try:
+        halves, used = enh._process_with_retry(enh._frames_to_tensor(frames), st, 30)
+    finally:
+        enh._apply_effects_batch = real
+    assert used <= 2 and isinstance(halves, enh.DecodedFrames)
+    _frames_eq(enh._tensor_to_frames(halves), out, "halved batches")
+
+
+@pytest.mark.parametrize("zero_border", [False, True], ids=["replicate", "zero"])
+@pytest.mark.parametrize("shape", [(3, 37, 344, 3), (2, 64, 1024, 3), (2, 90, 500, 3), (2, 5, 4096, 3), (1, 1, 2048, 3), (2, 1080, 1920, 3),
+                                   (1, 2160, 3840, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_u8_sharpen_then_seeded_grain_equals_the_converter_route(pkg, ops, dev, shape, zero_border):
+    """vrg_sharpen_grain_u8 -- decoded B,G,R bytes in, / 255, unsharp, per-frame-seeded grain, * 255 clip truncate, bytes out: the
+    enhancer's loop body (VRGDG_StandaloneVideoEnhancerNodes.py:417-421) in one kernel -- against converter -> fused fp32 kernel ->
+    converter (each held to the reference's fixtures / the oracle elsewhere), byte for byte; against the oracle from the bytes up for the
+    small shapes; and the reference's batch-invariance property (tests/test_standalone_video_enhancer.py:39-61) on bytes."""
+    from comfyui_vrgamedevgirl_amd import _hip, rng
+    import ctypes as C
+    g = torch.Generator().manual_seed(sum(shape) + int(zero_border))
+    frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    frames[0, 0, :8] = torch.tensor([0, 255, 1, 254, 128, 127, 255, 0], dtype=torch.uint8)[:, None]      # saturated codes on a border
+    x = frames.to(dev)
+    route = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(x), 0.6, zero_border, 0.05, 0.4, 1234, 17))
+    got = ops.sharpen_then_seeded_grain(x, 0.6, zero_border, 0.05, 0.4, 1234, 17)
+    assert got.dtype == torch.uint8
+    _frames_eq(got.cpu().numpy(), route.cpu().numpy(), "uint8 sharpen -> seeded grain")
+    out = torch.zeros_like(x)
+    d = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 1234 + 17, dev)).desc()
+    st = _hip.lib().vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(out), shape[0], shape[1], shape[2], 0.6, 1 if zero_border else 0,
+                                         0.05, 0.4, float(np.float32(1.0 - 0.4)), C.byref(d), _hip.current_stream())
+    assert st == _hip.VRG_OK                                   # the kernel itself ran (the op falls back for what it refuses)
+    _frames_eq(out.cpu().numpy(), route.cpu().numpy(), "vrg_sharpen_grain_u8")
+    if x.numel() < 1 << 20:
+        def noise_fn(fseed, shp):
+            gg = torch.Generator(device=dev).manual_seed(fseed)
+            return torch.randn(shp, generator=gg, device=dev).cpu()
+        want = R.seeded_grain(R.unsharp(R.frames_to_tensor(list(frames.numpy())), 0.6, zero_border).contiguous(), 0.05, 0.4, 1234, 17,
+                              noise_fn=noise_fn)
+        _frames_eq(got.cpu().numpy(), np.stack(R.tensor_to_frames(want)), "uint8 sharpen -> seeded grain vs oracle")
+        half = shape[0] // 2
+        if half:
+            split = torch.cat((ops.sharpen_then_seeded_grain(x[:half], 0.6, zero_border, 0.05, 0.4, 1234, 17),
+                               ops.sharpen_then_seeded_grain(x[half:], 0.6, zero_border, 0.05, 0.4, 1234, 17 + half)))
+            assert torch.equal(split, got)
+
+
+def test_u8_sharpen_grain_refuses_what_it_does_not_take(pkg, ops, dev):
+    """Widths not a multiple of 4 or below 344, several frames per noise chunk, in-place, one effect off: the entry point says so and the
+    operator returns the converter route's bytes."""
+    from comfyui_vrgamedevgirl_amd import _hip, rng
+    import ctypes as C
+    lib = _hip.lib()
+    for shp in ((2, 20, 56, 3), (2, 20, 346, 3)):
+        g = torch.Generator().manual_seed(shp[2])
+        x = torch.randint(0, 256, shp, generator=g, dtype=torch.uint8).to(dev)
+        out = torch.empty_like(x)
+        d = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 3, dev)).desc()
+        args = (shp[0], shp[1], shp[2], 0.5, 0, 0.04, 0.5, 0.5, C.byref(d), _hip.current_stream())
+        assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(out), *args) == _hip.VRG_ERR_UNSUPPORTED
+        assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(x), *args) == _hip.VRG_ERR_BAD_ARG
+        want = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(x), 0.5, False, 0.04, 0.5, 3, 0))
+        assert torch.equal(ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 3, 0), want)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randint(0, 256, (2, 20, 512, 3), generator=g, dtype=torch.uint8).to(dev)
+    d = ops.NoisePlan(2, rng.per_frame_seeded(x.numel(), 3, dev)).desc()
+    assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(torch.empty_like(x)), 2, 20, 512, 0.5, 0, 0.04, 0.5, 0.5, C.byref(d),
+                                    _hip.current_stream()) == _hip.VRG_ERR_UNSUPPORTED
+    for strength, intensity in ((0.0, 0.05), (0.6, 0.0), (0.0, 0.0)):       # one effect (or both) off: the reference's early returns
+        y = ops.frames_u8_to_f32(x)
+        if strength > 0:
+            y = ops.stencil3x3(y, "unsharp", strength, True)
+        if intensity > 0:
+            y = ops.film_grain_seeded_frames(y, intensity, 0.5, 3, 0)
+        assert torch.equal(ops.sharpen_then_seeded_grain(x, strength, True, intensity, 0.5, 3, 0), ops.f32_to_frames_u8(y))
 
 
 # ---------------------------------------------------------------------------------------- opening colour match (8f-4)
@@ -1953,6 +2042,36 @@ def test_output_bits_do_not_depend_on_the_number_of_ranks(dev, cm_stats):
     assert two["n_gpus"] == 2 and len(two["output_sha256_per_rank_per_chunk"]) == 2
     flat_two = [d for rank in two["output_sha256_per_rank_per_chunk"] for d in rank]
     assert flat_two == one["output_sha256_per_rank_per_chunk"][0], "2 ranks x 8 frames vs 1 rank x 16 frames: output bits differ"
+
+
+@pytest.mark.parametrize("cm_stats", ["device", "fp64"])
+def test_bench_eight_rank_flow_on_one_gpu_with_gloo(dev, cm_stats):
+    """The flow the driver launches on an 8-GPU node -- `bench.py --gpus 8` -> torch.distributed.run, one rank per GPU, barrier +
+    max-over-ranks timing, the reference statistics per rank (device) / rows split eight ways + all-reduce (fp64) -- exercised with
+    eight ranks sharing cuda:0 over gloo (8 x 3 buffers x 4 frames x 99.5 MB fit one GPU): every rank's chunk digests equal those of
+    ONE rank x 32 frames, and the line carries the fields the scaling record needs.  What this cannot show: any N > 1 TIMING and the
+    RCCL transport."""
+    import json
+    import subprocess
+    from conftest import ROOT
+
+    def run(gpus, frames):
+        env = dict(os.environ, VRGDG_DIST_BACKEND="gloo")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--frames", str(frames), "--steps", "1",
+                            "--warmup", "0", "--no-cpu-baseline", "--no-live-traffic", "--no-fast-variant", "--no-verify", "--digest",
+                            "--same-data", "--cm-stats", cm_stats], capture_output=True, text=True, env=env, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    eight, one = run(8, 4), run(1, 32)
+    assert eight["n_gpus"] == 8 and eight["rccl_ranks"] == 8 and eight["scaling"] == "weak"
+    assert len(eight["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in eight["per_rank_ms_per_step"])
+    assert eight["ms_per_step"] >= max(eight["per_rank_ms_per_step"]) - 1e-6              # the line's time is the max over ranks
+    assert "roofline" in eight and eight["roofline"]["bound"] == "hbm" and eight["config"]["frames_per_gpu"] == 4
+    assert len(eight["output_sha256_per_rank_per_chunk"]) == 8
+    flat = [d for rank in eight["output_sha256_per_rank_per_chunk"] for d in rank]
+    assert flat == one["output_sha256_per_rank_per_chunk"][0], "8 ranks x 4 frames vs 1 rank x 32 frames: output bits differ"
 
 
 def test_device_statistics_of_a_split_call_use_the_whole_calls_mean_factor(ops, dev):

@@ -10,43 +10,56 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def measure(frames=16, H=2160, W=3840, reps=2):
+def measure(frames=16, H=2160, W=3840, reps=3):
+    """Wall-clock seconds per call: one warm-up call per case, then `reps` (>= 3) ROUNDS in which every case runs once -- the cases are
+    interleaved so that a slow phase of the box hits all of them --, and the MEDIAN over the rounds with the spread (max - min) beside
+    it.  (Round 3 reported the minimum of ONE repetition per case: page-locked input once came out slower than pageable.)"""
+    import statistics
     from __graft_entry__ import load_package
     load_package()
     from comfyui_vrgamedevgirl_amd import nodes, VRGDG_IV_Adjustments as iv
+    reps = max(3, int(reps))
     g = torch.Generator().manual_seed(3)
     x = torch.rand((frames, H, W, 3), generator=g)
     ref = x[:1].clone()
     px = frames * H * W
     nbytes = x.numel() * 4
 
-    def wall(fn):
-        r = fn(); torch.cuda.synchronize(); del r
-        best = 1e9
-        for _ in range(reps):
-            t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0); del r
-        return best
+    def once(fn):
+        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0; del r
+        return dt
 
     cases = [("FastFilmGrain (bs 4)", lambda t: nodes.FastFilmGrain().apply_grain(t, 0.04, 0.5, 4)[0]),
              ("VRGDG_LUTS (AMD_TealOrange_33)", lambda t: iv.VRGDG_LUTS().apply_lut(t, "AMD_TealOrange_33.cube", "auto", 10.0)[0]),
              ("ColorMatchToReference (bs 1)", lambda t: nodes.ColorMatchToReference().match_color(t, ref, 1.0, 1)[0]),
              ("FastUnsharpSharpen", lambda t: nodes.FastUnsharpSharpen().apply_unsharp(t, 0.5, False)[0])]
-    rows = []
-    xp = x.pin_memory()
-    for name, fn in cases:
-        for label, src in (("pageable input", x), ("page-locked input", xp)):
-            t = wall(lambda: fn(src))
-            rows.append({"node": name, "input": label, "frames": frames, "seconds": round(t, 4), "Mpix_s": round(px / t / 1e6, 1),
-                         "GB_s_each_way": round(nbytes / t / 1e9, 2)})
 
     def chain(t):
         for _, fn in cases:
             t = fn(t)
         return t
-    t = wall(lambda: chain(x))
-    rows.append({"node": "grain -> LUT -> colour match -> unsharp, four node calls (each crosses PCIe both ways)", "input": "pageable input", "frames": frames,
-                 "seconds": round(t, 4), "Mpix_s": round(px / t / 1e6, 1)})
-    return {"frames": frames, "height": H, "width": W, "devices": os.environ.get("VRGDG_DEVICES", "") or "one", "rows": rows}
+    xp = x.pin_memory()
+    runs = []
+    for name, fn in cases:
+        for label, src in (("pageable input", x), ("page-locked input", xp)):
+            runs.append((name, label, (lambda f=fn, s_=src: f(s_))))
+    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls (each crosses PCIe both ways)", "pageable input", lambda: chain(x)))
+    for _, _, fn in runs:          # warm-up: the first call page-locks the result buffer
+        once(fn)
+    times = [[] for _ in runs]
+    for _ in range(reps):
+        for i, (_, _, fn) in enumerate(runs):
+            times[i].append(once(fn))
+    rows = []
+    for (name, label, _), ts in zip(runs, times):
+        t = statistics.median(ts)
+        row = {"node": name, "input": label, "frames": frames, "seconds": round(t, 4), "Mpix_s": round(px / t / 1e6, 1),
+               "seconds_min_max": [round(min(ts), 4), round(max(ts), 4)], "spread_pct": round(100.0 * (max(ts) - min(ts)) / t, 1), "reps": reps}
+        if not name.startswith("grain ->"):
+            row["GB_s_each_way"] = round(nbytes / t / 1e9, 2)
+        rows.append(row)
+    return {"frames": frames, "height": H, "width": W, "devices": os.environ.get("VRGDG_DEVICES", "") or "one", "timing": f"median of {reps} interleaved rounds",
+            "rows": rows}
 
 
 if __name__ == "__main__":
