@@ -62,10 +62,6 @@ def parse_args():
     ap.add_argument("--digest", action="store_true", help="add the SHA-256 of every rank's output (per RNG chunk) to the line: equal frame ranges of "
                                                           "runs with different GPU counts must give equal digests")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (CPU tensors in and out, PCIe inclusive) node rates of the line's `host_fed` key")
-    ap.add_argument("--pieces", type=int, default=None, help="frame ranges the two-pass chain is pipelined over (pass 2 of piece i next to pass 1 of "
-                                                           "piece i+1 on a second stream); default: ops.default_overlap_pieces; 1 = sequential passes")
-    ap.add_argument("--stats-pieces", type=int, default=None, help="frame ranges of pass 1 whose statistics reductions run on the high-priority side stream "
-                                                                 "next to pass 1 of the following range; default: ops.default_stats_pieces; 1 = one range")
     ap.add_argument("--same-data", action="store_true", help="frames are a function of their ABSOLUTE index in the job (rank r holds frames "
                                                              "[r*frames, (r+1)*frames) of one job-wide batch), so that runs with different GPU counts process "
                                                              "the same data; default: an independent batch per rank")
@@ -180,8 +176,6 @@ def live_traffic(timeout_s=150):
            "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")
-    # the staged form runs the three kernels' device code as roles of one launch per stage: per pixel of the chain, their sum
-    res["stage"] = {k: round(sum(res[p][k] for p in ("stats", "tstats", "apply")), 2) for k in ("read", "written", "total", "valu_lane_instr", "valu_trans", "valu_int64")}
     return res
 
 
@@ -339,7 +333,7 @@ def main():
 
     ref_events = []
 
-    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats, pieces=args.pieces, stats_pieces=args.stats_pieces):
+    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats):
         ref_ms = ref_ev = None
         if "colormatch" in stages:
             if ops._cm_stats(cm_stats, cm_math, dev) == "device":
@@ -366,7 +360,7 @@ def main():
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
                              cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
-        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws, overlap_pieces=pieces, stats_pieces=stats_pieces)
+        ops.fused_chain(x, spec, plans=plans, out=out, kernel_events=kernel_events, lab_workspace=lab_ws)
 
     def barrier():
         if dist.is_initialized():
@@ -432,30 +426,11 @@ def main():
         passes.setdefault(name, []).append(a.elapsed_ms(b))
     pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (pieces of a step added up)
     launches_per_step = {k: len(v) // max(args.steps, 1) for k, v in passes.items()}
-    # When the passes of a step overlap (pipelined pieces on two streams), a launch's duration includes the time it shares the CUs with
-    # the other pass: the same kernels are timed once more one after the other (outside the timed region) for their exclusive durations
-    n_pieces_used = max(launches_per_step.values()) if launches_per_step else 1
-    exclusive_ms = None
-    if "colormatch" in stages and n_pieces_used > 1:
-        step(pieces=1, stats_pieces=1)
-        barrier()
-        ex_events = []
-        for _ in range(2):
-            step(ex_events, pieces=1, stats_pieces=1)
-        barrier()
-        acc = {}
-        for name, a, b, nf in ex_events:
-            acc.setdefault(name, []).append(a.elapsed_ms(b))
-        exclusive_ms = {k: round(sum(v) / 2, 4) for k, v in acc.items()}
-    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12, "stage": 36}         # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px); the
-                                                                             # stage launches of a step together ARE the chain: 36 B/px
+    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}         # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
     kern_names = {"stats": ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it "
                             "by k_tstats_frame)" if "grain" in stages else
                             "k_lab_partials, Lab-only form (rgb->Lab pass 1, stores the Lab image; the statistics are reduced from it by k_tstats_frame)"),
                   "tstats": "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)",
-                  "stage": "k_stage (one launch per pipeline stage over 32-frame ranges; its workgroups run pass 1 = grain->LUT->Lab of range s, the torch-order "
-                           "statistics of range s-1 and pass 2 = match->Lab->RGB->unsharp of range s-2: the device code of k_produce_lab, k_tstats_rows and "
-                           "k_apply_march as roles of one grid)",
                   "apply": "k_apply_march<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, register-resident wave march)" if "colormatch" in stages
                   else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
                         else "k_chain_tile / k_chain_pointwise (fused apply pass)")}
@@ -508,7 +483,7 @@ def main():
         rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
         peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
         # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
-        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20", ("chain4_4k", "stage"): "k_stage",
+        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
                 ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
         ipp = live_ipp if live_ipp else next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
         src = ("a rocprofv3 --pmc SQ_INSTS_VALU pass on this box right after the timed region (own process, 16x4K frames)" if live_ipp
@@ -554,7 +529,6 @@ def main():
                                    f"(BASELINE configs[4] per-GPU shard)" if args.workload == "chain4_4k"
                        else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
-                       "pipelined_pieces_per_step": n_pieces_used,
                        "algorithmic_bytes_per_pixel_chain": bytes_per_px_chain,
                        "cm_math": "device" if "colormatch" in stages else None,
                        "cm_stats": ((f"device (torch-ROCm's reductions bit for bit, batch_size {CM_BATCH})" if (args.cm_stats or "device") == "device"
@@ -574,12 +548,6 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": launches_per_step,
-                         "exclusive_passes_ms": exclusive_ms,
-                         "overlap_note": (None if exclusive_ms is None else
-                                          f"the step runs as {n_pieces_used} stage launches (`stage`: pass 1 / statistics / pass 2 of three consecutive frame ranges as "
-                                          "workgroup roles of one grid, csrc/vrg_stage.hip); `exclusive_passes_ms` = the same device code as three kernels one after "
-                                          "the other over the whole batch (ops.fused_chain(..., overlap_pieces=1))"
-                                          if "stage" in pass_ms else "see ops.fused_chain: pieces"),
                          "issue": issue},
         }
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":

@@ -19,7 +19,7 @@ STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
 ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NoiseDesc(C.Structure):
@@ -55,15 +55,6 @@ class AdjustDesc(C.Structure):
                 ("div_mode", C.c_int32)]
 
 
-class StageDesc(C.Structure):
-    """vrg_stage_desc"""
-    _fields_ = [("height", C.c_int32), ("width", C.c_int32),
-                ("p1_in", C.c_void_p), ("p1_lab", C.c_void_p), ("p1_frames", C.c_int64), ("p1_desc", C.POINTER(ChainDesc)),
-                ("stats_lab", C.c_void_p), ("stats_frames", C.c_int64), ("stats_chunk_frames", C.c_int32), ("stats_eps", C.c_float),
-                ("stats_mean_std", C.c_void_p), ("stats_scratch", C.c_void_p), ("stats_scratch_bytes", C.c_int64),
-                ("p2_lab", C.c_void_p), ("p2_out", C.c_void_p), ("p2_frames", C.c_int64), ("p2_desc", C.POINTER(ChainDesc))]
-
-
 _F3 = C.c_float * 3
 _P = C.c_void_p
 _SIGNATURES = {
@@ -74,16 +65,6 @@ _SIGNATURES = {
     "vrg_event_record": (C.c_int, [_P, _P]),
     "vrg_event_elapsed_ms": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "vrg_event_destroy": (C.c_int, [_P]),
-    "vrg_selftest_divconst": (C.c_int, [_P, _P]),
-    "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
-    "vrg_selftest_lanes": (C.c_int, [_P, _P]),
-    "vrg_selftest_welford_division": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
-    "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
-    "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
-    "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
-    "vrg_debug_copy_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
-    "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
     "vrg_sharpen_grain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(NoiseDesc), _P]),
     "vrg_sharpen_grain_u8": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
@@ -117,12 +98,25 @@ _SIGNATURES = {
     "vrg_fused_chain_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P]),
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
     "vrg_chain_stats_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc)]),
-    "vrg_chain_stage_scratch_bytes": (C.c_int64, [C.c_int64]),
-    "vrg_chain_stage_f32": (C.c_int, [C.POINTER(StageDesc), _P]),
     "vrg_chain_stats_lab_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
 }
 
+# include/vrgdg_hip_debug.h: self-tests and probes -- for the test suite and the measurement tools, not part of the drop-in boundary
+_DEBUG_SIGNATURES = {
+    "vrg_selftest_divconst": (C.c_int, [_P, _P]),
+    "vrg_selftest_bm_radius": (C.c_int, [_P, _P]),
+    "vrg_selftest_lanes": (C.c_int, [_P, _P]),
+    "vrg_selftest_welford_division": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "vrg_debug_cm_math": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P]),
+    "vrg_debug_torch_reduce_config": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
+    "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
+    "vrg_debug_copy_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
+    "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
+}
+
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+DEBUG_SYMBOLS = tuple(sorted(_DEBUG_SIGNATURES))
 
 _lib = None
 _lock = threading.Lock()
@@ -136,7 +130,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
             f"libvrgdg_hip.so not found at {path}: build it with `python {os.path.join(PKG_DIR, 'build_ext.py')}` "
             "(hipcc, gfx950). This package has no CPU fallback.")
     lib = C.CDLL(path)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)   # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args

@@ -20,8 +20,8 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
 STAMP = LIB_PATH + ".stamp"
 
-SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_stage.hip", "vrg_adjust.hip",
-           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip")
+SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_adjust.hip",
+           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip", "vrg_probe.hip")
 HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
            "vrg_ziv_log_table.inc", "vrg_produce_body.hpp", "vrg_apply_body.hpp", "vrg_tstats_body.hpp")
 
@@ -41,7 +41,7 @@ HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 # "max-ilp" machine scheduler for the grain -> LUT -> sharpen march and the stand-alone stencils (chain 3 -3.4 %, sobel -6 %,
 # profiles/r03_sched_strategy_ab.log; the colour-match passes and the grain kernels are 1-5 % slower with it and keep the default)
 _MAX_ILP = ("-mllvm", "-amdgpu-sched-strategy=max-ilp")
-EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",), "vrg_stage.hip": ("-fno-slp-vectorize",),
+EXTRA_FLAGS = {"vrg_chain.hip": ("-fno-slp-vectorize",), "vrg_produce.hip": ("-fno-slp-vectorize",), "vrg_apply_march.hip": ("-fno-slp-vectorize",),
                "vrg_march.hip": _MAX_ILP, "vrg_stencil.hip": _MAX_ILP,
                "vrg_pointwise.hip": ("-fno-slp-vectorize",)}       # grain / fused sharpen -> grain -1..-3 % (profiles/r03_sched_strategy_ab.log)
 
@@ -58,8 +58,9 @@ def _digest() -> str:
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
-    with open(os.path.join(INCLUDE, "vrgdg_hip.h"), "rb") as fh:
-        h.update(fh.read())
+    for name in ("vrgdg_hip.h", "vrgdg_hip_debug.h"):
+        with open(os.path.join(INCLUDE, name), "rb") as fh:
+            h.update(fh.read())
     h.update(" ".join(HIPCC_FLAGS).encode())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
@@ -70,8 +71,9 @@ def _object_digest(name: str) -> str:
     for dep in (name,) + HEADERS:
         with open(os.path.join(CSRC, dep), "rb") as fh:
             h.update(fh.read())
-    with open(os.path.join(INCLUDE, "vrgdg_hip.h"), "rb") as fh:
-        h.update(fh.read())
+    for hname in ("vrgdg_hip.h", "vrgdg_hip_debug.h"):
+        with open(os.path.join(INCLUDE, hname), "rb") as fh:
+            h.update(fh.read())
     h.update(" ".join(HIPCC_FLAGS + EXTRA_FLAGS.get(name, ())).encode())
     return h.hexdigest()
 

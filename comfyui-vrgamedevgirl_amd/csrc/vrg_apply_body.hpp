@@ -1,5 +1,5 @@
 // vrg_apply_body.hpp -- the workgroup body of the apply march (see vrg_apply_march.hip for the design), as a device function shared by
-// k_apply_march and the fused stage kernel (vrg_stage.hip).
+// k_apply_march (round 3's fused stage kernel, tools/experiments/vrg_stage.hip.txt, ran it as a workgroup role).
 #pragma once
 #include "vrg_chain_stages.hpp"
 
@@ -21,7 +21,7 @@ __device__ __forceinline__ float am_next(float v) {   // value held by lane+1 (l
 
 struct AmRow { float l[3], c[3], r[3]; };               // one processed row: left tap, own value, right tap per channel
 
-// The workgroup body of k_apply_march, callable from other kernels (the fused stage kernel, vrg_stage.hip): `vblock` / `vgrid` = the
+// The workgroup body of k_apply_march, callable from other kernels: `vblock` / `vgrid` = the
 // workgroup's index in / the size of the apply grid, `PT` = the colour-match arithmetic object (tables staged in LDS by the caller).
 // GENERAL = false (frames of at least APPLY_COLS x APPLY_ROWS pixels and less than 2 GiB): the loop has NO conditional block -- the
 // two halo lanes of a wave "store" through a buffer descriptor at an offset past the frame, which the hardware drops -- so the
@@ -36,7 +36,7 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
                                                  int32_t strips_x, int32_t segs_y, uint32_t total_waves, const ChainK& D, const MATH& PT) {
     // XCD-aware placement as in k_chain_tile: workgroup b runs on XCD b % 8; give every XCD one contiguous run of work
     // (a launch with fewer workgroups than wave groups walks them with a stride of vgrid / 8 per XCD: the persistent form, used
-    // by an experiment that ran pass 2 beside pass 1 -- slower, ops.default_stats_pieces -- and kept because it costs nothing)
+    // by an experiment that ran pass 2 beside pass 1 -- slower, LABNOTES.md -- and kept because it costs nothing)
     const uint32_t groups = (total_waves + 3u) / 4u;
     const uint32_t per_xcd = (groups + 7u) / 8u;
     const int lane = threadIdx.x & 63;

@@ -392,7 +392,7 @@ static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, in
     return VRG_OK;
 }
 
-int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) {      // (also used by vrg_stage.hip)
+int fill_chain(const vrg_chain_desc* d, int32_t H, int32_t W, ChainK& D) {
     D = ChainK{};
     D.stages = d->stages;
     D.dm = host_dev_math();

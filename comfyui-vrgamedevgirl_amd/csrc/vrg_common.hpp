@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/vrgdg_hip.h"
+#include "../../include/vrgdg_hip_debug.h"
 #include "vrg_pixel_math.hpp"
 
 namespace vrg {

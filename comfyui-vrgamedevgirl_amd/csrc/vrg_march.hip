@@ -21,6 +21,28 @@
 // Without a grain stage the same kernel runs with a synthetic G = 48 rows (siblings = four row bands).
 #include "vrg_chain_stages.hpp"
 
+#ifndef VRG_MARCH_FAST
+#define VRG_MARCH_FAST 1      /* 0: every row takes the general step (round 3's kernel) */
+#endif
+#ifndef VRG_MARCH_MIN_WAVES
+#define VRG_MARCH_MIN_WAVES 3   /* waves per SIMD the register allocation must leave room for (launch bound) */
+#endif
+#ifndef VRG_MARCH_FINITE
+#define VRG_MARCH_FINITE 1    /* behind a LUT stage the rows are finite values in [0, 1]: the mean's Inf / NaN pass-through and the final clamp's NaN pass-through of the steady rows are dropped (same bits for finite data) */
+#endif
+#ifndef VRG_MARCH_ABLATE
+#define VRG_MARCH_ABLATE 0    /* TIMING ABLATIONS of the steady rows (wrong pixels; tools/build_variant.py): 1 = no table reads (same arithmetic on register values), 2 = no noise synthesis */
+#endif
+#ifndef VRG_MARCH_QUAD
+#define VRG_MARCH_QUAD 1      /* steady rows: the LUT gathers as quad-cooperative LDS-DMA (see lut_issue_dma) instead of six 16-byte loads per lane */
+#endif
+#ifndef VRG_MARCH_ENDIO
+#define VRG_MARCH_ENDIO 1     /* steady rows: the next row's pixel loads and the four stores are issued at the END of the row step, so that between the gathers' issue and their use no other memory operation sits in the (in-order) memory counter */
+#endif
+#ifndef VRG_MARCH_ROTATE
+#define VRG_MARCH_ROTATE 0    /* the NEXT row's noise is synthesised in three pieces between the gathers' issue and their use */
+#endif
+
 namespace vrg {
 
 struct MarchK {
@@ -44,6 +66,26 @@ __device__ __forceinline__ float lane_next(float v) {   // value held by lane+1
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 }
 
+// the same shifts for operands of an add (steady rows): no `old` value and bound_ctrl, so that the backend can fold the shift into
+// the add's first operand (v_add_f32_dpp) -- the lane at the wave's end reads 0.0, and it is a halo lane whose result is dropped
+#ifndef VRG_MARCH_TAPS_UNFOLD
+#define VRG_MARCH_TAPS_UNFOLD 0
+#endif
+__device__ __forceinline__ float tap_prev(float v) {
+#if VRG_MARCH_TAPS_UNFOLD
+    return lane_prev(v);
+#else
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+#endif
+}
+__device__ __forceinline__ float tap_next(float v) {
+#if VRG_MARCH_TAPS_UNFOLD
+    return lane_next(v);
+#else
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+#endif
+}
+
 __device__ __forceinline__ int64_t floor_div64(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 __device__ __forceinline__ int floor_div32(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
@@ -58,7 +100,7 @@ __global__ void k_selftest_lanes(float* out) {
 // stages the cube's node table in LDS (dynamic shared memory, one float4 per node) and the gathers of the LUT stage
 // become ds_read_b128 -- the L1 / L2 gather path that holds the global-table form at ~65 Gpix/s is not used at all.
 template <int STAGES, bool SHARPEN, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MARCH_MIN_WAVES : 1) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
     static_assert(!(STAGES & VRG_STAGE_COLORMATCH), "colour-match chains run on the tile / point-wise kernels");
     extern __shared__ __attribute__((aligned(16))) float march_lut_nodes[];
     const f32x4* lut_nodes = nullptr;
@@ -67,6 +109,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
         lut_nodes = reinterpret_cast<const f32x4*>(march_lut_nodes);
     }
     if (WAVES != 4) __syncthreads();
+    // LDS landing zone of the quad-cooperative gathers (steady rows, VRG_MARCH_QUAD): per wave two slots of six 1040-byte rounds
+    constexpr bool QUADP = (VRG_MARCH_QUAD != 0) && (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
+    constexpr int Q_ROUND = 1040, Q_SLOT = 6 * Q_ROUND;
+    __shared__ __attribute__((aligned(16))) char quad_slots[QUADP ? 4 * 2 * Q_SLOT : 16];
 
     constexpr int CLO = SHARPEN ? 1 : 0;     // first lane that produces output
     constexpr int CW = SHARPEN ? 61 : 63;    // output lanes per wave (lane 63 only provides noise)
@@ -139,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
         xin[m] = *reinterpret_cast<const px3*>(cin + li);
     }
 
-    for (int rho = r_first; rho <= r_last; ++rho, rowbase += E) {
+    auto general_row = [&](const int rho, const int rowbase) {
         px3 xnext[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -279,6 +325,297 @@ __global__ __launch_bounds__(64 * WAVES) void k_chain_march(const float* __restr
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (++yc[m] == H) { yc[m] = 0; ++fc[m]; }
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------------
+    // Round 4: the STEADY rows of a job -- every lane of all four siblings a whole pixel of the chunk, the row inside the job's
+    // Philox quarter (three calls per lane feed all twelve elements), the 3x3 windows of the output row inside one frame and one
+    // image row per sibling -- run a straight-line body with no validity / border / split-store decisions at all (the general
+    // row step above spends ~110 of its ~418 VALU instructions per pixel on them, and its wave-uniform branches cut the row into
+    // ~40 basic blocks that nothing can be scheduled across).  Which rows are steady is decided with scalar arithmetic only:
+    //   * per job (loop invariant): s = {0, 1, 2, 0} (G mod 3 == 2: every full-grid randn call of a 256-CU device), no sibling
+    //     strip wraps around a row end (its 64 columns are one image row: then y is wave-uniform per sibling and no output lane
+    //     sits on the left / right border), unsharp with a finite strength, a unit-domain LUT without strength blend, a chunk
+    //     below 2^29 elements (32-bit byte offsets; buffer descriptors);
+    //   * per row: b0 - E >= 0 and b0 + 193 < G (noise and output ownership), row and its neighbours inside the chunk, the
+    //     computed row's y in [2, H-1] for every sibling (output row in [1, H-2]).
+    // Pixel loads / stores go through buffer descriptors of the chunk: per-lane byte offsets are loop invariant (VGPRs), the row
+    // offset is an SGPR, lanes that produce no output store at an out-of-range offset (dropped by the range check): no address
+    // arithmetic and no exec-masked block in the loop, exact memory counters.  Same device functions (philox_for, box_muller,
+    // grain_pixel, lut_axis, lut_fetch_finish, unsharp arithmetic) in the same order: bit-identical to the general step.
+    // ------------------------------------------------------------------------------------------------------------------------
+    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) && WAVES == 4;
+    bool fast_wave = false;
+    if (FASTP) {
+        bool ok = M.s[0] == 0 && M.s[1] == 1 && M.s[2] == 2 && M.s[3] == 0 && M.numel < (1 << 29) && D.stencil_op == 0 &&
+                  __builtin_isfinite(D.strength) && r_last - r_first >= 4;
+        if (STAGES & VRG_STAGE_LUT) ok = ok && D.lut.unit_domain != 0 && D.lut.blend_mode == 1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int xlo = __builtin_amdgcn_readfirstlane(xm[m]);
+            ok = ok && __builtin_amdgcn_ballot_w64(xm[m] != xlo + lane) == 0;
+        }
+        fast_wave = ok;
+    }
+    int rho = r_first;
+    while (rho <= r_last) {
+        bool steady = false;
+        int ysc[4] = {0, 0, 0, 0};
+        if (FASTP && fast_wave) {
+            const int b0 = rowbase - q0s;
+            steady = rho >= r_first + 2 && b0 - E >= 0 && (uint32_t)(b0 + 3 * 63 + 4) < G && rowbase - E >= 0 &&
+                     (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
+                     (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
+            if (steady) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ysc[m] = __builtin_amdgcn_readfirstlane(yc[m]);
+                    steady = steady && ysc[m] >= 2;                                 // (yc <= H - 1 always)
+                }
+            }
+        }
+        if (!steady) {
+            general_row(rho, rowbase);
+            ++rho;
+            rowbase += E;
+            continue;
+        }
+        if (FASTP) {
+            typedef unsigned u3 __attribute__((ext_vector_type(3)));
+            const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cin), 0, M.numel * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(cout, 0, M.numel * 4, 0x00020000);
+            int ld_voff[4], st_voff[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ld_voff[m] = offm[m] * 4;
+                st_voff[m] = lane_out ? offm[m] * 4 : (int)0x80000000u;
+            }
+            const LutParams& P = D.lut;
+            const int nc = P.n - 1;
+            // the wave's landing slots: LDS byte address (for M0) and this lane's two read positions
+            const int wv_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            char* const quad_my = quad_slots + (QUADP ? wv_in_wg * 2 * Q_SLOT : 0);
+            const unsigned quad_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) char*)quad_my);
+            const char* const quad_a0 = quad_my + (lane & 3) * Q_ROUND + (lane & ~3) * 16;
+            const char* const quad_a1 = quad_my + (4 + ((lane & 3) >> 1)) * Q_ROUND + ((lane & ~3) + 2 * (lane & 1)) * 16;
+            int rows_done = 0;
+            bool more = true;
+            constexpr bool FINITE = VRG_MARCH_FINITE && (STAGES & VRG_STAGE_LUT);       // the stencil's inputs are LUT outputs: finite, in [0, 1]
+            // one Philox call + its two Box-Muller pairs: the normals of elements idx0 + j of the four siblings
+            auto noise_call = [&](uint32_t idx0, int j, float nzj[4]) {
+                if (VRG_MARCH_ABLATE & 2) {
+                    nzj[0] = xin[0].r + (float)j; nzj[1] = xin[1].g; nzj[2] = xin[2].b; nzj[3] = xin[3].r + (float)idx0;
+                    return;
+                }
+                const u32x4 r = philox_for(seed, idx0 + (uint32_t)j, ctr);
+                const f32x2 a = box_muller(r.x, r.y);
+                const f32x2 b = box_muller(r.z, r.w);
+                nzj[0] = a.x; nzj[1] = a.y; nzj[2] = b.x; nzj[3] = b.y;
+            };
+            float nz[3][4];
+            if (VRG_MARCH_ROTATE) {
+                const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
+            }
+            while (more) {
+                // ---- the next row's pixels (row offset in an SGPR)
+                u3 xraw[4];
+                if (!VRG_MARCH_ENDIO) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 0);
+                }
+                // ---- noise: three Philox calls per lane, twelve normals
+                if (!VRG_MARCH_ROTATE) {
+                    const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
+                }
+                const float nrm[4][3] = {{nz[0][0], nz[1][0], nz[2][0]},
+                                         {nz[1][1], nz[2][1], lane_next(nz[0][1])},
+                                         {nz[2][2], lane_next(nz[0][2]), lane_next(nz[1][2])},
+                                         {nz[0][3], nz[1][3], nz[2][3]}};
+                // ---- grain, LUT axes + gathers
+                float V[4][3];
+                LutFetch F[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float x[3] = {xin[m].r, xin[m].g, xin[m].b};
+                    grain_pixel(x, nrm[m], D.I, D.S, D.T, V[m]);
+                }
+                const int out_soff = (rowbase - E) * 4;
+                // Quad-cooperative LDS-DMA gather (VRG_MARCH_QUAD): a pixel's 96-byte record run is fetched by the FOUR lanes of its quad --
+                // round p = 0..3: the quad's lanes read the first 64 bytes of the run of the quad's pixel p (one 64-byte segment per quad
+                // and instruction: the texture unit looks up ONE tag for the four lanes where the per-lane form looks up four), rounds 4 / 5
+                // the last 32 bytes of two pixels each -- and the LDS-DMA lays each round out lane-linear (lane * 16 bytes), so pixel 4q+j
+                // finds its pieces 0..3 at [round j][lane 4q + c] and its pieces 4, 5 at [round 4 + j/2][lane 4q + 2 (j & 1) + c]: the
+                // transposition costs no VALU and no VGPR, and 2.9 instead of 6.4 L1 accesses per pixel (profiles/r04_probe_gather_pmc.json).
+                // The DMA instructions are inline assembly (the compiler neither counts them nor knows they write the LDS): issue and wait
+                // statements carry a memory clobber, the waits are counted by hand -- between the issue of a sibling's six rounds and their
+                // use only the next sibling's six rounds are issued (VRG_MARCH_ENDIO moves the row's other memory operations to its end).
+                auto lut_issue_dma = [&](int m) {
+                    F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                    F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                    F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (LUT_REC_FLOATS * 4);
+                    const int ql16 = (lane & 3) * 16, qh16 = 64 + (lane & 1) * 16;
+                    const int v0 = __builtin_amdgcn_update_dpp(0, cell, 0x00, 0xf, 0xf, false) + ql16;   // quad_perm [0,0,0,0]
+                    const int v1 = __builtin_amdgcn_update_dpp(0, cell, 0x55, 0xf, 0xf, false) + ql16;   // [1,1,1,1]
+                    const int v2 = __builtin_amdgcn_update_dpp(0, cell, 0xAA, 0xf, 0xf, false) + ql16;   // [2,2,2,2]
+                    const int v3 = __builtin_amdgcn_update_dpp(0, cell, 0xFF, 0xf, 0xf, false) + ql16;   // [3,3,3,3]
+                    const int v4 = __builtin_amdgcn_update_dpp(0, cell, 0x50, 0xf, 0xf, false) + qh16;   // [0,0,1,1]
+                    const int v5 = __builtin_amdgcn_update_dpp(0, cell, 0xFA, 0xf, 0xf, false) + qh16;   // [2,2,3,3]
+                    const unsigned l0 = quad_lds + (unsigned)((m & 1) * Q_SLOT);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\t"
+                                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+                                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %7\n\t"
+                                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
+                                 "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %7\n\t"
+                                 "s_mov_b32 m0, %12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %7\n\t"
+                                 "s_mov_b32 m0, %13\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %7\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "s"(P.cells), "s"(l0), "s"(l0 + Q_ROUND), "s"(l0 + 2 * Q_ROUND),
+                                   "s"(l0 + 3 * Q_ROUND), "s"(l0 + 4 * Q_ROUND), "s"(l0 + 5 * Q_ROUND)
+                                 : "memory");
+                };
+                auto lut_read_dma = [&](int m) {          // the pixel's six pieces out of its slot (after the hand-counted wait)
+                    const char* s0 = quad_a0 + (m & 1) * Q_SLOT;
+                    const char* s1 = quad_a1 + (m & 1) * Q_SLOT;
+                    F[m & 1].lo[0] = *reinterpret_cast<const f32x4*>(s0);
+                    F[m & 1].lo[1] = *reinterpret_cast<const f32x4*>(s0 + 16);
+                    F[m & 1].lo[2] = *reinterpret_cast<const f32x4*>(s0 + 32);
+                    F[m & 1].hi[0] = *reinterpret_cast<const f32x4*>(s0 + 48);
+                    F[m & 1].hi[1] = *reinterpret_cast<const f32x4*>(s1);
+                    F[m & 1].hi[2] = *reinterpret_cast<const f32x4*>(s1 + 16);
+                };
+                auto lut_issue = [&](int m) {
+                    if (VRG_MARCH_ABLATE & 1) {
+                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            F[m & 1].lo[ch] = f32x4{V[m][0], V[m][1], V[m][2], V[m][ch]};
+                            F[m & 1].hi[ch] = f32x4{V[m][2], V[m][1], V[m][0], V[m][ch]};
+                        }
+                        return;
+                    }
+                    if (QUADP) { lut_issue_dma(m); return; }
+                    if (STAGES & VRG_STAGE_LUT) {
+                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                        const uint32_t cell = (uint32_t)((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (uint32_t)(LUT_REC_FLOATS * 4);
+                        const f32x4* q = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.cells) + cell);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            F[m & 1].lo[ch] = q[ch];
+                            F[m & 1].hi[ch] = q[3 + ch];
+                        }
+                    }
+                };
+                u3 resq[4];
+                auto finish_emit = [&](int m) {
+                    float Dn[3] = {V[m][0], V[m][1], V[m][2]};
+                    if (STAGES & VRG_STAGE_LUT) lut_fetch_finish(F[m & 1], Dn);
+                    float res[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // unsharp_value's raster-order sum with the left / right taps taken from the neighbouring lanes
+                        float sum = tap_prev(U[m][c]) + U[m][c];
+                        sum = tap_next(U[m][c]) + sum;
+                        sum = tap_prev(Mi[m][c]) + sum;
+                        sum = sum + Mi[m][c];
+                        sum = tap_next(Mi[m][c]) + sum;
+                        sum = tap_prev(Dn[c]) + sum;
+                        sum = sum + Dn[c];
+                        sum = tap_next(Dn[c]) + sum;
+                        const float blur = FINITE ? VRG_DIVC(sum, 9.0f) : div9(sum);
+                        const float xc = Mi[m][c];
+                        const float dd = xc - blur;
+                        const float ee = D.strength * dd;
+                        res[c] = FINITE ? clamp01_finite(xc + ee) : clamp01(xc + ee);
+                        U[m][c] = Mi[m][c];
+                        Mi[m][c] = Dn[c];
+                    }
+                    if (!VRG_MARCH_ENDIO) {
+                        __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])}, rs_out,
+                                                              st_voff[m], out_soff, 0);
+                        asm volatile("s_nop 1" ::: "memory");        // see the note at the row-end stores
+                    } else
+                        resq[m] = u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])};
+                };
+                // the gathers of sibling m + 1 are in flight while sibling m is interpolated, sharpened and stored; with ROTATE a third of
+                // the next row's noise synthesis (independent of everything here) sits between each issue and the first use of its data
+                const uint32_t idx0n = (uint32_t)(rowbase + E - q0s) + 3u * (uint32_t)lane;
+                float nzn[3][4];
+                static_assert(!QUADP || VRG_MARCH_ENDIO, "the hand-counted waits of the quad form assume that the row's other memory operations sit at its end");
+                lut_issue(0);
+                lut_issue(1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 0, nzn[0]); __builtin_amdgcn_sched_barrier(0); }
+                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(0); }
+                finish_emit(0);
+                __builtin_amdgcn_sched_barrier(0);
+                lut_issue(2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 1, nzn[1]); __builtin_amdgcn_sched_barrier(0); }
+                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(1); }
+                finish_emit(1);
+                __builtin_amdgcn_sched_barrier(0);
+                lut_issue(3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 2, nzn[2]); __builtin_amdgcn_sched_barrier(0); }
+                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(2); }
+                finish_emit(2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lut_read_dma(3); }
+                finish_emit(3);
+                if (VRG_MARCH_ENDIO) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b96(resq[m], rs_out, st_voff[m], out_soff, 0);
+                    // a 96-bit store reads its data registers over several cycles; the backend pads the next VALU write of those
+                    // registers only for stores WITHOUT an SGPR offset (GCNHazardRecognizer::createsVALUHazard) -- with one, as here, the
+                    // R channel of the upper lanes of a 16-lane row came out as the NEXT row's value in builds whose schedule put a VALU
+                    // write right behind the store (profiles/r04_noslp_dpp_fold_diff.log): pad by hand
+                    asm volatile("s_nop 1" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (VRG_MARCH_ROTATE) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) nz[j][i] = nzn[j][i];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) xin[m] = px3{__uint_as_float(xraw[m].x), __uint_as_float(xraw[m].y), __uint_as_float(xraw[m].z)};
+                // ---- advance; is the next row steady as well?
+                ++rows_done;
+                ++rho;
+                rowbase += E;
+                const int b0n = rowbase - q0s;
+                more = rho <= r_last && (uint32_t)(b0n + 3 * 63 + 4) < G &&
+                       (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
+                       (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ++ysc[m];
+                    more = more && ysc[m] <= H - 1;
+                }
+            }
+            // per-lane row coordinates for the general steps that follow
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                yM[m] = yc[m] + rows_done - 1;
+                yc[m] += rows_done;
+                if (yc[m] >= H) { yc[m] -= H; ++fc[m]; }
+            }
         }
     }
 }

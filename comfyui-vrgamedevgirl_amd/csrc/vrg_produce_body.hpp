@@ -1,5 +1,5 @@
 // vrg_produce_body.hpp -- the workgroup body of colour-match pass 1 for chains that start with grain (see vrg_produce.hip for the
-// design), as a device function shared by k_produce_lab and the fused stage kernel (vrg_stage.hip).
+// design), as a device function (kept separate from the launcher so that other kernels can run it as a workgroup role).
 #pragma once
 #include "vrg_chain_stages.hpp"
 
@@ -53,7 +53,7 @@ inline void produce_geometry(const ChainK& D, int64_t frames, int64_t fe, Produc
     P.chunks = (uint32_t)(frames / D.noise.chunk_frames);
 }
 
-// The workgroup body of k_produce_lab, callable from other kernels (the fused stage kernel, vrg_stage.hip): `bx` = the workgroup's
+// The workgroup body of k_produce_lab, callable from other kernels: `bx` = the workgroup's
 // index in the produce grid, `sn` / `red` = its LDS (4 x (PR_SUB + 4) floats of staged normals; STATS: 4 x 12 doubles), `PT` = the
 // colour-match arithmetic object (its tables already staged in LDS by the caller, all threads synchronised).
 template <int STAGES, bool TWO_PART, bool STATS, class MATH>

@@ -168,6 +168,191 @@ __global__ void __launch_bounds__(64) k_tstats_rows_finish(const TsRows* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4 -- small batches (<= TS_ROWS_MAX_FRAMES frames, a scratch buffer): ONE ACCUMULATOR PER LANE.
+// torch's reduction of a plane is 512 threads x 2 Welford accumulators (+ 512 x 4 mean accumulators), each a strictly sequential
+// chain over n / 1024 (n / 2048) elements; nothing about the ORDER says that the two accumulators of a thread have to live in the
+// same lane, or the three channels in the same workgroup.  The half-block form above keeps torch's thread = our lane: 8 workgroups
+// of 4 waves per frame, every wave issuing ~80 instructions per round for its two accumulators (IEEE reciprocal of the count,
+// two updates, range flags) at the single-wave issue rate -- 1.39 ms per 4K frame, while 97 % of the chip idles -- and every one
+// of the 8 workgroups streams the WHOLE frame through its CU's L1 (99.5 MB at ~140 GB/s per CU = 0.7 ms: the floor of that form).
+// Here a workgroup owns 64 of torch's 512 threads and runs them as SEVEN waves: wave (c, a), c = 0..2, a = 0..1, carries Welford
+// accumulator a of channel c of those 64 threads -- one update per step and lane, ~14 instructions --, the seventh wave their
+// mean accumulators.  The six Welford waves walk the same 1.5 KB of the interleaved image per step (each uses 4 of every 24 bytes,
+// together all of them), so the CU's L1 fetches every line once and the workgroup streams 1/8 of the frame.  The reciprocal of the
+// running count -- the same number for every lane, known before any data -- comes from an LDS table {(float)k, RN(1 / k)} filled once
+// per workgroup with the IEEE division (k <= TS_LANES_MAX_STEPS).  Per-thread accumulators go to a scratch record; the finishing
+// kernel (512 threads per frame = torch's block) combines accumulators 0 and 1 of each thread and runs block_x_reduce /
+// block_y_reduce / project exactly as ts_frame_part does.  Same update arithmetic (ts_welf_update, Markstein division behind the
+// range flag, IEEE repeat of the workgroup when the flag is raised), same order: bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TsLaneRec { float mean, m2; int cnt; int pad; };
+struct TsLanes { TsLaneRec w[3][2][512]; float m[3][512]; };
+constexpr int TS_LANES_MAX_STEPS = 16384;            // table entries (LDS: 8 bytes each) -- frames up to 16.7 M pixels
+
+#ifndef VRG_TS_LANES_DEPTH
+#define VRG_TS_LANES_DEPTH 32     /* Welford steps (one 4-byte load per lane each) requested ahead: the chain is short now, the loop is bound by HBM latency / depth */
+#endif
+#ifndef VRG_TS_LANES_MEAN_DEPTH
+#define VRG_TS_LANES_MEAN_DEPTH 12   /* mean rounds (48 bytes per lane each) requested ahead */
+#endif
+
+template <bool FUSED, bool FAST, int DEPTH>
+static __device__ __forceinline__ bool ts_lane_chain(const float* __restrict__ ub, uint32_t lane_bytes, int steps, bool extra, const float2* __restrict__ tab,
+                                                     Welf& acc, int& cnt) {
+    // ub (wave-uniform): element of step 0 of thread 0 of this accumulator; lane_bytes: this lane's byte offset from it (loop invariant);
+    // a step advances 1024 pixels = 12288 bytes (scalar arithmetic).  `steps` whole steps for every lane, then one more for the lanes
+    // with `extra`.  Requests are branch-free and DEPTH steps ahead: a step index past the end is clamped to the last one (scalar min).
+    bool bad = false;
+    acc = WelfOp::ident();
+    float xb[DEPTH];
+    const int last = steps > 0 ? steps - 1 : 0;
+    auto load = [&](int k) {
+        const int kk = k < last ? k : last;                            // scalar
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ub + (size_t)kk * 3072) + lane_bytes);
+    };
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) xb[i] = load(i);
+    int k0 = 0;
+    for (; k0 + DEPTH <= steps; k0 += DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            const float2 t = tab[k0 + i];                             // {(float)(k + 1), RN(1 / (k + 1))}: uniform address, one LDS broadcast
+            ts_welf_update<FUSED, FAST>(acc, xb[i], t.x, t.y, bad);
+            xb[i] = load(k0 + i + DEPTH);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (k0 + i < steps) {
+            const float2 t = tab[k0 + i];
+            ts_welf_update<FUSED, FAST>(acc, xb[i], t.x, t.y, bad);
+        }
+    cnt = steps;
+    if (extra) {
+        const float2 t = tab[steps];
+        const float x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ub + (size_t)steps * 3072) + lane_bytes);
+        ts_welf_update<FUSED, FAST>(acc, x, t.x, t.y, bad);
+        cnt = steps + 1;
+    }
+    return bad;
+}
+
+template <int DEPTH>
+__global__ void __launch_bounds__(448) k_tstats_lanes(const float* __restrict__ lab, int64_t n, int64_t frames, TsLanes* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) float2 ts_rn_tab[];          // [steps + 1]
+    // workgroup w -> XCD w % 8: frame f = (w % 8) + 8 * (w / 64), thread group j = (w / 8) % 8: a frame's eight workgroups share an L2
+    const int64_t w = blockIdx.x;
+    const int64_t f = (w & 7) + 8 * (w >> 6);
+    const int j = (int)((w >> 3) & 7);
+    if (f >= frames) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int t = 64 * j + lane;                                                 // torch's thread index
+    const int64_t nvw = n / 2, nvm = n / 4;
+    const int64_t wsteps = nvw / 512;                                            // Welford steps every thread takes
+    const bool wextra = (int64_t)t < nvw - wsteps * 512;
+    for (int64_t i = threadIdx.x; i <= wsteps; i += 448) {
+        const float nf = (float)(i + 1);
+        ts_rn_tab[i] = float2{nf, 1.0f / nf};                                    // IEEE, correctly rounded (hipcc's default division)
+    }
+    __syncthreads();
+    const float* base = lab + (size_t)f * (size_t)n * 3;
+    TsLanes* R = recs + f;
+    bool bad = false;
+    Welf acc = WelfOp::ident();
+    int cnt = 0;
+    const bool fast = VRG_TS_MARKSTEIN && wsteps + 2 <= TS_MARKSTEIN_MAX_COUNT;
+    const int c = wave >> 1, a = wave & 1;
+    const float* ub = base + (wave < 6 ? a * 3 + c : 0);                          // wave-uniform
+    const uint32_t lane_bytes = (uint32_t)t * 24u;                               // element (2 t + a) * 3 + c
+    const int ws = (int)wsteps;
+    if (wave < 6) {
+        if (fast) bad = a ? ts_lane_chain<true, true, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt) : ts_lane_chain<false, true, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt);
+        else if (a) ts_lane_chain<true, false, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt);
+        else ts_lane_chain<false, false, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt);
+    } else {
+        // the mean accumulators of the 64 threads: vectors of four pixels, 512 vectors apart (ts_accumulate's mean_vec, thread t)
+        float ma[3][4];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ma[cc][i] = 0.0f;
+        auto mean_vec = [&](const f32x4& a0, const f32x4& a1, const f32x4& a2) {
+            const float e[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) ma[cc][i] = ma[cc][i] + e[i * 3 + cc];
+        };
+        constexpr int MD = VRG_TS_LANES_MEAN_DEPTH;
+        const int64_t msteps = nvm / 512;
+        const bool mextra = (int64_t)t < nvm - msteps * 512;
+        const int64_t last = msteps > 0 ? msteps - 1 : 0;
+        f32x4 mb[MD][3];
+        auto mload = [&](int i, int64_t r) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)(r * 512 + t) * 12);
+            mb[i][0] = q[0]; mb[i][1] = q[1]; mb[i][2] = q[2];
+        };
+#pragma unroll
+        for (int i = 0; i < MD; ++i) mload(i, i < last ? i : last);
+        int64_t r0 = 0;
+        for (; r0 + MD <= msteps; r0 += MD) {
+#pragma unroll
+            for (int i = 0; i < MD; ++i) {
+                mean_vec(mb[i][0], mb[i][1], mb[i][2]);
+                const int64_t nx = r0 + i + MD;
+                mload(i, nx < last ? nx : last);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MD; ++i)
+            if (r0 + i < msteps) mean_vec(mb[i][0], mb[i][1], mb[i][2]);
+        if (mextra) {
+            const f32x4* q = reinterpret_cast<const f32x4*>(base + (size_t)(msteps * 512 + t) * 12);
+            mean_vec(q[0], q[1], q[2]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            float m = ma[cc][0];
+            m = m + ma[cc][1];
+            m = m + ma[cc][2];
+            m = m + ma[cc][3];
+            R->m[cc][t] = m;
+        }
+    }
+    if (fast && __syncthreads_or(bad ? 1 : 0)) {                                 // a delta outside the proven range somewhere in the workgroup: IEEE division
+        if (wave < 6) {
+            if (a) ts_lane_chain<true, false, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt);
+            else ts_lane_chain<false, false, DEPTH>(ub, lane_bytes, ws, wextra, ts_rn_tab, acc, cnt);
+        }
+    }
+    if (wave < 6) R->w[c][a][t] = TsLaneRec{acc.mean, acc.m2, cnt, 0};
+}
+
+// torch's block (512 threads) per frame: accumulators 0 and 1 of each thread combined, then block_x_reduce / block_y_reduce / project
+__global__ void __launch_bounds__(512) k_tstats_lanes_finish(const TsLanes* __restrict__ recs, int bw, int bh, float factor, float eps, float* __restrict__ out) {
+    __shared__ Welf lds_w[512];
+    float* lds_m = reinterpret_cast<float*>(lds_w);
+    const int64_t f = blockIdx.x;
+    const int t = threadIdx.x;
+    const TsLanes* R = recs + f;
+    float* o6 = out + (size_t)f * 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float m = R->m[c][t];
+        m = ts_block_reduce<MeanOp>(m, bw, bh, true, t, true, lds_m);
+        if (t == 0) o6[c * 2] = m * factor;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const TsLaneRec r0 = R->w[c][0][t], r1 = R->w[c][1][t];
+        const Welf w0{r0.mean, r0.m2, r0.cnt, (float)r0.cnt}, w1{r1.mean, r1.m2, r1.cnt, (float)r1.cnt};
+        Welf w = WelfOp::combine(w0, w1);
+        w = ts_block_reduce<WelfOp>(w, bw, bh, true, t, true, lds_w);
+        if (t == 0) o6[c * 2 + 1] = welf_std(w) + eps;
+    }
+}
+
 template <bool SPLIT, int DEPTH>
 __global__ void __launch_bounds__(512) k_tstats_frame(const float* __restrict__ lab, int64_t n, int64_t frames, int bw, int bh, float factor,
                                                       float eps, float* __restrict__ out) {
@@ -215,27 +400,6 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
     return VRG_OK;
 }
 
-// For the fused stage kernel (vrg_stage.hip), which runs the half-block workgroups of k_tstats_rows as one of its roles: the geometry
-// of `count` calls of `b` frames (VRG_ERR_UNSUPPORTED unless the calls take the whole-frame form) and the finishing launch.
-int ts_rows_geometry(int64_t n, int b, int num_mp, int& bw, int& bh, float& factor) {
-    const int64_t O = (int64_t)b * 3;
-    if (b <= 0 || O * n > ((int64_t)1 << 29)) return VRG_ERR_UNSUPPORTED;
-    TsCfg cm, cw;
-    if (num_mp < 100 || !ts_config(O, n, 4, cm, num_mp) || !ts_config(O, n, 2, cw, num_mp)) return VRG_ERR_UNSUPPORTED;
-    const bool whole = (n % 4 == 0) && cm.vectorize && cw.vectorize && cm.split && cw.split && cm.bw * cm.bh == 512 && cw.bw * cw.bh == 512 &&
-                       cm.bw == cw.bw && cm.bh == cw.bh && cm.bh <= 8 && 256 % cm.bw == 0;
-    if (!whole) return VRG_ERR_UNSUPPORTED;
-    bw = cm.bw; bh = cm.bh;
-    factor = (float)O / (float)(O * n);
-    return VRG_OK;
-}
-
-int ts_rows_finish(const void* rows, int64_t frames, int bh, float factor, float eps, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(k_tstats_rows_finish, dim3((unsigned)((frames * 6 + 63) / 64)), dim3(64), 0, st, reinterpret_cast<const TsRows*>(rows), frames, bh, factor,
-                       eps, out);
-    return hipGetLastError() == hipSuccess ? VRG_OK : VRG_ERR_LAUNCH;
-}
-
 #ifndef VRG_TS_SPLIT_MAX_FRAMES
 #define VRG_TS_SPLIT_MAX_FRAMES 64
 #endif
@@ -281,6 +445,26 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
         // for the four-workgroup form (64 frames 1.85 ms against 1.98; four: 2.75), the plain one-round loop for the HBM-bound whole-frame
         // form (256 frames 4.4 ms; branch-free 5.5, two / four rounds 6.3 / 6.7): profiles/r03_stats_prefetch_depth_ab.log.
         // up to 32 frames (and a caller-supplied scratch buffer): eight half-block workgroups per frame, one wave per SIMD
+#ifndef VRG_TS_LANES
+#define VRG_TS_LANES 1
+#endif
+        if (VRG_TS_LANES && frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsLanes) && cm.bh == cw.bh &&
+            n / 1024 + 2 <= TS_LANES_MAX_STEPS && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
+            // one accumulator per lane: eight 7-wave workgroups per frame + torch's block as the finishing kernel
+            TsLanes* recs = reinterpret_cast<TsLanes*>(scratch);
+            const size_t lds = (size_t)(n / 1024 + 2) * sizeof(float2);
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tstats_lanes<VRG_TS_LANES_DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        TS_LANES_MAX_STEPS * (int)sizeof(float2)) != hipSuccess)
+                    return VRG_ERR_LAUNCH;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_tstats_lanes<VRG_TS_LANES_DEPTH>), dim3((unsigned)(64 * ((frames + 7) / 8))), dim3(448), lds, st, lab, n, frames, recs);
+            hipLaunchKernelGGL(k_tstats_lanes_finish, dim3((unsigned)frames), dim3(512), 0, st, recs, cm.bw, cm.bh, factor, eps, out);
+            VRG_CHECK_LAUNCH();
+            return VRG_OK;
+        }
         if (frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsRows) && cm.bh == cw.bh && cm.bh <= 8 && 256 % cm.bw == 0 &&
             (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
             TsRows* rows = reinterpret_cast<TsRows*>(scratch);
@@ -307,8 +491,8 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
 }  // namespace vrg
 
 extern "C" int64_t vrg_lab_stats_torch_scratch_bytes(int64_t frames) {
-    if (frames <= 0 || frames > vrg::TS_ROWS_MAX_FRAMES) return 0;       // only the small-batch (half-block) form uses a scratch buffer
-    return frames * (int64_t)sizeof(vrg::TsRows);
+    if (frames <= 0 || frames > vrg::TS_ROWS_MAX_FRAMES) return 0;       // only the small-batch forms use a scratch buffer
+    return frames * (int64_t)(sizeof(vrg::TsLanes) > sizeof(vrg::TsRows) ? sizeof(vrg::TsLanes) : sizeof(vrg::TsRows));
 }
 
 extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,

@@ -1,5 +1,4 @@
-// vrg_tstats_body.hpp -- the device side of the torch-order statistics replay that is shared between vrg_torch_stats.hip and the fused
-// stage kernel (vrg_stage.hip): the reduction ops, torch's block reduce, and the whole-frame thread loops (see vrg_torch_stats.hip for
+// vrg_tstats_body.hpp -- the device side of the torch-order statistics replay (vrg_torch_stats.hip): the reduction ops, torch's block reduce, and the whole-frame thread loops (see vrg_torch_stats.hip for
 // the design and the sources they follow).
 #pragma once
 #include "vrg_common.hpp"

@@ -54,7 +54,7 @@ CM_STATS = ("device", "fp64")
 
 
 _NO_DEVICE_STATS_WARNED = set()
-_STATE_LOCK = threading.Lock()          # guards the small per-process caches below (first-use races between host threads)
+_STATE_LOCK = threading.RLock()     # re-entrant: HipEvent.__del__ takes it and may run in a GC pass triggered while it is held          # guards the small per-process caches below (first-use races between host threads)
 
 
 def device_stats_supported(device) -> bool:
@@ -650,14 +650,23 @@ def device_stats_selfcheck(device, force: bool = False) -> bool:
         for probe, call_sizes in _selfcheck_planes(torch.device("cuda", key)):
             F, H, W, _ = probe.shape
             for calls in call_sizes:
-                got = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
-                _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
-                           "vrg_lab_stats_torch_f32")
                 want = []
                 for i in range(0, F, calls):
                     t = probe[i:i + calls].permute(0, 3, 1, 2).contiguous()
                     want.append(torch.stack([t.mean(dim=[2, 3]), t.std(dim=[2, 3])], dim=-1))
-                ok = ok and torch.equal(got, torch.cat(want, dim=0))
+                want = torch.cat(want, dim=0)
+                got = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
+                _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
+                           "vrg_lab_stats_torch_f32")
+                ok = ok and torch.equal(got, want)
+                # the form production takes (lab_stats_device): with a scratch buffer small batches run the one-accumulator-per-lane kernels
+                nbytes = int(_hip.lib().vrg_lab_stats_torch_scratch_bytes(F))
+                if nbytes:
+                    scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=probe.device)
+                    got2 = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
+                    _hip.check(_hip.lib().vrg_lab_stats_torch_ws_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got2), _f32(0.0), _hip.ptr(scratch), nbytes,
+                                                                     _hip.current_stream()), "vrg_lab_stats_torch_ws_f32")
+                    ok = ok and torch.equal(got2, want)
     with _STATE_LOCK:
         first = key not in _TS_CHECKED
         _TS_CHECKED[key] = ok
@@ -903,230 +912,10 @@ def chain_stats(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
 
 
 
-_PIPE_STREAMS = {}
-
-
-def _pipe_stream(device) -> "torch.cuda.Stream":
-    """The second frame-pass stream of a device: pass 2 (and the statistics reductions) of piece i run on it while pass 1 of piece
-    i + 1 runs on the caller's stream (fused_chain, `overlap_pieces`)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    with _STATE_LOCK:
-        st = _PIPE_STREAMS.get(key)
-        if st is None:
-            st = _PIPE_STREAMS[key] = torch.cuda.Stream(device=key)
-    return st
-
-
-def default_overlap_pieces(frames: int, frame_elems: int) -> int:
-    """How many pieces the two-pass colour-match chain is cut into so that its passes overlap (0 / 1 = one piece, sequential passes: the
-    default).  VRGDG_CM_PIECES overrides.  Pass 1 (grain -> LUT -> Lab) is bound by the LUT's gather address path with the vector ALUs
-    64 % busy, pass 2 (match -> Lab->RGB -> sharpen) by the vector ALUs with the address path idle -- on paper they should share a CU's
-    two bottlenecks.  Measured on the MI355X (profiles/r03_pipelined_pieces_sweep.log): they do not -- two full-size grids on two
-    streams are dispatched one after the other (256 x 4K frames: 59.3 ms in one piece, 61.9 / 62.4 / 68.9 / 82.0 in 2 / 4 / 8 / 16;
-    the small pieces' statistics reductions are latency bound on top), so the pipeline stays an option, off by default."""
-    env = os.environ.get("VRGDG_CM_PIECES", "").strip()
-    if env:
-        return max(int(env), 0)
-    return 0
-
-
-def _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events):
-    """Device-statistics two-pass chain as a software pipeline over `pieces` frame ranges (multiples of the RNG chunk and of the
-    statistics call size): on the caller's stream pass 1 of piece i; on the second stream, behind an event, the statistics reductions
-    and pass 2 of piece i -- next to pass 1 of piece i + 1.  Same kernels, same arguments per frame range, same results as the
-    one-piece form (the statistics calls and the RNG chunks are the same ones)."""
-    F, H, W, _ = x.shape
-    fe = H * W * 3
-    lib = _hip.lib()
-    main = torch.cuda.current_stream()
-    aux = _pipe_stream(x.device)
-    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
-    aux.wait_stream(main)                       # `out`, the Lab workspace and the statistics buffer may still be in use by earlier work
-    if spec.cm_ref_event is not None:
-        aux.wait_event(spec.cm_ref_event)
-    _device_stats_selfcheck(x.device)
-    keep = []
-    for f0, nf in pieces:
-        d1 = _chain_desc(spec, plan, keep, x)
-        if plan is not None:
-            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
-        if kernel_events is not None:
-            s0, s1 = HipEvent(), HipEvent()
-            s0.record()
-        _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
-                                              C.byref(d1), None, None, _hip.current_stream()), "vrg_chain_stats_lab_f32")
-        if kernel_events is not None:
-            s1.record()
-            kernel_events.append(("stats", s0, s1, nf))
-        done1 = torch.cuda.Event()
-        done1.record(main)
-        with torch.cuda.stream(aux):
-            aux.wait_event(done1)
-            if kernel_events is not None:
-                t0, t1 = HipEvent(), HipEvent()
-                t0.record()
-            lab_stats_device(lab_full[f0:f0 + nf], spec.cm_chunk, out=img_ms_full[f0:f0 + nf])
-            if kernel_events is not None:
-                t1.record()
-                kernel_events.append(("tstats", t0, t1, nf))
-            d2 = _chain_desc(spec, plan, keep, x)
-            d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
-            d2.img_ms = img_ms_full.data_ptr() + f0 * 24
-            if kernel_events is not None:
-                e0, e1 = HipEvent(), HipEvent()
-                e0.record()
-            _hip.check(lib.vrg_fused_chain_f32(C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), C.c_void_p(out.data_ptr() + f0 * fe * 4), nf, H, W,
-                                              C.byref(d2), _hip.current_stream()), "vrg_fused_chain_f32")
-            if kernel_events is not None:
-                e1.record()
-                kernel_events.append(("apply", e0, e1, nf))
-    main.wait_stream(aux)
-    for t in (x, out, lab_full, img_ms_full):
-        t.record_stream(aux)
-    return out
-
-
-def default_stage_frames(frames: int, frame_elems: int) -> int:
-    """Frames per range of the staged form of the two-pass colour-match chain (0 = not staged: the default).  VRGDG_CM_STAGE_FRAMES
-    overrides.  The staged form (csrc/vrg_stage.hip) runs pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 as
-    workgroup roles of ONE launch per stage.  Measured on the MI355X (profiles/r03_staged_pipeline_first.log, r03_staged_pipeline_pmc.log):
-    it hides most of the statistics' latency (a stage with pass 1 + statistics: 5.3 ms against 4.5 + 1.6) but pass 2 is NOT absorbed by
-    pass 1 -- a stage with all three roles takes 7.6 ms against 4.5 for pass 1 alone: pass 2 costs 2.25 ms inside the launch, 2.42 ms as
-    a kernel of its own.  96 x 4K frames: 22.6 ms staged, 23.7 sequential; 256 frames: 59.4 staged, 56.6 sequential (the short ranges
-    cost pass 1 its seven waves per SIMD and its tail).  Weighted for their instruction mix (transcendentals, 64-bit multiplies, compare /
-    select pairs) the passes run at 70-73 % and 79-82 % of the vector-ALU issue rate: what pass 1 leaves idle are single slots between
-    dependent instructions, which pass 2's long dependent chains do not fill."""
-    env = os.environ.get("VRGDG_CM_STAGE_FRAMES", "").strip()
-    if env:
-        return max(int(env), 0)
-    return 0
-
-
-def _fused_chain_staged(x, out, spec, plan, lab_full, ranges, kernel_events):
-    """grain -> (LUT) -> colour match -> sharpen with the device statistics as a software pipeline over `ranges` (>= 2 frame ranges of
-    whole RNG chunks / statistics calls / reference groups): stage s = ONE launch (vrg_chain_stage_f32) whose workgroups run pass 1 of
-    range s, the torch-order statistics of range s-1 and pass 2 of range s-2.  Returns False -- nothing launched -- when the library
-    cannot stage this chain (frame geometry, ...): the caller then takes the sequential form."""
-    F, H, W, _ = x.shape
-    fe = H * W * 3
-    lib = _hip.lib()
-    st = _hip.current_stream()
-    N = len(ranges)
-    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
-    most = max(nf for _, nf in ranges)
-    nbytes = int(lib.vrg_chain_stage_scratch_bytes(most))
-    scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=x.device)
-    _device_stats_selfcheck(x.device)
-    keep = [img_ms_full, scratch]
-    for s in range(N + 2):
-        sd = _hip.StageDesc()
-        sd.height, sd.width = H, W
-        if s < N:
-            f0, nf = ranges[s]
-            d1 = _chain_desc(spec, plan, keep, x)
-            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
-            sd.p1_in, sd.p1_lab, sd.p1_frames = x.data_ptr() + f0 * fe * 4, lab_full.data_ptr() + f0 * fe * 4, nf
-            sd.p1_desc = C.pointer(d1)
-        if 1 <= s <= N:
-            f0, nf = ranges[s - 1]
-            sd.stats_lab, sd.stats_frames, sd.stats_chunk_frames, sd.stats_eps = lab_full.data_ptr() + f0 * fe * 4, nf, int(spec.cm_chunk), _f32(1e-5)
-            sd.stats_mean_std = img_ms_full.data_ptr() + f0 * 24
-            sd.stats_scratch, sd.stats_scratch_bytes = scratch.data_ptr(), nbytes
-        if 2 <= s <= N + 1:
-            f0, nf = ranges[s - 2]
-            if s == 2 and spec.cm_ref_event is not None:
-                torch.cuda.current_stream().wait_event(spec.cm_ref_event)
-            d2 = _chain_desc(spec, plan, keep, x)
-            d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
-            d2.img_ms = img_ms_full.data_ptr() + f0 * 24
-            sd.p2_lab, sd.p2_out, sd.p2_frames = lab_full.data_ptr() + f0 * fe * 4, out.data_ptr() + f0 * fe * 4, nf
-            sd.p2_desc = C.pointer(d2)
-        if kernel_events is not None:
-            e0, e1 = HipEvent(), HipEvent()
-            e0.record()
-        rc = lib.vrg_chain_stage_f32(C.byref(sd), st)
-        if rc == 2 and s == 0:                   # VRG_ERR_UNSUPPORTED before anything ran
-            return False
-        _hip.check(rc, "vrg_chain_stage_f32")
-        if kernel_events is not None:
-            e1.record()
-            kernel_events.append(("stage", e0, e1, (ranges[s][1] if s < N else 0)))
-    return True
-
-
-def default_stats_pieces(frames: int, frame_elems: int) -> int:
-    """Into how many frame ranges pass 1 of the two-pass colour-match chain is cut so that the statistics reductions of range i run --
-    on the high-priority side stream -- next to pass 1 of range i + 1 (0 / 1 = one range: the default).  VRGDG_CM_STATS_PIECES
-    overrides.  Measured on the MI355X (profiles/r03_stats_overlap_sweep.log) and NOT adopted: 256 x 4K frames 56.4 ms in one range,
-    61.0 / 66.4 / 65.9 / 74.2 in 2 / 4 / 8 / 16 -- next to pass 1's seven waves per SIMD the reductions' dependent chains are starved
-    of issue slots (a range's reductions 12 ms instead of 2.6) and pass 1 itself slows by a quarter (43.7 instead of 33.7 ms).  A third
-    schedule -- pass 2 of range i as a PERSISTENT kernel (1 / 2 / 3 workgroups per CU walking the range's strips) on the high-priority
-    stream beside pass 1 of range i + 1 -- was built and measured too: 62.4 - 85.3 ms (profiles/r03_persistent_pass2_overlap_sweep.log);
-    removed.  Only the reference frame's handful of workgroups is worth a second stream."""
-    env = os.environ.get("VRGDG_CM_STATS_PIECES", "").strip()
-    if env:
-        return max(int(env), 0)
-    return 0
-
-
-def _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_events):
-    """Device-statistics two-pass chain with the statistics reductions off the critical path: pass 1 range by range on the caller's
-    stream; the reductions of range i on the high-priority side stream, behind an event, next to pass 1 of range i + 1; then pass 2 over
-    the whole batch in one launch.  Same kernels, same arguments per frame range, same results as the one-range form."""
-    F, H, W, _ = x.shape
-    fe = H * W * 3
-    lib = _hip.lib()
-    main = torch.cuda.current_stream()
-    side = _side_stream(x.device)
-    img_ms_full = torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
-    _device_stats_selfcheck(x.device)
-    keep = []
-    for f0, nf in pieces:
-        d1 = _chain_desc(spec, plan, keep, x)
-        if plan is not None:
-            d1.noise.chunk0 = plan.chunk0 + f0 // plan.chunk_frames
-        if kernel_events is not None:
-            s0, s1 = HipEvent(), HipEvent()
-            s0.record()
-        _hip.check(lib.vrg_chain_stats_lab_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), C.c_void_p(lab_full.data_ptr() + f0 * fe * 4), nf, H, W,
-                                              C.byref(d1), None, None, _hip.current_stream()), "vrg_chain_stats_lab_f32")
-        if kernel_events is not None:
-            s1.record()
-            kernel_events.append(("stats", s0, s1, nf))
-        done1 = torch.cuda.Event()
-        done1.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(done1)
-            if kernel_events is not None:
-                t0, t1 = HipEvent(), HipEvent()
-                t0.record()
-            lab_stats_device(lab_full[f0:f0 + nf], spec.cm_chunk, out=img_ms_full[f0:f0 + nf])
-            if kernel_events is not None:
-                t1.record()
-                kernel_events.append(("tstats", t0, t1, nf))
-    main.wait_stream(side)                      # the last range's reductions (and, on the same stream, the reference frame's statistics)
-    if spec.cm_ref_event is not None:
-        main.wait_event(spec.cm_ref_event)
-    d2 = _chain_desc(spec, plan, keep, x)
-    d2.stages = (d2.stages & _hip.STAGE_SHARPEN) | _hip.STAGE_COLORMATCH | _hip.STAGE_FROM_LAB
-    d2.img_ms = img_ms_full.data_ptr()
-    if kernel_events is not None:
-        e0, e1 = HipEvent(), HipEvent()
-        e0.record()
-    _hip.check(lib.vrg_fused_chain_f32(_hip.ptr(lab_full), _hip.ptr(out), F, H, W, C.byref(d2), _hip.current_stream()), "vrg_fused_chain_f32")
-    if kernel_events is not None:
-        e1.record()
-        kernel_events.append(("apply", e0, e1, F))
-    for t in (lab_full, img_ms_full):
-        t.record_stream(side)
-    return out
-
-
 @_on_device
 def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch.Generator] = None, plans=None,
                 out: Optional[torch.Tensor] = None, kernel_events: Optional[list] = None,
-                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True, overlap_pieces: Optional[int] = None,
-                stats_pieces: Optional[int] = None, stage_frames: Optional[int] = None) -> torch.Tensor:
+                lab_workspace: Optional[torch.Tensor] = None, cache_lab: bool = True) -> torch.Tensor:
     """One pass over HBM for grain -> LUT -> colour match -> 3x3 sharpen (colour match adds one statistics
     pass).  Bit-identical to applying the stand-alone operators in that order.
 
@@ -1187,53 +976,14 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
     if device_stats:
         # The reference's statistics are torch reductions over each batch_size call: they need the Lab image of WHOLE calls, so
         # pass 1 runs for every segment first, then the reductions over the batch, then pass 2 (cache_lab is implied).
-        # (Cutting the batch into pieces whose reductions run on a second stream next to the following piece's pass 1 was built and
-        # measured: 256 x 4K frames 63.2 ms in one piece, 65.8 / 67.9 / 67.3 in 2 / 4 / 8 -- the HBM-bound reductions slow the
-        # issue-bound pass they share the CUs with by more than they hide.  Not kept.)
+        # (Four schedules that overlap the passes over frame ranges were built and measured slower in round 3; they live in
+        # tools/experiments/ with their A/B logs, LABNOTES.md section "schedules".)
         if lab_workspace is not None:
             if lab_workspace.shape != x.shape or lab_workspace.dtype != torch.float32 or not lab_workspace.is_contiguous():
                 raise ValueError("lab_workspace must be a contiguous float32 tensor shaped like images")
             lab_full = lab_workspace
         else:
             lab_full = torch.empty((F, H, W, 3), dtype=torch.float32, device=x.device)
-        # Software pipeline over frame ranges (see _fused_chain_pipelined / default_overlap_pieces): only when the batch is one run of
-        # equal RNG chunks and equal statistics calls, so that every piece is made of whole chunks and whole calls
-        n_pieces = default_overlap_pieces(F, fe) if overlap_pieces is None else int(overlap_pieces)
-        n_stats = 0 if n_pieces > 1 else (default_stats_pieces(F, fe) if stats_pieces is None else int(stats_pieces))
-        # The staged form (one launch per pipeline stage, csrc/vrg_stage.hip): chains grain -> (LUT) -> colour match -> sharpen over
-        # one run of equal RNG chunks and equal statistics calls, default arithmetic, when no other schedule was asked for
-        per_stage = 0
-        if n_pieces <= 1 and n_stats <= 1 and overlap_pieces is None and stats_pieces is None:
-            per_stage = default_stage_frames(F, fe) if stage_frames is None else int(stage_frames)
-        if (per_stage > 0 and len(segments) == 1 and segments[0][2] is not None and isinstance(spec.cm_chunk, int) and spec.sharpen is not None and
-                _cm_math(spec.cm_math) == _hip.CM_MATH_DEVICE and (spec.variant & 0xff) in (0, 2)):
-            plan = segments[0][2]
-            unit = spec.cm_chunk * plan.chunk_frames // math.gcd(spec.cm_chunk, plan.chunk_frames)
-            R = int(spec.colormatch[0].shape[0])
-            if R != 1:
-                unit = unit * R // math.gcd(unit, R)
-            per = max(unit, per_stage // unit * unit)
-            if F % unit == 0 and F >= 2 * per:
-                ranges = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
-                if _fused_chain_staged(x, out, spec, plan, lab_full, ranges, kernel_events):
-                    return out
-        overlap_stats = n_stats > 1
-        if overlap_stats:
-            n_pieces = n_stats
-        if n_pieces > 1 and len(segments) == 1 and isinstance(spec.cm_chunk, int):
-            plan = segments[0][2]
-            unit = spec.cm_chunk * (plan.chunk_frames if plan is not None else 1) // math.gcd(spec.cm_chunk, plan.chunk_frames if plan is not None else 1)
-            R = int(spec.colormatch[0].shape[0])
-            if R != 1:
-                unit = unit * R // math.gcd(unit, R)
-            units = F // unit
-            if units >= 2:
-                n_pieces = min(n_pieces, units)
-                per = (units + n_pieces - 1) // n_pieces * unit
-                pieces = [(f0, min(per, F - f0)) for f0 in range(0, F, per)]
-                if overlap_stats:
-                    return _fused_chain_stats_overlap(x, out, spec, plan, lab_full, pieces, kernel_events)
-                return _fused_chain_pipelined(x, out, spec, plan, lab_full, pieces, kernel_events)
         for f0, nf, plan in segments:
             keep = []
             d = _chain_desc(spec, plan, keep, x)

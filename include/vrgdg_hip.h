@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 5
+#define VRG_ABI_VERSION 6
 
 enum vrg_status {
     VRG_OK = 0,
@@ -107,11 +107,6 @@ int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_
  * `in`): the noise-injection form used to prove arithmetic parity against the CPU reference. */
 int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int64_t pixels,
                            float intensity, float sat, float one_minus_sat, void* stream);
-
-/* Raw N(0,1) stream of the given chunks, bit-identical to torch.randn on this device (debug /
- * test entry: lets the tests compare the stream itself against torch). `frame_elems` = H*W*3. */
-int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
-                  const vrg_noise_desc* noise, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a4/a5/a6  3D LUT trilinear apply + strength blend.  Replaces VRGDG_LUTS._apply_cube_lut and
@@ -311,31 +306,6 @@ int vrg_adjust_u8(const uint8_t* in, uint8_t* out, float* tmp, int64_t frames, i
                   const vrg_adjust_desc* desc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * One stage of the headline chain's software pipeline over frame ranges (csrc/vrg_stage.hip): ONE launch whose workgroups take
- * one of three roles -- pass 1 (grain -> LUT -> Lab) of a frame range, the torch-order statistics of the Lab image of the previous
- * range, pass 2 (colour match from Lab -> 3x3 stencil) of the range before that -- so that the three share a CU's different
- * bottlenecks (gather address path / vector ALUs / dependent-chain latency).  A host walks s = 0 .. ranges + 1 and hands stage s
- * pass 1 of range s, the statistics of range s-1 and pass 2 of range s-2 (any of them may be empty: *_frames = 0; a stage with
- * statistics only is VRG_ERR_UNSUPPORTED -- use vrg_lab_stats_torch_ws_f32).  Each role is the same device code as its stand-alone
- * entry point (vrg_chain_stats_lab_f32 with stats = NULL, vrg_lab_stats_torch_ws_f32, vrg_fused_chain_f32 with
- * COLORMATCH | FROM_LAB | SHARPEN): results are bit-identical to calling those one after the other.
- *   p1_desc: stages GRAIN [| LUT], device colour-match arithmetic; p1_frames a multiple of the RNG chunk.
- *   stats_*: `stats_frames` frames of the Lab image, `stats_chunk_frames` frames per reference call (dividing stats_frames; video-sized
- *            frames only -- VRG_ERR_UNSUPPORTED otherwise), result in stats_mean_std [frames][3][2]; scratch of
- *            vrg_chain_stage_scratch_bytes(stats_frames) bytes, 16-byte aligned.
- *   p2_desc: stages COLORMATCH | FROM_LAB | SHARPEN with img_ms / ref_ms of the p2 frames.
- * ------------------------------------------------------------------------------------------- */
-typedef struct vrg_stage_desc {
-    int32_t height, width;
-    const float* p1_in; float* p1_lab; int64_t p1_frames; const vrg_chain_desc* p1_desc;
-    const float* stats_lab; int64_t stats_frames; int32_t stats_chunk_frames; float stats_eps; float* stats_mean_std;
-    void* stats_scratch; int64_t stats_scratch_bytes;
-    const float* p2_lab; float* p2_out; int64_t p2_frames; const vrg_chain_desc* p2_desc;
-} vrg_stage_desc;
-int64_t vrg_chain_stage_scratch_bytes(int64_t stats_frames);
-int vrg_chain_stage_f32(const vrg_stage_desc* stage, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
  * Introspection
  * ------------------------------------------------------------------------------------------- */
 int vrg_abi_version(void);
@@ -343,47 +313,6 @@ const char* vrg_error_string(int status);
 /* multiProcessorCount and maxThreadsPerMultiProcessor of the current device (what torch's
  * calc_execution_policy reads); returns VRG_ERR_NO_DEVICE without a GPU. */
 int vrg_device_info(int32_t* cu_count, int32_t* max_threads_per_cu);
-/* Device self-test: sweeps all 2^32 fp32 inputs through the FMA-based constant divisions of the kernels
- * (csrc/vrg_pixel_math.hpp div_const / div9) and counts disagreements with the IEEE quotient.
- * counts18 (device, 18 x u64): [0..8] mismatches for 1e-30 <= |x| <= 1e30 (expected 0 for all nine
- * constants), [9..17] mismatches outside that range. */
-int vrg_selftest_divconst(unsigned long long* counts18, void* stream);
-/* Device self-test: the trimmed correctly-rounded square root of the Box-Muller radius (csrc/vrg_pixel_math.hpp
- * sqrt_normal_range) against the backend's IEEE sqrt for all 2^32 Philox words; counts1[0] = mismatches (expected 0). */
-int vrg_selftest_bm_radius(unsigned long long* counts1, void* stream);
-/* Device self-test: the Welford update's division by the running count as the statistics kernels evaluate it (reciprocal + two FMAs,
- * csrc/vrg_tstats_body.hpp) against the IEEE quotient, for the counts n_first .. n_first + n_count - 1 (< 2^24) x all 2^23 fp32
- * significands; mismatches1[0] (device, zeroed by the caller) += mismatches (expected 0). */
-int vrg_selftest_welford_division(unsigned long long* mismatches1, uint32_t n_first, uint32_t n_count, void* stream);
-/* Device self-test of the DPP lane shifts the wave-march kernel relies on: out128[i] = value held by lane i-1,
- * out128[64+i] = value held by lane i+1, for lane values 0..63. */
-int vrg_selftest_lanes(float* out128, void* stream);
-/* Element-wise pieces of the colour-match arithmetic for the parity tests (n values, or n triples for op 5..8):
- * op 0 ocml powf(x, y); 1 x * fl(1/y); 2 x / y; 3 fast-policy pow_pos(x, y); 4 fast-policy cube root;
- * 5 / 6 rgb->Lab / Lab->rgb with the device policy; 7 / 8 the same with the fast policy; 9 / 10 / 11 dev_pow(x, y), the
- * transcription of ocml powf without its special-case scaffolding that the device policy evaluates: 9 any x > 0 and finite y,
- * 10 the flavour of sRGB -> linear (x >= 2^-20, 0 < y <= 4), 11 the flavour of linear -> sRGB and the Lab cube root
- * (x >= 2^-20, 0 < y <= 0.5); 12 / 13 / 14 dev_pow_ziv(x, y) as sRGB -> linear / linear -> sRGB / the Lab cube root call it
- * (table logarithm + rounding test, the transcription where the test fails or x is outside the call site's domain);
- * 15: 1.0 where the rounding test of dev_pow_ziv fails for (x, y), else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
- * 18 / 19 dev_pow_ziv's table ln x, head / tail. */
-int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
-/* Host-only (no GPU needed): the launch geometry vrg_lab_stats_torch_f32 derives -- torch's setReduceConfig on the MI355X -- for
- * `num_outputs` outputs of `reduce_len` contiguous fp32 elements, `vec` = 4 (mean) or 2 (std): cfg4 = {block_width, block_height,
- * reduction split across the rows (1) or one output per row (0), vectorised thread loop (1) or strided (0)}. */
-int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32_t vec, int32_t* cfg4);
-/* Timing probe for LUT record fetch patterns (tools/gpu_diag.py); `out` = one float per pixel (a checksum).
- * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;
- * 5 / 6: channel split -- one / two channels of the node table in LDS (8 ds_read per pixel), the rest gathered (4 / 2 x 16 B). */
-int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
-/* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
- * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,
- * 6 v_cmp+v_cndmask pairs, 7 v_mul_f64/v_fma_f64); `out` = blocks*256 floats.  Measures the VALU roofline. */
-int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream);
-/* Streaming-copy ceiling: out[i] = in[i] over n_floats fp32 values (a multiple of 4; 16-byte aligned
- * pointers), 16 B per lane.  mode 0: plain loads / stores; 1: non-temporal; 2: non-temporal, four float4 per thread; 3: read only;
- * 4: write only (a constant).  What every streaming kernel of this library is priced against, next to the 8 TB/s spec peak. */
-int vrg_debug_copy_f32(const float* in, float* out, int64_t n_floats, int32_t mode, void* stream);
 /* HIP-event timing helper for bench.py: records an event on `stream` and returns elapsed ms
  * between two recorded events (torch.cuda.Event only sees torch's current stream). */
 int vrg_event_create(void** ev);

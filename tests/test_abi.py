@@ -18,15 +18,24 @@ def hip(pkg):
     return _hip
 
 
-def test_header_symbols_are_exported(hip):
-    header = open(os.path.join(ROOT, "include", "vrgdg_hip.h")).read()
+def _declared(name):
+    header = open(os.path.join(ROOT, "include", name)).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(vrg_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no prototypes found"
+    return set(re.findall(r"\b(vrg_[a-z0-9_]+)\s*\(", header))
+
+
+def test_header_symbols_are_exported(hip):
+    """The drop-in boundary (vrgdg_hip.h) and the separate self-test / probe header (vrgdg_hip_debug.h): every prototype is exported
+    and bound, and the boundary carries no debug entry point."""
+    declared, debug = _declared("vrgdg_hip.h"), _declared("vrgdg_hip_debug.h")
+    assert declared and debug, "no prototypes found"
     lib = hip.load_library()
-    for sym in sorted(declared):
-        assert hasattr(lib, sym), f"{sym} declared in vrgdg_hip.h but not exported"
-    assert declared == set(hip.EXPORTED_SYMBOLS), "ctypes prototypes out of sync with the header"
+    for sym in sorted(declared | debug):
+        assert hasattr(lib, sym), f"{sym} declared but not exported"
+    assert declared == set(hip.EXPORTED_SYMBOLS), "ctypes prototypes out of sync with vrgdg_hip.h"
+    assert debug == set(hip.DEBUG_SYMBOLS), "ctypes prototypes out of sync with vrgdg_hip_debug.h"
+    assert not [s for s in declared if s.startswith(("vrg_debug_", "vrg_selftest_"))]
+    assert not (declared & debug)
 
 
 def test_struct_layouts_match_the_header(hip):
@@ -38,7 +47,7 @@ def test_struct_layouts_match_the_header(hip):
 
 def test_versions_and_error_strings(hip):
     lib = hip.load_library()
-    assert lib.vrg_abi_version() == 5
+    assert lib.vrg_abi_version() == 6
     assert lib.vrg_error_string(0) == b"ok"
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8

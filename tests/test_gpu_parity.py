@@ -2092,42 +2092,6 @@ def test_device_statistics_of_a_split_call_use_the_whole_calls_mean_factor(ops, 
     assert _same_bits_or_nan(got, want), (got - want).abs().max()
 
 
-@pytest.mark.parametrize("F,chunk,bs,n_ref,pieces", [(12, 2, 3, 1, 2), (12, 2, 1, 1, 8), (16, 4, 1, 1, 3), (12, 0, 2, 2, 4), (7, 0, 1, 1, 7), (24, 4, 6, 3, 2)])
-def test_pipelined_pieces_equal_the_one_piece_chain(ops, dev, F, chunk, bs, n_ref, pieces):
-    """fused_chain(overlap_pieces=n): pass 1 of piece i+1 on the caller's stream next to the statistics reductions and pass 2 of piece i
-    on a second stream.  Pieces are whole RNG chunks, whole statistics calls and whole reference groups, so every kernel sees the same
-    frames with the same arguments: output bits equal the sequential form's (and the generator ends where it would have)."""
-    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
-    x = _rand((F, 54, 96, 3), 311).to(dev)
-    ref = _rand((n_ref, 30, 40, 3), 312).to(dev)
-    ref_ms = ops.reference_stats(ref)
-    grain = (0.05, 0.4, chunk) if chunk else None
-    spec = ops.ChainSpec(grain=grain, lut=(dlut, 8.0), colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.6, False), cm_chunk=bs)
-    gen = torch.cuda.default_generators[dev.index]
-    torch.manual_seed(9)
-    want = ops.fused_chain(x, spec, overlap_pieces=1)
-    off_want = gen.get_offset()
-    torch.manual_seed(9)
-    got = ops.fused_chain(x, spec, overlap_pieces=pieces)
-    torch.cuda.synchronize()
-    assert gen.get_offset() == off_want
-    assert_bit_equal(got, want, f"{pieces} pipelined pieces vs one piece")
-    ev = []
-    torch.manual_seed(9)
-    again = ops.fused_chain(x, spec, overlap_pieces=pieces, kernel_events=ev, out=torch.empty_like(x), lab_workspace=torch.empty_like(x))
-    assert_bit_equal(again, want, "pipelined, caller-supplied buffers, timed")
-    assert {n for n, *_ in ev} == {"stats", "tstats", "apply"} and all(a.elapsed_ms(b) >= 0 for _, a, b, _ in ev)
-    # the other schedule over the same ranges: only the statistics reductions leave the caller's stream (high-priority side stream,
-    # next to pass 1 of the following range), pass 2 is one launch over the batch
-    ev = []
-    torch.manual_seed(9)
-    got = ops.fused_chain(x, spec, stats_pieces=pieces, kernel_events=ev)
-    torch.cuda.synchronize()
-    assert gen.get_offset() == off_want
-    assert_bit_equal(got, want, f"statistics of {pieces} ranges overlapped with pass 1 vs one range")
-    assert sum(1 for n, *_ in ev if n == "apply") == 1 and sum(1 for n, *_ in ev if n == "tstats") >= 2
-
-
 def test_node_path_over_several_gpu_lanes_equals_one_device(pkg, dev, monkeypatch):
     """VRGDG_DEVICES: a host-fed batch goes round-robin over several GPUs (ComfyUI runs its graph in ONE process: this, not torchrun,
     is how a node reaches the other GPUs of a node).  The 1-GPU test box exercises it with the device list [cuda:0, cuda:0, cuda:0] --
@@ -2208,41 +2172,6 @@ def test_device_statistics_markstein_fallback(pkg, ops, dev, F, b, scale):
     assert _same_bits_or_nan(got, want)
 
 
-@pytest.mark.parametrize("F,chunk,bs,n_ref,per,lut", [(12, 2, 1, 1, 4, True), (12, 2, 3, 1, 6, True), (16, 4, 2, 1, 4, False), (24, 4, 6, 3, 12, True),
-                                                      (20, 4, 1, 1, 8, True), (8, 1, 1, 1, 1, True)])
-def test_staged_pipeline_equals_the_sequential_chain(ops, dev, F, chunk, bs, n_ref, per, lut):
-    """The staged form of grain -> (LUT) -> colour match -> sharpen (csrc/vrg_stage.hip): one launch per pipeline stage whose workgroups run
-    pass 1 of frame range s, the torch-order statistics of range s-1 and pass 2 of range s-2.  Every role is the device code of its
-    stand-alone kernel, ranges are whole RNG chunks / statistics calls / reference groups: output bits and the generator afterwards equal
-    the sequential form's -- for every block shape of the statistics ((256,2) / (128,4) / (64,8)), with and without a LUT stage, a ragged
-    last range, single-frame ranges, and a reference batch."""
-    data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")
-    x = _rand((F, 96, 128, 3), 411).to(dev)
-    ref = _rand((n_ref, 30, 40, 3), 412).to(dev)
-    ref_ms = ops.reference_stats(ref)
-    spec = ops.ChainSpec(grain=(0.05, 0.4, chunk), lut=(dlut, 8.0) if lut else None, colormatch=(ref_ms, 0.9), sharpen=("unsharp", 0.6, False), cm_chunk=bs)
-    gen = torch.cuda.default_generators[dev.index]
-    torch.manual_seed(19)
-    want = ops.fused_chain(x, spec, overlap_pieces=1)                       # sequential passes
-    off_want = gen.get_offset()
-    ev = []
-    torch.manual_seed(19)
-    got = ops.fused_chain(x, spec, stage_frames=per, kernel_events=ev)
-    torch.cuda.synchronize()
-    assert gen.get_offset() == off_want
-    n_ranges = -(-F // per)
-    assert [n for n, *_ in ev] == ["stage"] * (n_ranges + 2), [n for n, *_ in ev]       # really staged (not the fallback)
-    assert_bit_equal(got, want, f"staged pipeline, {n_ranges} ranges of {per} frames, vs sequential passes")
-    # and against the oracle composition (colour match evaluated by torch on the device)
-    torch.manual_seed(19)
-    o = R.fast_film_grain(x.cpu(), 0.05, 0.4, chunk, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
-    if lut:
-        o = R.apply_lut_with_strength(o, data, 8.0)
-    if n_ref == 1:
-        o = R.unsharp(R.color_match(o.to(dev), ref, 0.9, bs).cpu(), 0.6, False)
-        assert_bit_equal(got, o, "staged pipeline vs the oracle composition")
-
-
 def test_first_use_of_the_per_process_caches_from_several_host_threads(pkg, ops, dev):
     """The small per-process caches (side streams, the device-statistics self-check, the HIP event pool, the LUT cache) are created on first
     use; several host threads hitting that first use at the same moment must neither fail nor change a result."""
@@ -2261,7 +2190,7 @@ def test_first_use_of_the_per_process_caches_from_several_host_threads(pkg, ops,
 
     want = work()
     with ops._STATE_LOCK:
-        ops._SIDE_STREAMS.clear(); ops._PIPE_STREAMS.clear(); ops._TS_CHECKED.clear(); ops.HipEvent._pool.clear()
+        ops._SIDE_STREAMS.clear(); ops._TS_CHECKED.clear(); ops.HipEvent._pool.clear()
     iv.VRGDG_LUTS._LUT_CACHE = {}
     got, errors = [None] * 6, []
     gate = threading.Barrier(6)

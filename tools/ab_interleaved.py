@@ -94,6 +94,11 @@ def run_case(case):
         return {"chain3_video": timed(lambda: chain3(xv))}
     if case == "grain_lut":
         return {"grain_lut": timed(lambda: grain_lut(x))}
+    if case == "grain_sharpen":
+        def gs():
+            gen.manual_seed(5)
+            ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), sharpen=("unsharp", 0.5, False)), generator=gen, out=out)
+        return {"grain_sharpen": timed(gs)}
     if case == "chain4":
         return {"chain4." + k: v for k, v in chain4_passes().items()}
     if case == "kernels":
@@ -141,7 +146,7 @@ for k, per in times.items():
         noise = max(row[n]["spread_pct"], b["spread_pct"])
         row[n]["vs_" + base_name + "_pct"] = round(delta, 2)
         row[n]["verdict"] = ("inside the spread: no winner" if abs(delta) <= noise else (f"{n} faster" if delta < 0 else f"{base_name} faster"))
-    if k.startswith("chain3") or k == "grain_lut":
+    if k.startswith("chain3") or k in ("grain_lut", "grain_sharpen"):
         for n in row:
             row[n]["gpix_s"] = round(px / row[n]["median_ms"] / 1e6, 2)
     report["metrics"][k] = row

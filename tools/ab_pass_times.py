@@ -61,4 +61,4 @@ for it in range(iters + 2):
         tot["wall"] = w0.elapsed_ms(w1)
         for k, v in tot.items():
             acc.setdefault(k, []).append(v)
-print(os.environ.get("VRGDG_HIP_LIB", "default"), which, "pieces=" + os.environ.get("VRGDG_CM_PIECES", "auto"), "stats_pieces=" + os.environ.get("VRGDG_CM_STATS_PIECES", "auto"), "stage_frames=" + os.environ.get("VRGDG_CM_STAGE_FRAMES", "auto"), "variant=" + os.environ.get("VRGDG_VARIANT", "0"), {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})
+print(os.environ.get("VRGDG_HIP_LIB", "default"), which, "variant=" + os.environ.get("VRGDG_VARIANT", "0"), {k: (round(statistics.median(v), 3), round(min(v), 3)) for k, v in acc.items()})

@@ -1,20 +1,52 @@
-"""Build an A/B variant of libvrgdg_hip.so with extra compiler flags / defines: tools/ab/lib_<name>.so
-    python tools/build_variant.py b -fno-slp-vectorize
-Used with VRGDG_HIP_LIB=tools/ab/lib_<name>.so (tools/ab_libs.sh)."""
-import os, subprocess, sys
+"""Build an A/B variant of libvrgdg_hip.so: tools/ab/lib_<name>.so
+    python tools/build_variant.py b -fno-slp-vectorize                               (every unit with the extra flags)
+    python tools/build_variant.py c --unit vrg_march.hip -DVRG_MARCH_ROTATE=0        (only that unit rebuilt; the others linked from csrc/.obj)
+    python tools/build_variant.py d --unit vrg_march.hip --source tools/ab/old.hip --no-unit-flags -mllvm -amdgpu-sched-strategy=max-ilp
+--source: compile this file in the unit's place (it must sit in csrc/ or include its headers by absolute path: it is copied into csrc/ under a
+temporary name); --no-unit-flags: drop build_ext.EXTRA_FLAGS of the unit (give the wanted ones explicitly).
+Used with tools/ab_interleaved.py --libs name=tools/ab/lib_<name>.so,..."""
+import os, shutil, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "comfyui-vrgamedevgirl_amd"))
 import build_ext as be
-name, extra = sys.argv[1], sys.argv[2:]
+args = sys.argv[1:]
+name = args.pop(0)
+unit = source = None
+unit_flags = True
+if "--unit" in args:
+    i = args.index("--unit"); unit = args[i + 1]; del args[i:i + 2]
+if "--source" in args:
+    i = args.index("--source"); source = args[i + 1]; del args[i:i + 2]
+if "--no-unit-flags" in args:
+    args.remove("--no-unit-flags"); unit_flags = False
+extra = args
 out_dir = os.path.join(ROOT, "tools", "ab")
 obj_dir = os.path.join(out_dir, "obj_" + name)
 os.makedirs(obj_dir, exist_ok=True)
-cflags = [f for f in be.HIPCC_FLAGS if f != "-shared"] + extra
+cflags = [f for f in be.HIPCC_FLAGS if f != "-shared"]
+be.build(verbose=False)                      # the default objects exist and are current
+
+
 def one(src):
+    if unit is not None and src != unit:
+        return os.path.join(be.CSRC, ".obj", src + ".o")
     obj = os.path.join(obj_dir, src + ".o")
-    subprocess.run([be._hipcc(), *cflags, *be.EXTRA_FLAGS.get(src, ()), "-I", be.INCLUDE, "-c", os.path.join(be.CSRC, src), "-o", obj], check=True)
+    path = os.path.join(be.CSRC, src)
+    tmp = None
+    if source is not None and src == unit:
+        tmp = os.path.join(be.CSRC, f"_variant_{name}_{src}")
+        shutil.copyfile(os.path.join(ROOT, source) if not os.path.isabs(source) else source, tmp)
+        path = tmp
+    try:
+        flags = list(be.EXTRA_FLAGS.get(src, ())) if (unit_flags or src != unit) else []
+        subprocess.run([be._hipcc(), *cflags, *flags, *extra, "-I", be.INCLUDE, "-x", "hip", "-c", path, "-o", obj], check=True)
+    finally:
+        if tmp:
+            os.remove(tmp)
     return obj
+
+
 with ThreadPoolExecutor(8) as pool:
     objs = list(pool.map(one, be.SOURCES))
 lib = os.path.join(out_dir, f"lib_{name}.so")
