@@ -340,9 +340,9 @@ def main():
                 # device statistics = torch's own reduction over the WHOLE reference frame: every rank evaluates it (no exchange), on
                 # the side stream -- only the apply pass needs it, pass 1 of the batch runs meanwhile
                 if args.sync_ref:
-                    ref_ms = ops.reference_stats(ref, cm_math)
+                    ref_ms = ops.reference_stats(ref, cm_math, step_frames=frames)
                 else:
-                    ref_ms, ref_ev = ops.reference_stats_async(ref, cm_math)
+                    ref_ms, ref_ev = ops.reference_stats_async(ref, cm_math, step_frames=frames)
             else:
                 # fp64 (n, mean, M2): rows split across the ranks + all-reduce over RCCL (BASELINE configs[4])
                 if kernel_events is not None:
@@ -462,7 +462,7 @@ def main():
     try:
         if traffic is not None or args.workload not in ("chain4_4k", "chain3_4k"):      # the PMC passes cover these two workloads' kernels
             raise StopIteration
-        tj, tname = _profile_json("r02_pmc_traffic_fetch_write.json", "r01_pmc_traffic_fetch_write.json")
+        tj, tname = _profile_json("r04_pmc_traffic_fetch_write.json", "r03_pmc_traffic_fetch_write.json", "r02_pmc_traffic_fetch_write.json")
         summ = tj.get("summary", {})
         if summ.get(key, {}).get("total"):
             traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
@@ -479,7 +479,7 @@ def main():
     # against the probe's measured peak for plain fp32 / integer ops
     issue = None
     try:
-        recs, iname = _profile_json("r02_pmc_valu_instr_per_px.json", "r01_pmc_valu_instr_per_px.json")
+        recs, iname = _profile_json("r04_pmc_valu_instr_per_px.json", "r03_pmc_valu_instr_per_px.json", "r02_pmc_valu_instr_per_px.json")
         rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
         peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
         # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
@@ -513,7 +513,7 @@ def main():
         ts = []
         for _ in range(4):
             a, b = ops.HipEvent(), ops.HipEvent()
-            a.record(); ops.reference_stats(ref); b.record(); torch.cuda.synchronize()
+            a.record(); ops.reference_stats(ref, step_frames=frames); b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_ms(b))
         ref_ms_per_step = round(sorted(ts[1:])[1], 4)
         if ref_events:

@@ -28,14 +28,17 @@ def compute_device() -> torch.device:
             raise RuntimeError("comfyui-vrgamedevgirl_amd: no AMD GPU visible to PyTorch-ROCm; these nodes are "
                                "MI355X-native and have no CPU path")
         dev = torch.device("cuda", torch.cuda.current_device())
+    if dev.index is None:                          # comfy may hand back torch.device("cuda"): name the device
+        dev = torch.device("cuda", torch.cuda.current_device())
     return dev
 
 
 def compute_devices() -> list:
     """The GPUs a host-fed batch is spread over.  Default: the one compute device.  ``VRGDG_DEVICES=all``: every visible GPU (the node
     path's way to the other seven MI355X of a node: ComfyUI runs its graph in ONE process, so torchrun-style sharding is not available
-    to it); ``VRGDG_DEVICES=0,2,3``: those device indices, the first one being the primary (its generator is the one the reference's
-    torch.randn calls would consume).  An index may repeat (``0,0``: two lanes on one GPU -- how the 1-GPU test box exercises this).
+    to it); ``VRGDG_DEVICES=0,2,3``: those device indices.  The PRIMARY is always ``compute_device()`` -- the nodes reserve their noise
+    from its generator (the one the reference's torch.randn calls would consume) and compare lanes against it -- so a list that does
+    not contain it gets it prepended.  An index may repeat (``0,0``: two lanes on one GPU -- how the 1-GPU test box exercises this).
     GPUs with another CU count than the primary are dropped: the Philox geometry of a randn call depends on it."""
     primary = compute_device()
     spec = os.environ.get("VRGDG_DEVICES", "").strip().lower()
@@ -47,7 +50,9 @@ def compute_devices() -> list:
         idx = [int(v) for v in spec.split(",") if v.strip() != ""]
         if not idx or any(i < 0 or i >= torch.cuda.device_count() for i in idx):
             raise ValueError(f"VRGDG_DEVICES={spec!r}: expected 'all' or a comma-separated list of visible device indices")
-    cus = torch.cuda.get_device_properties(idx[0]).multi_processor_count
+        if primary.index not in idx:
+            idx = [primary.index] + idx
+    cus = torch.cuda.get_device_properties(primary.index).multi_processor_count
     return [torch.device("cuda", i) for i in idx if torch.cuda.get_device_properties(i).multi_processor_count == cus]
 
 
@@ -119,6 +124,93 @@ class _Staging:
 _STAGING = _Staging()
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Adjacent nodes of this pack in one graph: ComfyUI hands node B the very tensor object node A returned.  A's result still
+# exists on the GPU when its download finishes, so the device copy is kept (bounded, weakly keyed by the CPU tensor) and B
+# skips its upload: grain -> LUT -> colour match -> unsharp pays 1 upload + 4 downloads instead of 4 + 4.  The reference's
+# contract is untouched (nodes.py:50, 61, 64-66: CPU tensors in, CPU tensors out); results and generator state are the
+# same bits -- B reads the frames A wrote, from HBM instead of over PCIe.
+#   * keyed by the CPU tensor OBJECT (weak reference: the device copy dies with it) and validated by data pointer, shape,
+#     dtype and torch's version counter: an in-place change of the intermediate bumps `_version` and B uploads as before;
+#   * bounded: VRGDG_DEVICE_CACHE_GB (default 8) GiB of device copies, oldest dropped first; 0 disables;
+#   * the nodes never write their input frames, so a cached copy can feed any number of readers.
+# ------------------------------------------------------------------------------------------------------------
+DEVICE_CACHE_BYTES = int(float(os.environ.get("VRGDG_DEVICE_CACHE_GB", "8")) * (1 << 30))
+
+
+class _DeviceCopies:
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.entries = {}          # id(cpu tensor) -> dict(ref, ptr, shape, dtype, version, device, pieces=[(s, e, gpu, event)], nbytes)
+        self.order = []            # ids, oldest first
+        self.hits = 0
+        self.misses = 0
+
+    def _drop(self, key):
+        ent = self.entries.pop(key, None)
+        if ent is not None and key in self.order:
+            self.order.remove(key)
+
+    def remember(self, cpu: torch.Tensor, device: torch.device, pieces):
+        import weakref
+        nbytes = sum(int(g.numel()) * g.element_size() for _, _, g, _ in pieces)
+        if DEVICE_CACHE_BYTES <= 0 or nbytes > DEVICE_CACHE_BYTES:
+            return
+        key = id(cpu)
+        with self.lock:
+            self._drop(key)
+            total = sum(e["nbytes"] for e in self.entries.values())
+            while self.order and total + nbytes > DEVICE_CACHE_BYTES:
+                old = self.order[0]
+                total -= self.entries[old]["nbytes"]
+                self._drop(old)
+
+            def gone(_ref, key=key):
+                with self.lock:
+                    self._drop(key)
+            self.entries[key] = {"ref": weakref.ref(cpu, gone), "ptr": cpu.data_ptr(), "shape": tuple(cpu.shape), "dtype": cpu.dtype,
+                                 "version": cpu._version, "device": device, "pieces": pieces, "nbytes": nbytes}
+            self.order.append(key)
+
+    def lookup(self, cpu: torch.Tensor, device: torch.device):
+        """The device pieces of `cpu` if it is, unchanged, a result this process downloaded from `device`; else None."""
+        if DEVICE_CACHE_BYTES <= 0:
+            return None
+        with self.lock:
+            ent = self.entries.get(id(cpu))
+            ok = (ent is not None and ent["ref"]() is cpu and ent["ptr"] == cpu.data_ptr() and ent["shape"] == tuple(cpu.shape) and
+                  ent["dtype"] == cpu.dtype and ent["version"] == cpu._version and ent["device"] == device)
+            if not ok:
+                if ent is not None:
+                    self._drop(id(cpu))           # changed since the download: the device copy is stale
+                self.misses += 1
+                return None
+            self.hits += 1
+            self.order.remove(id(cpu))
+            self.order.append(id(cpu))
+            return ent["pieces"]
+
+    def clear(self):
+        with self.lock:
+            self.entries.clear()
+            self.order.clear()
+
+
+_DEVICE_COPIES = _DeviceCopies()
+
+
+def _device_frames(pieces, s: int, e: int, compute):
+    """Frames [s, e) out of cached device pieces [(ps, pe, gpu, ran_event)] on stream `compute`: a view when one piece holds them,
+    one device-side concatenation otherwise."""
+    parts = []
+    for ps, pe, gpu, ran in pieces:
+        lo, hi = max(s, ps), min(e, pe)
+        if lo < hi:
+            compute.wait_event(ran)
+            parts.append(gpu[lo - ps:hi - ps])
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+
 def piece_frames(n_frames: int, frame_bytes: int, multiple_of: int = 1) -> int:
     per = max(1, PIPE_BYTES // max(frame_bytes, 1))
     per = max(multiple_of, (per // multiple_of) * multiple_of)
@@ -168,6 +260,8 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
     per = piece_frames(F, max(in_fb, out_fb), multiple_of)
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
     n_lanes = min(len(devices), len(pieces))
+    cached = _DEVICE_COPIES.lookup(images, devices[0]) if n_lanes == 1 else None      # an unchanged result of a previous node: already in HBM
+    produced = []
     with _STAGING.lock:
         lanes = []
         seen = {}
@@ -201,18 +295,24 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
             if len(pending) == depth:           # bounds the device memory in flight; frees ring slot k
                 retire(pending.pop(0))
             with torch.cuda.device(dev):
-                with torch.cuda.stream(h2d):
-                    # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
-                    # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
-                    # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
-                    # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
-                    # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
-                    # than the copy.
-                    gpu_in = images[s:e].to(dev, non_blocking=True)
-                    up = torch.cuda.Event()
-                    up.record(h2d)
+                up = None
+                if cached is not None:
+                    with torch.cuda.stream(compute):
+                        gpu_in = _device_frames(cached, s, e, compute)       # the previous node's result, still in HBM: no upload
+                else:
+                    with torch.cuda.stream(h2d):
+                        # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
+                        # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
+                        # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
+                        # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
+                        # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
+                        # than the copy.
+                        gpu_in = images[s:e].to(dev, non_blocking=True)
+                        up = torch.cuda.Event()
+                        up.record(h2d)
                 with torch.cuda.stream(compute):
-                    compute.wait_event(up)
+                    if up is not None:
+                        compute.wait_event(up)
                     gpu_out = fn(gpu_in, s)                             # kernels on this lane's compute stream
                     if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
                         gpu_out = gpu_out.to(out_dtype).contiguous()
@@ -227,7 +327,11 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                     done = torch.cuda.Event()
                     done.record(d2h)
             pending.append((k, s, e, done, (gpu_in, gpu_out)))      # tensors stay referenced until their DMA retired
+            if n_lanes == 1:
+                produced.append((s, e, gpu_out, ran))
         while pending:
             retire(pending.pop(0))
         # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
+    if n_lanes == 1 and produced:
+        _DEVICE_COPIES.remember(out, devices[0], produced)       # the next node of this pack may be handed `out`: its frames are still in HBM
     return out

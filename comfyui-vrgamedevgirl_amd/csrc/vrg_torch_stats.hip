@@ -181,7 +181,10 @@ __global__ void __launch_bounds__(64) k_tstats_rows_finish(const TsRows* __restr
 // mean accumulators.  The six Welford waves walk the same 1.5 KB of the interleaved image per step (each uses 4 of every 24 bytes,
 // together all of them), so the CU's L1 fetches every line once and the workgroup streams 1/8 of the frame.  The reciprocal of the
 // running count -- the same number for every lane, known before any data -- comes from an LDS table {(float)k, RN(1 / k)} filled once
-// per workgroup with the IEEE division (k <= TS_LANES_MAX_STEPS).  Per-thread accumulators go to a scratch record; the finishing
+// per workgroup with the IEEE division (k <= TS_LANES_MAX_STEPS; a table in global memory read with scalar loads measured 1.17 ms instead of 0.78).
+// 65 KB of LDS and 250 VGPRs per workgroup: this is the LATENCY form -- it wins when the GPU is otherwise idle (the statistics of the reference frame of a
+// SMALL step: 4 / 8 / 16 frames per step 2.0 / 2.8 / 4.5 ms against 2.4 / 3.4 / 5.0) and loses beside a full-size pass 1 (64 frames: 16.8 against 14.4 ms:
+// it cannot be placed until pass 1 drains, then delays pass 2), so it is chosen by the CALLER (vrg_lab_stats_torch_lat_f32), never automatically.  Per-thread accumulators go to a scratch record; the finishing
 // kernel (512 threads per frame = torch's block) combines accumulators 0 and 1 of each thread and runs block_x_reduce /
 // block_y_reduce / project exactly as ts_frame_part does.  Same update arithmetic (ts_welf_update, Markstein division behind the
 // range flag, IEEE repeat of the workgroup when the flag is raised), same order: bit-identical.
@@ -191,10 +194,13 @@ struct TsLanes { TsLaneRec w[3][2][512]; float m[3][512]; };
 constexpr int TS_LANES_MAX_STEPS = 16384;            // table entries (LDS: 8 bytes each) -- frames up to 16.7 M pixels
 
 #ifndef VRG_TS_LANES_DEPTH
-#define VRG_TS_LANES_DEPTH 32     /* Welford steps (one 4-byte load per lane each) requested ahead: the chain is short now, the loop is bound by HBM latency / depth */
+#define VRG_TS_LANES_DEPTH 8      /* Welford steps (one 4-byte load per lane each) requested ahead.  8 = a 12 KB window shared by the six Welford waves in the CU's 32 KB L1; 16 / 32 / 48 measured SLOWER (0.95 / 0.91 / 2.3 ms per 4K frame against 0.76-0.79: the window falls out of the L1, then out of the registers) -- profiles/r04_bench_stats_lanes_depths.json */
 #endif
 #ifndef VRG_TS_LANES_MEAN_DEPTH
-#define VRG_TS_LANES_MEAN_DEPTH 12   /* mean rounds (48 bytes per lane each) requested ahead */
+#define VRG_TS_LANES_MEAN_DEPTH 12   /* mean rounds (48 bytes per lane each) requested ahead (16: more than 256 registers, 2.1 ms) */
+#endif
+#ifndef VRG_TS_LANES_MAX_FRAMES
+#define VRG_TS_LANES_MAX_FRAMES 2    /* one 4K frame 0.78 ms against the half-block form's 1.12 (-30 %); 4-16 frames: equal; 32: the half-block form wins (1.25 against 1.6) */
 #endif
 
 template <bool FUSED, bool FAST, int DEPTH>
@@ -240,7 +246,7 @@ static __device__ __forceinline__ bool ts_lane_chain(const float* __restrict__ u
 
 template <int DEPTH>
 __global__ void __launch_bounds__(448) k_tstats_lanes(const float* __restrict__ lab, int64_t n, int64_t frames, TsLanes* __restrict__ recs) {
-    extern __shared__ __attribute__((aligned(16))) float2 ts_rn_tab[];          // [steps + 1]
+    extern __shared__ __attribute__((aligned(16))) float2 ts_rn_tab[];          // [steps + 1]: {(float)(k + 1), RN(1 / (k + 1))}
     // workgroup w -> XCD w % 8: frame f = (w % 8) + 8 * (w / 64), thread group j = (w / 8) % 8: a frame's eight workgroups share an L2
     const int64_t w = blockIdx.x;
     const int64_t f = (w & 7) + 8 * (w >> 6);
@@ -421,7 +427,7 @@ constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 constexpr int64_t TS_ROWS_MAX_FRAMES = VRG_TS_ROWS_MAX_FRAMES;
 
 static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, int num_mp, void* scratch, int64_t scratch_bytes,
-                           hipStream_t st) {
+                           hipStream_t st, bool prefer_lanes = false) {
     if (count <= 0 || b <= 0) return VRG_OK;
     const int64_t O = (int64_t)b * 3;
     const float factor = (float)O / (float)(O * n);                  // static_cast<float>(num_output_elements) / numel, of the WHOLE call
@@ -448,7 +454,7 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
 #ifndef VRG_TS_LANES
 #define VRG_TS_LANES 1
 #endif
-        if (VRG_TS_LANES && frames <= TS_ROWS_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsLanes) && cm.bh == cw.bh &&
+        if (VRG_TS_LANES && prefer_lanes && frames <= VRG_TS_LANES_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsLanes) && cm.bh == cw.bh &&
             n / 1024 + 2 <= TS_LANES_MAX_STEPS && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
             // one accumulator per lane: eight 7-wave workgroups per frame + torch's block as the finishing kernel
             TsLanes* recs = reinterpret_cast<TsLanes*>(scratch);
@@ -492,7 +498,7 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
 
 extern "C" int64_t vrg_lab_stats_torch_scratch_bytes(int64_t frames) {
     if (frames <= 0 || frames > vrg::TS_ROWS_MAX_FRAMES) return 0;       // only the small-batch forms use a scratch buffer
-    return frames * (int64_t)(sizeof(vrg::TsLanes) > sizeof(vrg::TsRows) ? sizeof(vrg::TsLanes) : sizeof(vrg::TsRows));
+    return frames * (int64_t)(sizeof(vrg::TsLanes) > sizeof(vrg::TsRows) ? sizeof(vrg::TsLanes) : sizeof(vrg::TsRows));       // the larger of the two small-batch forms' records
 }
 
 extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
@@ -500,8 +506,21 @@ extern "C" int vrg_lab_stats_torch_f32(const float* lab, int64_t frames, int32_t
     return vrg_lab_stats_torch_ws_f32(lab, frames, height, width, chunk_frames, mean_std, eps, nullptr, 0, stream);
 }
 
+static int lab_stats_torch_any(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames, float* mean_std, float eps, void* scratch,
+                               int64_t scratch_bytes, void* stream, bool prefer_lanes);
+
 extern "C" int vrg_lab_stats_torch_ws_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
                                           float* mean_std, float eps, void* scratch, int64_t scratch_bytes, void* stream) {
+    return lab_stats_torch_any(lab, frames, height, width, chunk_frames, mean_std, eps, scratch, scratch_bytes, stream, false);
+}
+
+extern "C" int vrg_lab_stats_torch_lat_f32(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames,
+                                           float* mean_std, float eps, void* scratch, int64_t scratch_bytes, void* stream) {
+    return lab_stats_torch_any(lab, frames, height, width, chunk_frames, mean_std, eps, scratch, scratch_bytes, stream, true);
+}
+
+static int lab_stats_torch_any(const float* lab, int64_t frames, int32_t height, int32_t width, int32_t chunk_frames, float* mean_std, float eps, void* scratch,
+                               int64_t scratch_bytes, void* stream, bool prefer_lanes) {
     using namespace vrg;
     if (frames < 0 || height <= 0 || width <= 0 || chunk_frames <= 0) return VRG_ERR_BAD_ARG;
     if (frames == 0) return VRG_OK;
@@ -519,9 +538,9 @@ extern "C" int vrg_lab_stats_torch_ws_f32(const float* lab, int64_t frames, int3
     hipStream_t st = (hipStream_t)stream;
     const int64_t full = frames / chunk_frames;
     const int tail = (int)(frames % chunk_frames);
-    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, cus, scratch, scratch_bytes, st);
+    int rc = ts_launch_calls(lab, n, full, chunk_frames, eps, mean_std, cus, scratch, scratch_bytes, st, prefer_lanes);
     if (rc != VRG_OK) return rc;
-    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, scratch, scratch_bytes, st);
+    if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, scratch, scratch_bytes, st, prefer_lanes);
     return rc;
 }
 

@@ -121,7 +121,10 @@ class ColorMatchToReference:
                 for b in sizes:
                     expand += [f] * n_ref if b == 1 else list(range(f, f + b))
                     f += b
-        ref_ms, ref_ready = ops.reference_stats_async(ref)      # side stream: only the apply pass of the first group waits for it
+        # side stream: only the apply pass of the first group waits for it.  Host frames: the GPU idles while the first piece crosses
+        # PCIe, so the reduction takes its latency form; device frames: only steps of few frames leave it the room (ops.SMALL_STEP_FRAMES)
+        step_frames = frames if images.is_cuda else 0
+        ref_ms, ref_ready = ops.reference_stats_async(ref, step_frames=step_frames)
         # The statistics of a chunk are ONE torch reduction call over its frames (nodes.py:109-110): the call sizes shape the
         # device statistics (ops.CM_STATS), so every piece streamed through the GPU is made of whole calls.
         if n_ref == 1:
@@ -149,7 +152,7 @@ class ColorMatchToReference:
         def run_on(device):
             if device == dev:
                 return run
-            ms_d, ready_d = ops.reference_stats_async(ref.to(device))        # every GPU reduces the reference frame itself: same bits
+            ms_d, ready_d = ops.reference_stats_async(ref.to(device), step_frames=step_frames)   # every GPU reduces the reference frame itself: same bits
 
             def run_d(gpu_frames, first):
                 return ops.color_match(gpu_frames, None, match_strength, ref_ms=ms_d, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),

@@ -659,14 +659,16 @@ def device_stats_selfcheck(device, force: bool = False) -> bool:
                 _hip.check(_hip.lib().vrg_lab_stats_torch_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got), _f32(0.0), _hip.current_stream()),
                            "vrg_lab_stats_torch_f32")
                 ok = ok and torch.equal(got, want)
-                # the form production takes (lab_stats_device): with a scratch buffer small batches run the one-accumulator-per-lane kernels
+                # the forms production takes (lab_stats_device): with a scratch buffer, the throughput entry and the latency entry
+                # (one accumulator per lane, <= 2 frames per call)
                 nbytes = int(_hip.lib().vrg_lab_stats_torch_scratch_bytes(F))
                 if nbytes:
                     scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=probe.device)
-                    got2 = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
-                    _hip.check(_hip.lib().vrg_lab_stats_torch_ws_f32(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got2), _f32(0.0), _hip.ptr(scratch), nbytes,
-                                                                     _hip.current_stream()), "vrg_lab_stats_torch_ws_f32")
-                    ok = ok and torch.equal(got2, want)
+                    for name in ("vrg_lab_stats_torch_ws_f32", "vrg_lab_stats_torch_lat_f32"):
+                        got2 = torch.empty((F, 3, 2), dtype=torch.float32, device=probe.device)
+                        _hip.check(getattr(_hip.lib(), name)(_hip.ptr(probe), F, H, W, calls, _hip.ptr(got2), _f32(0.0), _hip.ptr(scratch), nbytes,
+                                                             _hip.current_stream()), name)
+                        ok = ok and torch.equal(got2, want)
     with _STATE_LOCK:
         first = key not in _TS_CHECKED
         _TS_CHECKED[key] = ok
@@ -694,10 +696,12 @@ def _device_stats_selfcheck(device) -> None:
 
 
 @_on_device
-def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Optional[torch.Tensor] = None, latency_form: bool = False) -> torch.Tensor:
     """fp32 ``[F, 3, 2]`` = (mean, unbiased std + eps) of an interleaved Lab image ``[F,H,W,3]`` with the BITS
     ``lab.mean(dim=[2,3])`` / ``lab.std(dim=[2,3]) + 1e-5`` have when torch evaluates them on this GPU for ``chunks`` frames per
-    call (nodes.py:99-100, 109-110).  include/vrgdg_hip.h: vrg_lab_stats_torch_f32."""
+    call (nodes.py:99-100, 109-110).  include/vrgdg_hip.h: vrg_lab_stats_torch_f32.  `latency_form`: allow the one-accumulator-per-lane
+    kernels for calls of at most two frames (vrg_lab_stats_torch_lat_f32) -- faster on an otherwise idle GPU, slower beside a full-size
+    pass; same bits."""
     x = _check_frames(lab, "lab", channels=3)
     F, H, W, _ = x.shape
     ms = out if out is not None else torch.empty((F, 3, 2), dtype=torch.float32, device=x.device)
@@ -712,15 +716,22 @@ def lab_stats_device(lab: torch.Tensor, chunks=1, eps: float = 1e-5, out: Option
     for f0, nf, c in _chunk_runs(F, chunks):
         nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(nf))      # small batches: the half-block form wants a scratch buffer (0: another form)
         scratch = torch.empty((nbytes + 15) // 16 * 4, dtype=torch.float32, device=x.device) if nbytes else None
-        _hip.check(lib.vrg_lab_stats_torch_ws_f32(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c, C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps),
-                                                 _hip.ptr(scratch) if scratch is not None else None, nbytes, _hip.current_stream()),
-                   "vrg_lab_stats_torch_ws_f32")
+        entry = lib.vrg_lab_stats_torch_lat_f32 if latency_form else lib.vrg_lab_stats_torch_ws_f32
+        _hip.check(entry(C.c_void_p(x.data_ptr() + f0 * fe * 4), nf, H, W, c, C.c_void_p(ms.data_ptr() + f0 * 24), _f32(eps),
+                         _hip.ptr(scratch) if scratch is not None else None, nbytes, _hip.current_stream()),
+                   "vrg_lab_stats_torch_lat_f32" if latency_form else "vrg_lab_stats_torch_ws_f32")
     return ms
 
 
-def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None) -> torch.Tensor:
+#: steps of at most this many frames take the latency form of the reference frame's statistics (measured: 4 / 8 / 16 frames per step
+#: 2.0 / 2.8 / 4.5 ms against 2.4 / 3.4 / 5.0; 32 / 64 frames 8.4 / 16.8 against 8.0 / 14.4 -- profiles/r04_frames_table_*.json)
+SMALL_STEP_FRAMES = 16
+
+
+def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None, step_frames: Optional[int] = None) -> torch.Tensor:
     """fp32 ``[R, 3, 2]`` (mean, std + 1e-5) of the reference frame(s) (nodes.py:98-100): one reduction call over the whole
-    reference batch with the device statistics."""
+    reference batch with the device statistics.  `step_frames`: how many frames the step these statistics belong to processes, if the
+    caller knows -- small steps leave the GPU idle and take the latency form of the reduction (SMALL_STEP_FRAMES)."""
     ref = _check_frames(reference_image, "reference_image", channels=3)
     if _cm_stats(cm_stats, cm_math, ref.device) == "fp64":
         return finalize_stats(lab_stats(ref, cm_math))
@@ -730,7 +741,7 @@ def reference_stats(reference_image: torch.Tensor, cm_math=None, cm_stats=None) 
         d = _chain_desc(ChainSpec(cm_math=cm_math), None, [], ref)
         _hip.check(_hip.lib().vrg_chain_stats_lab_f32(_hip.ptr(ref), _hip.ptr(lab), Rn, H, W, C.byref(d), None, None, _hip.current_stream()),
                    "vrg_chain_stats_lab_f32")        # the Lab image only
-    return lab_stats_device(lab, max(int(Rn), 1))
+    return lab_stats_device(lab, max(int(Rn), 1), latency_form=step_frames is not None and int(step_frames) <= SMALL_STEP_FRAMES)
 
 
 _SIDE_STREAMS = {}
@@ -750,7 +761,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 
 
 @_on_device
-def reference_stats_async(reference_image: torch.Tensor, cm_math=None, cm_stats=None):
+def reference_stats_async(reference_image: torch.Tensor, cm_math=None, cm_stats=None, step_frames: Optional[int] = None):
     """reference_stats on the side stream: returns (ref_ms, event).  The reference frame's statistics are one latency-bound chain
     (16,200 dependent Welford updates per accumulator for a 4K frame: 1.5-2 ms on a handful of workgroups) that only the APPLY pass
     needs -- give `event` to ChainSpec.cm_ref_event and pass 1 of the batch runs meanwhile."""
@@ -758,7 +769,7 @@ def reference_stats_async(reference_image: torch.Tensor, cm_math=None, cm_stats=
     side = _side_stream(reference_image.device)
     side.wait_stream(main)                         # the reference frame may have been produced on the caller's stream
     with torch.cuda.stream(side):
-        ref_ms = reference_stats(reference_image, cm_math, cm_stats)
+        ref_ms = reference_stats(reference_image, cm_math, cm_stats, step_frames=step_frames)
         ev = torch.cuda.Event()
         ev.record(side)
     ref_ms.record_stream(main)

@@ -52,10 +52,11 @@ def test_versions_and_error_strings(hip):
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8
     assert lib.vrg_lab_stats_scratch_bytes(-1) == 0
-    # the torch-order statistics want a scratch buffer only for the batches their half-block form takes (<= 32 frames): 0 = another form
-    per = lib.vrg_lab_stats_torch_scratch_bytes(1)
-    assert per > 0 and per % 16 == 0
-    assert lib.vrg_lab_stats_torch_scratch_bytes(32) == 32 * per
+    # the torch-order statistics want a scratch buffer only for the batches their small-batch forms take (<= 32 frames): per-frame records
+    # (sized for the larger of the two record layouts, so either entry point can use it); 0 = another form
+    per = lib.vrg_lab_stats_torch_scratch_bytes(32) // 32
+    assert per > 0 and per % 16 == 0 and lib.vrg_lab_stats_torch_scratch_bytes(32) == 32 * per
+    assert lib.vrg_lab_stats_torch_scratch_bytes(3) == 3 * per and lib.vrg_lab_stats_torch_scratch_bytes(1) == per
     assert lib.vrg_lab_stats_torch_scratch_bytes(33) == 0 and lib.vrg_lab_stats_torch_scratch_bytes(0) == 0
 
 

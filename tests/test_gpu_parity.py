@@ -62,7 +62,7 @@ def assert_bit_equal(got, want, what=""):
 def test_native_library_is_loaded(pkg):
     from comfyui_vrgamedevgirl_amd import _hip
     lib = _hip.lib()
-    assert lib.vrg_abi_version() == 5
+    assert lib.vrg_abi_version() == _hip.ABI_VERSION == 6
     with open("/proc/self/maps") as fh:
         assert any("libvrgdg_hip.so" in line for line in fh), "HIP extension not mapped into the process"
     import ctypes as C
@@ -1443,6 +1443,51 @@ def test_pipelined_host_staging_equals_sequential(pkg, dev, monkeypatch):
     assert torch.equal(a, calls["unsharp"]())
 
 
+def test_adjacent_nodes_skip_the_reupload_and_a_mutated_intermediate_is_uploaded_again(pkg, ops, dev):
+    """Two nodes of this pack one after the other in a graph: ComfyUI hands the second the very tensor the first returned, whose frames
+    are still in HBM -- the second node reads them there instead of uploading them again (_devices._DEVICE_COPIES).  Same bits as the
+    plain path, same generator state; an intermediate changed in place (torch's version counter) is uploaded like any other tensor; the
+    device copy dies with the CPU tensor."""
+    import gc
+    from comfyui_vrgamedevgirl_amd import nodes, _devices
+    cache = _devices._DEVICE_COPIES
+    cache.clear()
+    x = _rand((6, 90, 160, 3), 77)
+    gen = torch.cuda.default_generators[dev.index]
+    torch.manual_seed(123)
+    a = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0]
+    off = gen.get_offset()
+    assert a.device.type == "cpu" and id(a) in cache.entries
+    h0, m0 = cache.hits, cache.misses
+    b = nodes.FastUnsharpSharpen().apply_unsharp(a, 0.7, False)[0]              # the frames of `a` are taken from HBM
+    assert cache.hits == h0 + 1 and gen.get_offset() == off
+    plain = nodes.FastUnsharpSharpen().apply_unsharp(a.clone(), 0.7, False)[0]  # a copy is a tensor the cache has never seen: uploaded
+    assert cache.misses >= m0 + 1 and torch.equal(b, plain)
+    c = nodes.ColorMatchToReference().match_color(b, x[:1], 0.8, 2)[0]          # a third node on the second one's result: another hit
+    assert cache.hits == h0 + 2
+    assert torch.equal(c, nodes.ColorMatchToReference().match_color(b.clone(), x[:1], 0.8, 2)[0])
+    a[0, 0, 0, 0] += 0.25                                                          # in-place change of the intermediate
+    h1 = cache.hits
+    d = nodes.FastUnsharpSharpen().apply_unsharp(a, 0.7, False)[0]
+    assert cache.hits == h1 and id(a) not in cache.entries                      # stale copy dropped, frames uploaded
+    assert torch.equal(d, nodes.FastUnsharpSharpen().apply_unsharp(a.clone(), 0.7, False)[0]) and not torch.equal(d, b)
+    key = id(b)
+    assert key in cache.entries
+    del b
+    gc.collect()
+    assert key not in cache.entries                                             # the device copy goes with the CPU tensor
+    old = _devices.DEVICE_CACHE_BYTES
+    try:
+        _devices.DEVICE_CACHE_BYTES = 0                                          # VRGDG_DEVICE_CACHE_GB=0: nothing is kept
+        cache.clear()
+        e = nodes.FastUnsharpSharpen().apply_unsharp(x, 0.7, False)[0]
+        assert not cache.entries and torch.equal(nodes.FastUnsharpSharpen().apply_unsharp(e, 0.7, False)[0],
+                                                 nodes.FastUnsharpSharpen().apply_unsharp(e.clone(), 0.7, False)[0])
+    finally:
+        _devices.DEVICE_CACHE_BYTES = old
+        cache.clear()
+
+
 def test_enhancer_loop_stays_on_gpu_between_uint8_edges(pkg, dev):
     """decode -> _frames_to_tensor -> _process_with_retry -> _tensor_to_frames (VRGDG_StandaloneVideoEnhancerNodes.py:405-420
     of the reference): frames cross PCIe as uint8, the fp32 tensor never leaves the GPU, result == oracle from the bytes up."""
@@ -2133,27 +2178,32 @@ def test_node_path_over_several_gpu_lanes_equals_one_device(pkg, dev, monkeypatc
 
 
 @pytest.mark.parametrize("F,H,W,b", [(1, 64, 3840, 1), (5, 8, 3840, 1), (6, 8, 3840, 2), (9, 8, 3840, 3), (32, 4, 3840, 1), (40, 4, 3840, 1), (12, 270, 480, 6),
-                                     (2, 2160, 3840, 1)])
+                                     (2, 2160, 3840, 1), (1, 2160, 3840, 1), (2, 270, 482, 2), (1, 1, 2052, 1), (2, 31, 1028, 1), (2, 64, 3840, 2)])
 def test_device_statistics_forms_agree_with_torch(pkg, ops, dev, F, H, W, b):
-    """The three whole-frame forms of the statistics replay -- eight half-block workgroups per frame + finishing kernel (<= 32 frames,
-    scratch supplied), four workgroups per frame (<= 64 frames), one workgroup per frame -- against torch's mean / std on the device,
-    for every block shape ((256,2) / (128,4) / (64,8) = batch_size 1 / 2 / >= 3) and ragged last calls."""
+    """The whole-frame forms of the statistics replay -- one accumulator per lane (seven-wave workgroups owning 64 of torch's threads,
+    <= 2 frames, scratch supplied, through the latency entry point only: the reference frame of a small step; steps that only some
+    threads take, both block shapes), eight
+    half-block workgroups per frame + finishing kernel (<= 32 frames, scratch supplied), four workgroups per frame (<= 64 frames), one
+    workgroup per frame -- against torch's mean / std on the device, for every block shape ((256,2) / (128,4) / (64,8) = batch_size
+    1 / 2 / >= 3) and ragged last calls."""
     import ctypes as C
     from comfyui_vrgamedevgirl_amd import _hip
     lab = (_rand((F, H, W, 3), 700 + F) * 130.0 - 45.0).to(dev)
     want = _torch_reductions(lab, b)
     lib = _hip.lib()
-    for with_scratch in (True, False):
+    for entry, with_scratch in (("vrg_lab_stats_torch_ws_f32", True), ("vrg_lab_stats_torch_lat_f32", True), ("vrg_lab_stats_torch_ws_f32", False),
+                                ("vrg_lab_stats_torch_lat_f32", False)):
         got = torch.empty((F, 3, 2), device=dev)
         nbytes = int(lib.vrg_lab_stats_torch_scratch_bytes(F)) if with_scratch else 0
         scratch = torch.empty(max(nbytes // 4, 4), device=dev) if with_scratch else None
-        _hip.check(lib.vrg_lab_stats_torch_ws_f32(_hip.ptr(lab), F, H, W, b, _hip.ptr(got), ops._f32(1e-5), _hip.ptr(scratch) if with_scratch else None,
-                                                 nbytes, _hip.current_stream()), "vrg_lab_stats_torch_ws_f32")
-        assert _same_bits_or_nan(got, want), (with_scratch, (got - want).abs().max())
+        _hip.check(getattr(lib, entry)(_hip.ptr(lab), F, H, W, b, _hip.ptr(got), ops._f32(1e-5), _hip.ptr(scratch) if with_scratch else None,
+                                       nbytes, _hip.current_stream()), entry)
+        assert _same_bits_or_nan(got, want), (entry, with_scratch, (got - want).abs().max())
     assert _same_bits_or_nan(ops.lab_stats_device(lab, b), want)
+    assert _same_bits_or_nan(ops.lab_stats_device(lab, b, latency_form=True), want)
 
 
-@pytest.mark.parametrize("F,b,scale", [(3, 1, 1e-33), (6, 2, 1e-36), (66, 1, 1e-33), (40, 1, 3e37), (4, 1, 1.0)])
+@pytest.mark.parametrize("F,b,scale", [(3, 1, 1e-33), (6, 2, 1e-36), (66, 1, 1e-33), (40, 1, 3e37), (4, 1, 1.0), (1, 1, 1e-33), (2, 2, 3e37), (2, 1, 1e-36)])
 def test_device_statistics_markstein_fallback(pkg, ops, dev, F, b, scale):
     """The whole-frame statistics kernels divide by the running count with Markstein's sequence (reciprocal off the dependent chain),
     proven equal to the IEEE quotient for 2^-100 <= |delta| <= 2^100; a workgroup that meets another delta repeats its frame with the
@@ -2163,8 +2213,11 @@ def test_device_statistics_markstein_fallback(pkg, ops, dev, F, b, scale):
     if scale == 1.0:
         lab[1, 3, 17, 2] = float("nan")
         lab[2, 0, 0, 0] = float("inf")
+    if F <= 2 and scale < 1.0:
+        lab[0, 2, 100, 1] = float("nan")               # the one-accumulator-per-lane form (<= 2 frames) meets a NaN as well
     want = _torch_reductions(lab, b)
     assert _same_bits_or_nan(ops.lab_stats_device(lab, b), want)
+    assert _same_bits_or_nan(ops.lab_stats_device(lab, b, latency_form=True), want)
     import ctypes as C
     from comfyui_vrgamedevgirl_amd import _hip
     got = torch.empty((F, 3, 2), device=dev)          # and the forms that take no scratch buffer

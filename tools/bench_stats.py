@@ -11,8 +11,9 @@ ap.add_argument("--libs", required=True)
 ap.add_argument("--frames", default="1,2,4,8,16,32")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--json", default="")
+ap.add_argument("--forms", default="throughput,latency", help="vrg_lab_stats_torch_ws_f32 / vrg_lab_stats_torch_lat_f32")
 a = ap.parse_args()
-libs = [(i.split("=", 1)[0], _hip.load_library(os.path.abspath(i.split("=", 1)[1]))) for i in a.libs.split(",")]
+libs = [(i.split("=", 1)[0] + ":" + f, _hip.load_library(os.path.abspath(i.split("=", 1)[1])), f == "latency") for i in a.libs.split(",") for f in a.forms.split(",")]
 dev = torch.device("cuda", 0)
 H, W = 2160, 3840
 g = torch.Generator(device=dev).manual_seed(7)
@@ -21,19 +22,19 @@ lab = torch.rand((Fmax, H, W, 3), generator=g, device=dev) * 100.0 - 30.0
 rows = []
 for F in [int(f) for f in a.frames.split(",")]:
     x = lab[:F]
-    outs, ts = {}, {n: [] for n, _ in libs}
+    outs, ts = {}, {n: [] for n, _, _ in libs}
     for rnd in range(a.rounds + 1):
-        for n, lib in libs:
+        for n, lib, lat in libs:
             _hip._lib = lib
             e0, e1 = ops.HipEvent(), ops.HipEvent()
-            e0.record(); o = ops.lab_stats_device(x, 1); e1.record()
+            e0.record(); o = ops.lab_stats_device(x, 1, latency_form=lat); e1.record()
             t = e0.elapsed_ms(e1)
             if rnd == 0:
                 outs[n] = o.clone()
             else:
                 ts[n].append(t)
     want = torch.stack([x.permute(0, 3, 1, 2).contiguous().mean(dim=[2, 3]), x.permute(0, 3, 1, 2).contiguous().std(dim=[2, 3]) + 1e-5], dim=-1)
-    for n, _ in libs:
+    for n, _, _ in libs:
         med = statistics.median(ts[n])
         rows.append({"frames": F, "lib": n, "ms_median": round(med, 4), "ms_min": round(min(ts[n]), 4), "ms_max": round(max(ts[n]), 4),
                      "spread_pct": round(100 * (max(ts[n]) - min(ts[n])) / med, 1), "equals_torch": bool(torch.equal(outs[n], want))})

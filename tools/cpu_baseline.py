@@ -1,5 +1,5 @@
 """CPU baseline of the reference's own nodes on THIS box's host cores (the build container has the reference checkout):
-per node and the chains of BASELINE.json's configs, warm-up 1, median of 3.  Writes profiles/r02_cpu_baseline_buildbox.json.
+per node and the chains of BASELINE.json's configs, warm-up 1, median of 3.  Writes profiles/r04_cpu_baseline_buildbox.json.
 
     python tools/cpu_baseline.py [frames_4k] [frames_1080p]
 """
@@ -22,4 +22,4 @@ for label, (H, W, n) in {"4K": (2160, 3840, f4k), "1080p": (1080, 1920, f1080)}.
         row.update({"size": label, "chain": "+".join(stages)})
         out["rows"].append(row)
         print(json.dumps(row), flush=True)
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_buildbox.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_buildbox.json"), "w"), indent=1)
