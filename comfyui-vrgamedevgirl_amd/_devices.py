@@ -5,6 +5,8 @@ from __future__ import annotations
 import os
 import threading
 
+import time
+
 import torch
 
 #: upper bound of one host->device staging transfer (bytes of fp32 frames) -- sequential fallback path
@@ -241,6 +243,63 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
     return _stream_frames_on(devices, fns, images, multiple_of, out_dtype)
 
 
+#: Pageable input frames: "ring" = this pack copies them into a page-locked ring with several host threads (vrg_host_copy) and uploads
+#: from there asynchronously; "runtime" = the HIP runtime's own pageable copy, which starts only when everything queued on the device
+#: has drained -- upload, kernels and download then run one after the other (profiles/r04_host_fed_timeline_runtime_pageable.json).
+PAGEABLE_UPLOAD = os.environ.get("VRGDG_PAGEABLE_UPLOAD", "ring")
+#: host threads of one staging copy, bytes of one ring slot, ring slots
+STAGE_THREADS = int(os.environ.get("VRGDG_STAGE_THREADS", "8"))
+STAGE_CHUNK_BYTES = 64 << 20
+STAGE_SLOTS = 4
+
+
+class _UploadRing:
+    """Page-locked ring the pageable pieces of one call go through: copy a chunk in with the host threads, upload it asynchronously,
+    reuse the slot once that upload has finished."""
+
+    def __init__(self, staging, lane_key):
+        self.slots = [staging.pinned(("in", lane_key, k), STAGE_CHUNK_BYTES) for k in range(STAGE_SLOTS)]
+        self.busy = [None] * STAGE_SLOTS
+        self.n = 0
+
+    def upload(self, src: torch.Tensor, dev: torch.device, h2d) -> tuple:
+        """`src`: contiguous CPU frames.  Returns (device tensor, event after its last chunk) -- the copies are queued on `h2d`."""
+        from . import _hip
+        lib = _hip.lib()
+        nbytes = src.numel() * src.element_size()
+        with torch.cuda.stream(h2d):
+            gpu = torch.empty(src.shape, dtype=src.dtype, device=dev)
+            flat = gpu.view(-1).view(torch.uint8)
+            base = src.data_ptr()
+            ev = None
+            for off in range(0, nbytes, STAGE_CHUNK_BYTES):
+                n = min(STAGE_CHUNK_BYTES, nbytes - off)
+                k = self.n % STAGE_SLOTS
+                self.n += 1
+                if self.busy[k] is not None:
+                    self.busy[k].synchronize()
+                _hip.check(lib.vrg_host_copy(self.slots[k].data_ptr(), base + off, n, STAGE_THREADS), "vrg_host_copy")
+                flat[off:off + n].copy_(self.slots[k][:n], non_blocking=True)
+                ev = _event()
+                ev.record(h2d)
+                self.busy[k] = ev
+        return gpu, ev
+
+    def drain(self):
+        for ev in self.busy:
+            if ev is not None:
+                ev.synchronize()
+
+
+#: tools/host_fed_timeline.py sets this to a list: one (piece, host seconds before / after the upload call, upload / kernels / download events)
+#: entry per piece, events with timing
+_TRACE = None
+
+
+def _event():
+    return torch.cuda.Event(enable_timing=_TRACE is not None)
+
+
 def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
     images = images.contiguous()
     F = int(images.shape[0])
@@ -273,6 +332,8 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
             lanes.append((dev, h2d, d2h, torch.cuda.current_stream(dev) if k == 0 else own, fns[li]))
         depth = min(PIPE_DEPTH * n_lanes, len(pieces))
         ring = None if pin_out else [_STAGING.pinned(("out", k), per * out_fb) for k in range(depth)]
+        stage_in = cached is None and PAGEABLE_UPLOAD == "ring" and images.device.type == "cpu" and not images.is_pinned()
+        in_rings = [_UploadRing(_STAGING, li) for li in range(n_lanes)] if stage_in else None
         pending = []                    # (slot, s, e, d2h_done_event, keep_alive)
         caller = torch.cuda.current_stream(lanes[0][0])
         for li in range(1, n_lanes):    # further lanes start after whatever the caller's stream has queued (the frames may depend on it)
@@ -300,16 +361,20 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                     with torch.cuda.stream(compute):
                         gpu_in = _device_frames(cached, s, e, compute)       # the previous node's result, still in HBM: no upload
                 else:
-                    with torch.cuda.stream(h2d):
-                        # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms
-                        # for 16 4K frames in and out, both PCIe directions busy.  Pageable sources block this host thread
-                        # for their copy (the runtime stages them at the full 56 GB/s) while the other two streams keep
-                        # working: 57 ms.  Staging them through an own page-locked ring was measured slower and erratic
-                        # (host memcpy next to two active DMA engines: 15-90 GB/s), page-locking them in place costs more
-                        # than the copy.
-                        gpu_in = images[s:e].to(dev, non_blocking=True)
-                        up = torch.cuda.Event()
-                        up.record(h2d)
+                    t0 = time.perf_counter()
+                    if stage_in:
+                        # Pageable frames through this pack's page-locked ring (PAGEABLE_UPLOAD): the host threads copy while the
+                        # previous piece uploads, runs and downloads.
+                        gpu_in, up = in_rings[i % n_lanes].upload(images[s:e], dev, h2d)
+                    else:
+                        # Page-locked sources (e.g. the result of a previous node of this pack) upload asynchronously: 36 ms for
+                        # 16 4K frames in and out, both PCIe directions busy.  VRGDG_PAGEABLE_UPLOAD=runtime: pageable sources
+                        # block this host thread for the runtime's copy, which also waits for the device to drain: 57 ms.
+                        with torch.cuda.stream(h2d):
+                            gpu_in = images[s:e].to(dev, non_blocking=True)
+                            up = _event()
+                            up.record(h2d)
+                    t1 = time.perf_counter()
                 with torch.cuda.stream(compute):
                     if up is not None:
                         compute.wait_event(up)
@@ -317,20 +382,25 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                     if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
                         gpu_out = gpu_out.to(out_dtype).contiguous()
                     gpu_in.record_stream(compute)
-                    ran = torch.cuda.Event()
+                    ran = _event()
                     ran.record(compute)
                 dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
                 with torch.cuda.stream(d2h):
                     d2h.wait_event(ran)
                     dst.copy_(gpu_out, non_blocking=True)
                     gpu_out.record_stream(d2h)
-                    done = torch.cuda.Event()
+                    done = _event()
                     done.record(d2h)
+            if _TRACE is not None and up is not None:
+                _TRACE.append((i, t0, t1, up, ran, done))
             pending.append((k, s, e, done, (gpu_in, gpu_out)))      # tensors stay referenced until their DMA retired
             if n_lanes == 1:
                 produced.append((s, e, gpu_out, ran))
         while pending:
             retire(pending.pop(0))
+        if in_rings is not None:
+            for r in in_rings:
+                r.drain()
         # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
     if n_lanes == 1 and produced:
         _DEVICE_COPIES.remember(out, devices[0], produced)       # the next node of this pack may be handed `out`: its frames are still in HBM

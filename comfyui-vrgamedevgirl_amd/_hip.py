@@ -90,6 +90,7 @@ _SIGNATURES = {
     "vrg_lab_stats_finalize": (C.c_int, [_P, _P, C.c_int64, _P]),
     "vrg_lab_stats_torch_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P]),
     "vrg_lab_stats_torch_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "vrg_host_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32]),
     "vrg_lab_stats_torch_ws_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, C.c_int64, _P]),
     "vrg_lab_stats_torch_lat_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, C.c_int64, _P]),
     "vrg_stats_allreduce_scratch_bytes": (C.c_int64, [C.c_int64]),

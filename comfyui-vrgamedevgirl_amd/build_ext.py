@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
 STAMP = LIB_PATH + ".stamp"
 
 SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_adjust.hip",
-           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip", "vrg_probe.hip")
+           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip", "vrg_probe.hip", "vrg_host.hip")
 HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
            "vrg_ziv_log_table.inc", "vrg_produce_body.hpp", "vrg_apply_body.hpp", "vrg_tstats_body.hpp")
 
@@ -109,7 +109,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl"]      # vrg_collective.hip: dlopen / dlsym (RCCL at run time)
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl", "-pthread"]      # vrg_collective.hip: dlopen / dlsym (RCCL at run time)
     if verbose:
         print("[vrgdg-amd] linking:", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

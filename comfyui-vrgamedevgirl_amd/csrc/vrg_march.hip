@@ -31,7 +31,7 @@
 #define VRG_MARCH_FINITE 1    /* behind a LUT stage the rows are finite values in [0, 1]: the mean's Inf / NaN pass-through and the final clamp's NaN pass-through of the steady rows are dropped (same bits for finite data) */
 #endif
 #ifndef VRG_MARCH_ABLATE
-#define VRG_MARCH_ABLATE 0    /* TIMING ABLATIONS of the steady rows (wrong pixels; tools/build_variant.py): 1 = no table reads (same arithmetic on register values), 2 = no noise synthesis */
+#define VRG_MARCH_ABLATE 0    /* TIMING ABLATIONS of the steady rows (wrong pixels; tools/build_variant.py): 1 = no table reads (same arithmetic on register values), 2 = no noise synthesis, 4 = the non-steady rows of a fast wave skipped */
 #endif
 #ifndef VRG_MARCH_QUAD
 #define VRG_MARCH_QUAD 1      /* steady rows: the LUT gathers as quad-cooperative LDS-DMA (see lut_issue_dma) instead of six 16-byte loads per lane */
@@ -197,9 +197,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
         float nz[3][4], nx[2][4];
         bool fast = false;
         const int b0 = rowbase - q0s;
+#ifndef VRG_MARCH_EDGE_SHARED
+#define VRG_MARCH_EDGE_SHARED 1   /* rows that leave the Philox quarter (priming rows, the ragged first / last row): shared calls of the neighbouring quarter instead of one call per element */
+#endif
+        // Rows that are not wholly inside the job's Philox quarter.  Element `rel` (relative to sibling m's quarter) below 0 lies in the
+        // PREVIOUS quarter -- component m - 1 of the same call for m >= 1, component 3 of call k - 1 for m = 0, subsequence rel + G --, at or
+        // above G in the NEXT one (component m + 1, or component 0 of call k + 1 for m = 3, subsequence rel - G): the same sharing as in
+        // the quarter, so three calls per lane at the shifted subsequences and three at the neighbouring call index feed all four siblings
+        // (a ragged row adds the quarter's own three) instead of twelve per-element calls, each behind a 64-bit division.  A row never
+        // reaches both neighbours (G >> 193).  Pixels outside the chunk (k = 0 / the last call) get garbage that `valid` discards.
+        bool shared_edge = false;
+        float nzb[3][4];
         if (STAGES & VRG_STAGE_GRAIN) {
             fast = (b0 >= 0) && ((uint32_t)(b0 + 3 * 63 + 4) < G);
-            if (fast) {
+            const bool own = (b0 + 3 * 63 + 4 >= 0) && (b0 < (int)G);        // some element of the row lies in the quarter
+            if (fast || (VRG_MARCH_EDGE_SHARED && own)) {
                 const uint32_t idx0 = (uint32_t)b0 + 3u * (uint32_t)lane;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -208,10 +220,32 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     const f32x2 b = box_muller(r.z, r.w);
                     nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = b.x; nz[j][3] = b.y;
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { nz[j][0] = 0.0f; nz[j][1] = 0.0f; nz[j][2] = 0.0f; nz[j][3] = 0.0f; }
+            }
+            if (fast) {
 #pragma unroll
                 for (int m = 1; m < 4; ++m) {
                     nx[0][m] = lane_next(nz[0][m]);
                     nx[1][m] = lane_next(nz[1][m]);
+                }
+            } else if (VRG_MARCH_EDGE_SHARED) {
+                shared_edge = true;
+                const bool prev = b0 < 0;                                       // wave-uniform: the row reaches into the previous quarter (else the next)
+                const uint32_t idxb = (uint32_t)b0 + (prev ? G : 0u - G) + 3u * (uint32_t)lane;
+                const uint64_t ctr_far = prev ? ctr - 1 : ctr + 1;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u32x4 r = philox_for(seed, idxb + j, ctr);
+                    const f32x2 a = box_muller(r.x, r.y);
+                    const f32x2 b = box_muller(r.z, r.w);
+                    const u32x4 rf = philox_for(seed, idxb + j, ctr_far);
+                    const float far = normal_component(rf, prev ? 3 : 0);
+                    nzb[j][0] = prev ? far : a.y;
+                    nzb[j][1] = prev ? a.x : b.x;
+                    nzb[j][2] = prev ? a.y : b.y;
+                    nzb[j][3] = prev ? b.x : far;
                 }
             }
         }
@@ -233,6 +267,23 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                         n[0] = nz[1][m]; n[1] = nz[2][m]; n[2] = nx[0][m];
                     } else {
                         n[0] = nz[2][m]; n[1] = nx[0][m]; n[2] = nx[1][m];
+                    }
+                } else if (shared_edge) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        // s_m is wave-uniform but not a compile-time constant here: both alignments of the element, selected
+                        float own_v[3], far_v[3];
+#pragma unroll
+                        for (int sft = 0; sft < 3; ++sft) {
+                            const int p = sft + c, j = p % 3;
+                            own_v[sft] = p >= 3 ? lane_next(nz[j][m]) : nz[j][m];
+                            far_v[sft] = p >= 3 ? lane_next(nzb[j][m]) : nzb[j][m];
+                        }
+                        const int sm = M.s[m];
+                        const float o_ = sm == 0 ? own_v[0] : (sm == 1 ? own_v[1] : own_v[2]);
+                        const float f_ = sm == 0 ? far_v[0] : (sm == 1 ? far_v[1] : far_v[2]);
+                        const bool inq = (uint32_t)(b0 + 3 * lane + sm + c) < G;
+                        n[c] = inq ? o_ : f_;
                     }
                 } else if (valid[m]) {
 #pragma unroll
@@ -376,6 +427,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
             }
         }
         if (!steady) {
+            if (!((VRG_MARCH_ABLATE & 4) && fast_wave))       // timing ablation: the non-steady rows of a fast wave are skipped (wrong pixels)
             general_row(rho, rowbase);
             ++rho;
             rowbase += E;

@@ -113,7 +113,26 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch_r4(const px3* __restrict_
     const int nc = n - 1;
     const int cell = (B.cell * nc + G.cell) * n + R.cell;
     float acc = 0.0f;
-    if (MODE == 9 || MODE == 10) {
+    if (MODE >= 13) {
+        // the six 16-byte pieces per lane (mode 0's requests) with cache-policy bits on the loads: 13 none (the inline-assembly baseline),
+        // 14 sc0, 15 sc1, 16 nt, 17 sc0 sc1, 18 sc0 sc1 nt -- does any of them make the L1 ask the L2 for less than a whole 128-byte line?
+        const float* q = cells + (size_t)cell * 12;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f t[6];
+#define VRG_DBG_LD(BITS)                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                \
+            asm volatile("global_load_dwordx4 %0, %1, off " BITS : "=&v"(t[i]) : "v"(q + 4 * i) : "memory");
+        if (MODE == 13) { VRG_DBG_LD("") }
+        else if (MODE == 14) { VRG_DBG_LD("sc0") }
+        else if (MODE == 15) { VRG_DBG_LD("sc1") }
+        else if (MODE == 16) { VRG_DBG_LD("nt") }
+        else if (MODE == 17) { VRG_DBG_LD("sc0 sc1") }
+        else { VRG_DBG_LD("sc0 sc1 nt") }
+#undef VRG_DBG_LD
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc += (t[i].x + t[i].y) + (t[i].z + t[i].w);
+    } else if (MODE == 9 || MODE == 10) {
         const f32x4* q = reinterpret_cast<const f32x4*>(cells + (size_t)cell * 12);
         const f32x4 t = q[0];
         acc += (t.x + t.y) + (t.z + t.w);
@@ -451,7 +470,7 @@ int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float 
 }
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
-    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 12) return VRG_ERR_BAD_ARG;
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 18) return VRG_ERR_BAD_ARG;
     const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
     const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
     if (mode >= 9) {
@@ -459,7 +478,13 @@ int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float
             case 9: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<9>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
             case 10: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<10>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
             case 11: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<11>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
-            default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<12>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 12: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<12>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 13: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<13>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 14: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<14>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 15: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<15>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 16: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 17: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<17>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<18>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
         }
         VRG_CHECK_LAUNCH();
         return VRG_OK;

@@ -325,6 +325,15 @@ int vrg_event_record(void* ev, void* stream);
 int vrg_event_elapsed_ms(void* start, void* stop, float* ms);
 int vrg_event_destroy(void* ev);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Host side of the node path (reference: nodes.py:50, 61-66 -- CPU tensors in, `images.to(device)` per batch)
+ * ------------------------------------------------------------------------------------------- */
+/* memcpy of `bytes` from `src` to `dst` (host pointers, not overlapping) split over `threads` host threads (0 = 8; at most 64; parts of
+ * whole pages, none below 2 MiB).  The node layer stages pageable frames into a page-locked ring with it, so that upload, kernels and
+ * download of a pageable batch overlap like those of a page-locked one.  Blocks until the bytes are there.  No device work. */
+int vrg_host_copy(void* dst, const void* src, int64_t bytes, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,3 +94,21 @@ def test_argument_validation_without_device(hip):
     cd = hip.ChainDesc(stages=8, variant=99, stencil_op=0, border=0)
     assert lib.vrg_fused_chain_f32(one, one, 1, 4, 4, C.byref(cd), null) == 2                    # unknown variant
     assert lib.vrg_fused_chain_f32(one, one, 0, 4, 4, C.byref(cd), null) == 0
+
+
+def test_host_copy_splits_over_threads_and_validates(hip):
+    """vrg_host_copy: the staging copy of pageable frames (no device involved): every byte arrives for sizes around the part and page
+    boundaries and any thread count; nothing beyond `bytes` is written; bad arguments are refused."""
+    import torch
+    lib = hip.load_library()
+    src = torch.randint(0, 256, ((5 << 21) + 4099,), dtype=torch.uint8)
+    for nbytes in (0, 1, 4095, 4096, (1 << 21) - 1, (1 << 21) + 1, (4 << 21) + 8191, src.numel()):
+        for threads in (0, 1, 2, 5, 64, 1000):
+            dst = torch.full((src.numel() + 64,), 7, dtype=torch.uint8)
+            assert lib.vrg_host_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, threads) == 0
+            assert torch.equal(dst[:nbytes], src[:nbytes]), (nbytes, threads)
+            assert int(dst[nbytes:].min()) == 7 and int(dst[nbytes:].max()) == 7, (nbytes, threads)
+    one = C.c_void_p(16)
+    assert lib.vrg_host_copy(None, one, 8, 1) == 1 and lib.vrg_host_copy(one, None, 8, 1) == 1
+    assert lib.vrg_host_copy(one, one, -1, 1) == 1 and lib.vrg_host_copy(one, one, 8, -2) == 1
+    assert lib.vrg_host_copy(None, None, 0, 0) == 0

@@ -1443,6 +1443,49 @@ def test_pipelined_host_staging_equals_sequential(pkg, dev, monkeypatch):
     assert torch.equal(a, calls["unsharp"]())
 
 
+def test_pageable_frames_through_the_page_locked_ring_equal_the_runtime_copy(pkg, dev, monkeypatch):
+    """Pageable input frames reach the GPU through this pack's page-locked ring (_devices._UploadRing: vrg_host_copy with several host
+    threads, then asynchronous uploads) or through the runtime's own pageable copy (VRGDG_PAGEABLE_UPLOAD=runtime), page-locked ones
+    directly: the same results and generator state every way -- with ring slots smaller than a piece, larger than the whole batch, and
+    of a size that divides neither frames nor pieces; uint8 frames (byte counts off every alignment) as well."""
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+    x = _rand((7, 45, 83, 3), 521)
+    ref = _rand((1, 20, 30, 3), 522)
+    frame_bytes = x[0].numel() * 4
+    calls = {"grain": lambda t: nodes.FastFilmGrain().apply_grain(t, 0.05, 0.5, 2)[0],
+             "colour match": lambda t: nodes.ColorMatchToReference().match_color(t, ref, 0.8, 1)[0],
+             "unsharp": lambda t: nodes.FastUnsharpSharpen().apply_unsharp(t, 0.7, False)[0]}
+    monkeypatch.setattr(_devices, "PIPE_BYTES", frame_bytes * 2)
+    monkeypatch.setattr(_devices, "DEVICE_CACHE_BYTES", 0)
+    want = {}
+    for name, fn in calls.items():
+        monkeypatch.setattr(_devices, "PAGEABLE_UPLOAD", "runtime")
+        torch.manual_seed(77)
+        want[name] = (fn(x), torch.cuda.get_rng_state(dev))
+    monkeypatch.setattr(_devices, "PAGEABLE_UPLOAD", "ring")
+    for chunk in (4099, frame_bytes, frame_bytes * 3 // 2 + 4, 64 << 20):
+        monkeypatch.setattr(_devices, "STAGE_CHUNK_BYTES", chunk)
+        _devices._STAGING.buffers.clear()
+        for threads in (1, 3):
+            monkeypatch.setattr(_devices, "STAGE_THREADS", threads)
+            for name, fn in calls.items():
+                torch.manual_seed(77)
+                got = fn(x)
+                assert torch.equal(got, want[name][0]), (name, chunk, threads)
+                assert torch.equal(torch.cuda.get_rng_state(dev), want[name][1]), (name, chunk)
+    torch.manual_seed(77)
+    assert torch.equal(calls["grain"](x.pin_memory()), want["grain"][0])
+    # bytes: the route the stand-alone enhancer feeds (frames as uint8) -- 45 * 83 * 3 bytes per frame, a multiple of nothing
+    u8 = (x * 255.0).to(torch.uint8)
+    double = lambda g, first: g.to(torch.int16).mul(2).clamp(max=255).to(torch.uint8)
+    monkeypatch.setattr(_devices, "STAGE_CHUNK_BYTES", 10007)
+    _devices._STAGING.buffers.clear()
+    monkeypatch.setattr(_devices, "PIPE_BYTES", u8[0].numel() * 3)
+    got = _devices.stream_frames(u8, double)
+    assert got.dtype == torch.uint8 and torch.equal(got, (u8.to(torch.int16) * 2).clamp(max=255).to(torch.uint8))
+    _devices._STAGING.buffers.clear()
+
+
 def test_adjacent_nodes_skip_the_reupload_and_a_mutated_intermediate_is_uploaded_again(pkg, ops, dev):
     """Two nodes of this pack one after the other in a graph: ComfyUI hands the second the very tensor the first returned, whose frames
     are still in HBM -- the second node reads them there instead of uploading them again (_devices._DEVICE_COPIES).  Same bits as the

@@ -13,7 +13,8 @@ cp $E/prof_chain4_4k/trace_kernel_stats.csv profiles/${R}_bench_chain4_rocprofv3
 cp $E/prof_chain3_4k/trace_kernel_stats.csv profiles/${R}_bench_chain3_rocprofv3_kernel_stats.csv
 cp gpurun_out/traffic_${TAG}/traffic.json profiles/${R}_pmc_traffic_fetch_write.json
 cp gpurun_out/issue_${TAG}/summary.json profiles/${R}_pmc_valu_instr_per_px.json
-cp $E/pmc_summary.txt profiles/${R}_pmc_stall_summary_chain3_chain4_chain4fast.txt
+[ -f $E/pmc_summary.txt ] && cp $E/pmc_summary.txt profiles/${R}_pmc_stall_summary_chain3_chain4_chain4fast.txt
 cp $E/diag.json profiles/${R}_diag_kernels.json
 cp gpurun_out/cm_test_measured.json profiles/${R}_cm_test_measured.json
+for f in frames_table host_fed_nodes u8_enhancer ab_r03_r04; do [ -f $E/$f.json ] && cp $E/$f.json profiles/${R}_$f.json; done
 ls -la profiles | grep ${R}_ | wc -l
