@@ -797,13 +797,14 @@ VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
 // condition holds for every argument: |e ln2 + T_j| >= |r - r^2/2| whenever the former is not zero (e != 0: >= 0.28; e == 0: the
 // table's smallest non-zero |T_j| is 0.0078 against max |r| 0.0051 in those intervals -- asserted for every (e, j) by
 // tools/make_ziv_log_table.py), and |r| >= r^2/2.
-VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out) {
+VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out, float& A_out) {
     const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
     const float ef = (float)(d >> 23);
     const uint32_t off = (uint32_t)d & 0x007fffffu;
     const float m = f32_from_bits(off + 0x3f2aaaabu);                // [2/3, 4/3)
     const float* t = T + ((off >> 16) << 2);
     const float c = t[0], th = t[1], tl = t[2];
+    A_out = t[3];
     const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (7-bit c)
     const float Eh = ef * f32_from_bits(0x3f317200u);                // e * ln2 head (15 bits: exact product)
     const float h = r * r;
@@ -829,25 +830,38 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 }
 
 // Half-width of the interval that contains ocml's y ln x around this function's: y * |ln x (ocml) - ln x (table)|.  The two
-// logarithms are deterministic functions of x, so their distance has an exact maximum over a finite domain; measured over
-// EVERY fp32 of [0.0031308, 4] (tools/ziv_log_accuracy.py, profiles/): 2^-34.73 max(|e ln2|, |ln x|) and 2^-36.00 absolute --
-// almost all of it ocml's own error (its epln is good to 2^-34.7, the table log to 2^-37.3).  The bounds below are those
-// maxima times 1.25 (the +-delta additions and ocml's own last roundings are five orders of magnitude smaller).
-VRG_HD float ziv_delta(float y, float Lh, float Eh) {
+// logarithms are deterministic functions of x, so their distance has an exact maximum over a finite domain.  Almost all of it is
+// ocml's own error (its epln is good to 2^-34.7, the table log to 2^-37.3), a smooth function of m: the table's T_lo_j carries the
+// midpoint of that distance over the arguments with table index j (so the table tracks OCML's logarithm), and its fourth word A_j =
+// 1.25 x the largest distance left for index j, measured over EVERY fp32 of [0.0031308, 4] (tools/ziv_per_index.py ->
+// tools/ziv_calibration.json; 2^-38.8 for the median index, 2^-36.2 for the worst, where one global bound used to stand at
+// 2^-35.7).  Near x = 1 -- the indexes around m = 1 carry no bias -- the distance is relative to |ln x|: the second bound, 1.25 x the
+// measured global maximum relative to max(|e ln2|, |ln x|) (2^-35.25 with this table).  It is not optional: saturated pixels
+// (v = 1.0 -> q = 0.9999995, 2 % of the lanes of a graded frame) sit there, and without it pass 1 ran the transcription in every
+// wave (VRG_ZIV_REL = 0: 928 instead of 709 instructions per pixel).  (The +-delta additions and ocml's own last roundings are
+// five orders of magnitude smaller.)
+#ifndef VRG_ZIV_REL
+#define VRG_ZIV_REL 1
+#endif
+VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
+#if VRG_ZIV_REL
     const float a = __builtin_fabsf(Lh), b = __builtin_fabsf(Eh);
-    const float rel = (a > b ? a : b) * (y * f32_from_bits(0x2e420300u));          // 2^-34.4
-    const float ab = y * f32_from_bits(0x2d9d9624u);                                // 2^-35.7
-    return rel < ab ? rel : ab;
+    const float rel = (a > b ? a : b) * f32_from_bits(0x2e06f428u);                 // 2^-34.92 = 1.25 x the measured maximum
+    return y * (rel < A ? rel : A);
+#else
+    (void)Lh; (void)Eh;
+    return y * A;
+#endif
 }
 
 // The fast route alone: returns the candidate and whether the rounding test (and the domain test) passed.
 VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float& out) {
-    float Lh, Ll, Eh;
-    ziv_log(x, T, Lh, Ll, Eh);
+    float Lh, Ll, Eh, A;
+    ziv_log(x, T, Lh, Ll, Eh, A);
     const float p17 = y * Lh;
     const float p24 = __builtin_fmaf(y, Lh, -p17);
     const float p44 = __builtin_fmaf(y, Ll, p24);
-    const float delta = ziv_delta(y, Lh, Eh);
+    const float delta = ziv_delta(y, Lh, Eh, A);
     const float up = p44 + delta, dn = p44 - delta;
     const float php = p17 + up;
     const float phm = p17 + dn;

@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ i
     if (i >= n) return;
     if (op >= 16) {          // 16 / 17: ocml's ln x = hi + lo (epln, as transcribed); 18 / 19: dev_pow_ziv's table log
         float a, b;
-        float eh;
-        if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh);
+        float eh, aj;
+        if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh, aj);
         out[i] = (op & 1) ? b : a;
     } else if (op >= 12) {
         // the Lab transforms' powers as they are called there (dev_pow_ziv with each call site's domain): op 12 sRGB -> linear

@@ -19,10 +19,18 @@
 
 namespace vrg {
 
+#ifndef VRG_PRODUCE_MAX_WAVES_LABONLY
+#define VRG_PRODUCE_MAX_WAVES_LABONLY 8   /* cap on the workgroups per CU (= waves per SIMD) of the Lab-only form; 8 = none.  Measured with LDS padding, 64 frames: 4 / 5 / 6 per CU = 8.02 / 7.64 / 7.54 ms (profiles/r04_ab_pass1_occupancy.json): the six that 80 VGPRs allow are the fastest */
+#endif
 template <int STAGES, bool TWO_PART, bool STATS = true>
 __global__ __launch_bounds__(256, TWO_PART ? 1 : (STATS ? VRG_PRODUCE_WAVES : VRG_PRODUCE_WAVES_LABONLY)) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
                                                       const float* __restrict__ pivots, double* __restrict__ rec,
                                                       int32_t* __restrict__ rec_frame) {
+    // optional occupancy cap of the Lab-only form (a launch bound only sets a minimum): unused LDS makes the (N + 1)-th workgroup not fit
+    constexpr int CAP = (!TWO_PART && !STATS) ? VRG_PRODUCE_MAX_WAVES_LABONLY : 8;
+    constexpr int PAD = CAP >= 8 ? 16 : (160 * 1024 / (CAP + 1) + 512 - 14400 > 16 ? 160 * 1024 / (CAP + 1) + 512 - 14400 : 16);
+    __shared__ char occupancy_pad[PAD];
+    if (P.numel < 0) occupancy_pad[threadIdx.x] = (char)blockIdx.x;      // never true: keeps the array
     __shared__ float sn[4][PR_SUB + 4];
     __shared__ double red[STATS ? 4 : 1][12];
     VRG_CM_MATH(PT, true, (STAGES & VRG_STAGE_FASTMATH) != 0, D.dm);
