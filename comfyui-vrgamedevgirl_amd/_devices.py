@@ -250,8 +250,16 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
 #: from there asynchronously; "runtime" = the HIP runtime's own pageable copy, which starts only when everything queued on the device
 #: has drained -- upload, kernels and download then run one after the other (profiles/r04_host_fed_timeline_runtime_pageable.json).
 PAGEABLE_UPLOAD = os.environ.get("VRGDG_PAGEABLE_UPLOAD", "ring")
-#: host threads of one staging copy, bytes of one ring slot, ring slots
-STAGE_THREADS = int(os.environ.get("VRGDG_STAGE_THREADS", "8"))
+#: host threads of one staging copy (8, or the cores this process may run on if fewer), bytes of one ring slot, ring slots
+def _default_stage_threads() -> int:
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, min(8, cores))
+
+
+STAGE_THREADS = int(os.environ.get("VRGDG_STAGE_THREADS", "0")) or _default_stage_threads()
 STAGE_CHUNK_BYTES = 64 << 20
 STAGE_SLOTS = 4
 
