@@ -396,7 +396,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
     // arithmetic and no exec-masked block in the loop, exact memory counters.  Same device functions (philox_for, box_muller,
     // grain_pixel, lut_axis, lut_fetch_finish, unsharp arithmetic) in the same order: bit-identical to the general step.
     // ------------------------------------------------------------------------------------------------------------------------
-    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) && WAVES == 4;
+#ifndef VRG_MARCH_FAST_LDS
+#define VRG_MARCH_FAST_LDS 1    /* the steady-row body for the 12-wave form as well (cube of at most 21^3 staged in LDS: the gathers are eight ds_read_b128 per pixel) */
+#endif
+    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) &&
+                           (WAVES == 4 || (VRG_MARCH_FAST_LDS != 0 && (STAGES & VRG_STAGE_LUT)));
     bool fast_wave = false;
     if (FASTP) {
         bool ok = M.s[0] == 0 && M.s[1] == 1 && M.s[2] == 2 && M.s[3] == 0 && M.numel < (1 << 29) && D.stencil_op == 0 &&
@@ -556,6 +560,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                         return;
                     }
                     if (QUADP) { lut_issue_dma(m); return; }
+                    if ((STAGES & VRG_STAGE_LUT) && WAVES != 4) {       // node table in LDS: the eight corners of the cell, laid out as the record form has them
+                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                        const int n = P.n, nn = n * n;
+                        const f32x4* t = lut_nodes + ((F[m & 1].B.cell * n + F[m & 1].G.cell) * n + F[m & 1].R.cell);
+                        const f32x4 q000 = t[0], q001 = t[nn], q010 = t[n], q011 = t[nn + n];
+                        const f32x4 q100 = t[1], q101 = t[nn + 1], q110 = t[n + 1], q111 = t[nn + n + 1];
+                        F[m & 1].lo[0] = f32x4{q000.x, q001.x, q010.x, q011.x};  F[m & 1].hi[0] = f32x4{q100.x, q101.x, q110.x, q111.x};
+                        F[m & 1].lo[1] = f32x4{q000.y, q001.y, q010.y, q011.y};  F[m & 1].hi[1] = f32x4{q100.y, q101.y, q110.y, q111.y};
+                        F[m & 1].lo[2] = f32x4{q000.z, q001.z, q010.z, q011.z};  F[m & 1].hi[2] = f32x4{q100.z, q101.z, q110.z, q111.z};
+                        return;
+                    }
                     if (STAGES & VRG_STAGE_LUT) {
                         F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
                         F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
