@@ -110,7 +110,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
     }
     if (WAVES != 4) __syncthreads();
     // LDS landing zone of the quad-cooperative gathers (steady rows, VRG_MARCH_QUAD): per wave two slots of six 1040-byte rounds
-    constexpr bool QUADP = (VRG_MARCH_QUAD != 0) && (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
+#ifndef VRG_MARCH_FAST_FLAT
+#define VRG_MARCH_FAST_FLAT 1    /* the steady-row body for chains WITHOUT a stencil as well (grain -> LUT): no taps, no row history, rows stored as they are computed */
+#endif
+    constexpr bool QUADP = (VRG_MARCH_QUAD != 0) && (VRG_MARCH_FAST != 0) && (SHARPEN || VRG_MARCH_FAST_FLAT) && (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
     constexpr int Q_ROUND = 1040, Q_SLOT = 6 * Q_ROUND;
     __shared__ __attribute__((aligned(16))) char quad_slots[QUADP ? 4 * 2 * Q_SLOT : 16];
 
@@ -399,17 +402,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
 #ifndef VRG_MARCH_FAST_LDS
 #define VRG_MARCH_FAST_LDS 1    /* the steady-row body for the 12-wave form as well (cube of at most 21^3 staged in LDS: the gathers are eight ds_read_b128 per pixel) */
 #endif
-    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && SHARPEN && (STAGES & VRG_STAGE_GRAIN) &&
+    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && (SHARPEN || VRG_MARCH_FAST_FLAT) && (STAGES & VRG_STAGE_GRAIN) &&
                            (WAVES == 4 || (VRG_MARCH_FAST_LDS != 0 && (STAGES & VRG_STAGE_LUT)));
     bool fast_wave = false;
     if (FASTP) {
-        bool ok = M.s[0] == 0 && M.s[1] == 1 && M.s[2] == 2 && M.s[3] == 0 && M.numel < (1 << 29) && D.stencil_op == 0 &&
-                  __builtin_isfinite(D.strength) && r_last - r_first >= 4;
+        bool ok = M.s[0] == 0 && M.s[1] == 1 && M.s[2] == 2 && M.s[3] == 0 && M.numel < (1 << 29) && r_last - r_first >= 4;
+        if (SHARPEN) ok = ok && D.stencil_op == 0 && __builtin_isfinite(D.strength);
         if (STAGES & VRG_STAGE_LUT) ok = ok && D.lut.unit_domain != 0 && D.lut.blend_mode == 1;
+        if (SHARPEN) {                    // without a stencil nothing depends on (x, y): sibling strips may wrap around row ends
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int xlo = __builtin_amdgcn_readfirstlane(xm[m]);
-            ok = ok && __builtin_amdgcn_ballot_w64(xm[m] != xlo + lane) == 0;
+            for (int m = 0; m < 4; ++m) {
+                const int xlo = __builtin_amdgcn_readfirstlane(xm[m]);
+                ok = ok && __builtin_amdgcn_ballot_w64(xm[m] != xlo + lane) == 0;
+            }
         }
         fast_wave = ok;
     }
@@ -419,10 +424,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
         int ysc[4] = {0, 0, 0, 0};
         if (FASTP && fast_wave) {
             const int b0 = rowbase - q0s;
-            steady = rho >= r_first + 2 && b0 - E >= 0 && (uint32_t)(b0 + 3 * 63 + 4) < G && rowbase - E >= 0 &&
-                     (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
-                     (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
-            if (steady) {
+            if (SHARPEN)
+                steady = rho >= r_first + 2 && b0 - E >= 0 && (uint32_t)(b0 + 3 * 63 + 4) < G && rowbase - E >= 0 &&
+                         (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
+                         (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
+            else                          // the row itself inside the quarter and the chunk; the next row's loads addressable
+                steady = b0 >= 0 && (uint32_t)(b0 + 3 * 63 + 4) < G && rowbase >= 0 &&
+                         (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
+                         (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
+            if (steady && SHARPEN) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     ysc[m] = __builtin_amdgcn_readfirstlane(yc[m]);
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     const float x[3] = {xin[m].r, xin[m].g, xin[m].b};
                     grain_pixel(x, nrm[m], D.I, D.S, D.T, V[m]);
                 }
-                const int out_soff = (rowbase - E) * 4;
+                const int out_soff = (SHARPEN ? rowbase - E : rowbase) * 4;
                 // Quad-cooperative LDS-DMA gather (VRG_MARCH_QUAD): a pixel's 96-byte record run is fetched by the FOUR lanes of its quad --
                 // round p = 0..3: the quad's lanes read the first 64 bytes of the run of the quad's pixel p (one 64-byte segment per quad
                 // and instruction: the texture unit looks up ONE tag for the four lanes where the per-lane form looks up four), rounds 4 / 5
@@ -592,7 +602,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     if (STAGES & VRG_STAGE_LUT) lut_fetch_finish(F[m & 1], Dn);
                     float res[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
+                    for (int c = 0; c < (SHARPEN ? 0 : 3); ++c) res[c] = Dn[c];          // no stencil: the row as it is
+#pragma unroll
+                    for (int c = 0; c < (SHARPEN ? 3 : 0); ++c) {
                         // unsharp_value's raster-order sum with the left / right taps taken from the neighbouring lanes
                         float sum = tap_prev(U[m][c]) + U[m][c];
                         sum = tap_next(U[m][c]) + sum;
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                        (int64_t)rowbase + 3ll * (int64_t)G + 3 * 63 < (int64_t)M.numel - 2 &&
                        (int64_t)rowbase + E + 3ll * (int64_t)G + 3 * 63 <= (int64_t)li_max;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < (SHARPEN ? 4 : 0); ++m) {
                     ++ysc[m];
                     more = more && ysc[m] <= H - 1;
                 }
@@ -683,7 +695,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
             for (int m = 0; m < 4; ++m) {
                 yM[m] = yc[m] + rows_done - 1;
                 yc[m] += rows_done;
-                if (yc[m] >= H) { yc[m] -= H; ++fc[m]; }
+                if (SHARPEN) {
+                    if (yc[m] >= H) { yc[m] -= H; ++fc[m]; }
+                } else {
+                    while (yc[m] >= H) { yc[m] -= H; ++fc[m]; }      // without a stencil steady rows run across frame boundaries
+                }
             }
         }
     }
