@@ -7,17 +7,25 @@ Workload (BASELINE.json metric / configs[4] per-GPU shard): every rank holds `--
 4K fp32 RGB frames resident in HBM (generated on device, never touched by the host), chain = Fast Film Grain
 (I=0.04, s=0.5, one torch.randn draw per 4 frames) -> 3D LUT 33^3 (strength 10) -> Color Match to a 4K
 reference frame (k=1) -> Fast Unsharp (0.5, edge-replicate).  A step = one pass of that chain over the rank's
-batch: reference-frame statistics (rows split across ranks + all-reduce when N>1), the statistics pass over the
-batch, and the fused apply pass.  Weak scaling: per-GPU work is fixed, value = all ranks' pixels / max time.
+batch: reference-frame statistics, the statistics pass over the batch, and the fused apply pass.  Weak scaling:
+per-GPU work is fixed, value = all ranks' pixels / max time.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the step, timed with HIP events on the stream
-it is launched on; `cpu_baseline` times the reference's own node classes on the host cores where the reference checkout
-exists (the build container: kind "reference"), otherwise the oracle port of them (kind "port"), on a bounded sample.
+it is launched on: the contract's HBM figures plus the unit that actually binds it (`bound`, `valu_busy_frac`,
+`issue_frac_weighted`).  `configs` (N = 1) holds the other single-GPU BASELINE configs as legs of the same run, each timed
+the way the headline is, on both synthetic pixel distributions: chain3_4k x256 (configs[2]), grain_lut_1080p x128
+(configs[1]), colormatch_4k x512 (configs[3]), and the headline on video-like pixels -- with ms_per_step, Mpixels/s, the
+dominant kernel, its HBM and VALU-busy fractions and `verified` (first / last RNG chunk against the oracle after the timed
+steps).  `cpu_baseline` times the reference's own node classes on the host cores where the reference checkout exists (the
+build container: kind "reference"), otherwise the oracle port of them (kind "port"), on a bounded sample, on rank 0 at any N.
 
 `--gpus N` with N > 1 and no torchrun environment re-executes itself under `python -m torch.distributed.run` (one rank
-per GPU, RCCL); it fails loudly when fewer than N GPUs are visible.  Colour-match arithmetic: the default "device" policy
-(bit-equal to torch-ROCm's element-wise ops); the "fast" policy is timed next to it and reported
-under `fast_variant`, never as `value`.
+per GPU, RCCL); it fails loudly when fewer than N GPUs are visible.  At N > 1 the line carries a second timed leg,
+`fp64_stats_leg`: the same chain with the fp64 statistics policy, whose reference-frame statistics are reduced over rows
+split across the ranks and merged by the RCCL all-reduce inside every timed step (the collective configs[4] names; the default
+device policy evaluates torch's own reduction over the whole reference frame on every rank and needs none).  Colour-match
+arithmetic: the default "device" policy (bit-equal to torch-ROCm's element-wise ops); the "fast" policy is
+timed next to it and reported under `fast_variant`, never as `value`.
 """
 from __future__ import annotations
 
@@ -66,6 +74,10 @@ def parse_args():
                                                              "[r*frames, (r+1)*frames) of one job-wide batch), so that runs with different GPU counts process "
                                                              "the same data; default: an independent batch per rank")
     ap.add_argument("--cm-stats", default=None, choices=["device", "fp64"], help="colour statistics of the headline leg (default: device)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` legs (the other single-GPU BASELINE configs, both pixel distributions; N = 1, headline "
+                                                              "workload only)")
+    ap.add_argument("--no-fp64-leg", action="store_true", help="N > 1: skip the second headline leg with the fp64 statistics policy (the one whose reference-frame "
+                                                               "statistics cross the RCCL all-reduce inside the timed steps)")
     return ap.parse_args()
 
 
@@ -126,13 +138,27 @@ def _profile_json(*names):
     raise FileNotFoundError(names[0])
 
 
+#: pass of a workload -> substrings that name its kernel in a rocprofv3 trace (first match wins per kernel name)
+PASS_KERNELS = {
+    ("chain4_4k", "stats"): ("k_produce_lab<3",),
+    ("chain4_4k", "apply"): ("k_apply_march<",),
+    ("chain4_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
+    ("chain3_4k", "apply"): ("k_chain_march<3, true",),
+    ("grain_lut_1080p", "apply"): ("k_chain_pointwise", "k_chain_tile<3", "k_chain_march<3, false"),
+    ("colormatch_4k", "stats"): ("k_lab_partials", "k_rgb_lab", "k_produce_lab<0"),
+    ("colormatch_4k", "apply"): ("k_apply_march<",),
+    ("colormatch_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
+}
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9          # 1,024 SIMDs at the 2.4 GHz the PMC runs report (GRBM_GUI_ACTIVE / time)
+
+
 def live_traffic(timeout_s=150):
-    """HBM bytes and VALU lane-instructions per pixel of the headline kernels from the PMC counters ON THIS BOX: three extra
-    `rocprofv3 --kernel-trace --pmc` runs (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU: separate passes, as MI355X_MICROARCH.md
-    prescribes) of tools/prof_driver.py, which executes
-    the same kernels on 16 x 4K frames in its own process (rocprofv3 wraps a process, so it cannot observe this one).
-    FETCH_SIZE is doubled (the gfx950 under-count for wide coalesced reads; calibrated on k_lut3d's known 12 B/px in the same
-    run), both counters are in KB.  Returns {"stats": {...}, "apply": {...}, "chain3_apply": {...}} or raises."""
+    """HBM bytes, VALU lane-instructions and VALU-busy cycles per pixel of every kernel of the bench's workloads from the PMC counters
+    ON THIS BOX: three extra `rocprofv3 --kernel-trace --pmc` runs (FETCH_SIZE; WRITE_SIZE; the SQ set -- separate passes, as
+    MI355X_MICROARCH.md prescribes) of tools/prof_driver.py, which executes the same kernels on 16 x 4K frames in its own process
+    (rocprofv3 wraps a process, so it cannot observe this one).  FETCH_SIZE is doubled (the gfx950 under-count for wide coalesced
+    reads; calibrated on k_lut3d's known 12 B/px in the same run), both counters are in KB; the SQ_* counters count wave64
+    instructions / quad-cycles summed over the chip.  Returns {(workload, pass): {...}, "calibration_k_lut3d": {...}} or raises."""
     import csv
     import glob
     import shutil
@@ -144,8 +170,9 @@ def live_traffic(timeout_s=150):
     tmp = tempfile.mkdtemp(prefix="vrg_traffic_")
     per_px = {}
     px = 16 * 2160 * 3840
+    sq = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")
     try:
-        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT64")):
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), sq):
             out = os.path.join(tmp, counters[0])
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -157,26 +184,42 @@ def live_traffic(timeout_s=150):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
                         if "vrg" in r["Kernel_Name"] and r["Counter_Name"] in counters:
-                            # FETCH_SIZE / WRITE_SIZE count KB; the SQ_INSTS_* count wave64 instructions (x64 lanes)
-                            scale = 64.0 if r["Counter_Name"].startswith("SQ_") else 1024.0
-                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]) * scale / px)
+                            # FETCH_SIZE / WRITE_SIZE count KB; SQ_INSTS_* wave64 instructions (x64 lanes); the others quad-cycles (x4)
+                            c = r["Counter_Name"]
+                            scale = 1024.0 if not c.startswith("SQ_") else (64.0 if c.startswith("SQ_INSTS") else 4.0)
+                            per_px.setdefault(r["Kernel_Name"], {}).setdefault(c, []).append(float(r["Counter_Value"]) * scale / px)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
-    def bpp(match):
-        rd = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 2.0 for k, v in per_px.items() if match(k) and "FETCH_SIZE" in v)
-        wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for k, v in per_px.items() if match(k) and "WRITE_SIZE" in v)
-        def avg(c):
-            return sum(sum(v[c]) / len(v[c]) for k, v in per_px.items() if match(k) and c in v)
-        vi, tr, i64 = avg("SQ_INSTS_VALU"), avg("SQ_INSTS_VALU_TRANS_F32"), avg("SQ_INSTS_VALU_INT64")
-        return {"read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2), "valu_lane_instr": round(vi, 1),
-                "valu_trans": round(tr, 1), "valu_int64": round(i64, 1)}
-    res = {"stats": bpp(lambda k: "k_produce_lab<3" in k), "apply": bpp(lambda k: "k_apply_march<20" in k or "k_chain_tile<20" in k),
-           "tstats": bpp(lambda k: "k_tstats_frame" in k or "k_tstats_rows<" in k),
-           "chain3_apply": bpp(lambda k: "k_chain_march<3" in k), "calibration_k_lut3d": bpp(lambda k: "k_lut3d" in k)}
+    def summary(substrings):
+        names = [k for k in per_px if any(s in k for s in substrings)]
+        def avg(c, mult=1.0):
+            return sum(sum(per_px[k][c]) / len(per_px[k][c]) * mult for k in names if c in per_px[k])
+        rd, wr = avg("FETCH_SIZE", 2.0), avg("WRITE_SIZE")
+        busy, wave = avg("SQ_ACTIVE_INST_VALU"), avg("SQ_WAVE_CYCLES")
+        return {"kernels": sorted(n.split("(")[0][:80] for n in names), "read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2),
+                "valu_lane_instr": round(avg("SQ_INSTS_VALU"), 1), "valu_trans": round(avg("SQ_INSTS_VALU_TRANS_F32"), 1),
+                "valu_int64": round(avg("SQ_INSTS_VALU_INT64"), 1),
+                "valu_busy_simd_cycles": round(busy, 3),                    # SIMD-cycles per pixel with a VALU instruction executing
+                "wave_cycles": round(wave, 3), "wait_issue_share": round(avg("SQ_WAIT_INST_ANY") / wave, 3) if wave else None,
+                "wait_memory_share": round(avg("SQ_WAIT_ANY") / wave, 3) if wave else None}
+    res = {key: summary(subs) for key, subs in PASS_KERNELS.items()}
+    res["calibration_k_lut3d"] = summary(("k_lut3d",))
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")
     return res
+
+
+def committed_pmc():
+    """{(workload, pass): {...}} from the newest committed profiles/rNN_pmc_bench_kernels.json (written by tools/collect_bench_pmc.py from a
+    live_traffic() run on a GPU box), or {} -- what the legs fall back to when the live passes are switched off or fail."""
+    for n in ("r05_pmc_bench_kernels.json",):
+        path = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(path):
+            with open(path) as fh:
+                raw = json.load(fh)
+            return {(tuple(k.split("|")) if "|" in k else k): v for k, v in raw.get("passes", {}).items()}, n
+    return {}, None
 
 
 def _median_time(fn, warmup=1, reps=3):
@@ -288,52 +331,50 @@ def output_digests(out, chunk):
     return [hashlib.sha256(out[f:f + chunk].cpu().numpy().tobytes()).hexdigest() for f in range(0, out.shape[0], chunk)]
 
 
-def main():
-    args = parse_args()
-    self_launch(args)
-    # stdout carries exactly one line, the JSON: everything else that writes to fd 1 while we run (RCCL prints a
-    # version banner to stdout when a communicator is created) is sent to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    from __graft_entry__ import load_package
-    load_package()
-    from comfyui_vrgamedevgirl_amd import ops, sharding
-    from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
-    from comfyui_vrgamedevgirl_amd import cube
-    import torch.distributed as dist
+class Ctx:
+    """What every leg needs: the package modules, the rank geometry, the LUT."""
+    pass
 
-    rank, local, world = sharding.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun --nproc-per-node {args.gpus}, or let "
-                         "bench.py launch itself)")
-    if world > 1:
-        want_backend = os.environ.get("VRGDG_DIST_BACKEND", "nccl")      # gloo only for functional tests on a 1-GPU box
-        if not dist.is_initialized() or dist.get_world_size() != world or dist.get_backend() != want_backend:
-            raise SystemExit("bench.py: RCCL process group did not come up with the requested world size")
-    dev = torch.device("cuda", torch.cuda.current_device())
-    H, W, stages = WORKLOADS[args.workload]
-    frames = args.frames or {"grain_lut_1080p": 128, "colormatch_4k": 512}.get(args.workload, 256)      # BASELINE.json configs[1..4]
+
+def _kernel_name(stages, which):
+    if which == "stats":
+        return ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it by "
+                "k_tstats_frame)" if "grain" in stages else
+                "k_lab_partials, Lab-only form (rgb->Lab pass 1, stores the Lab image; the statistics are reduced from it by k_tstats_frame)")
+    if which == "tstats":
+        return "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)"
+    if "colormatch" in stages:
+        return "k_apply_march<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, register-resident wave march)"
+    if "sharpen" in stages and "grain" in stages:
+        return "k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)"
+    return "k_chain_tile / k_chain_pointwise (fused apply pass)"
+
+
+ALGO_BPP = {"stats": 12, "apply": 24, "tstats": 12}         # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
+
+
+def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_stats=None, verify=True, digest=False, fast_variant=False,
+                 time_reference_stats=False):
+    """One leg: `frames` synthetic frames of `workload` resident in HBM on every rank, `warmup` untimed + `steps` timed steps bracketed
+    by barrier + synchronize, MAX over ranks.  Returns the measurements and frees its buffers."""
+    ops, sharding, dist = C.ops, C.sharding, C.dist
+    rank, world, dev = C.rank, C.world, C.dev
+    H, W, stages = WORKLOADS[workload]
     chunk = 4
-
-    lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
-    lut = ops.upload_lut(lut_cpu, dev)
-    x = make_frames(frames, H, W, dev, 1234 + (0 if args.same_data else rank), args.dist, first_frame=rank * frames if args.same_data else None)
+    x = make_frames(frames, H, W, dev, 1234 + (0 if args.same_data else rank), pixel_dist, first_frame=rank * frames if args.same_data else None)
     out = torch.empty_like(x)
     lab_ws = torch.empty_like(x) if "colormatch" in stages else None      # Lab image between the two colour-match passes
-    ref = make_frames(1, H, W, dev, 4321, args.dist)          # same reference frame on every rank
+    ref = make_frames(1, H, W, dev, 4321, pixel_dist)          # same reference frame on every rank
     fe = H * W * 3
-
     # one job-wide generator state: rank r takes chunks [r*frames/chunk, ...) of the same stream, so the result
     # does not depend on the number of GPUs
     geom_stream = None
     if "grain" in stages:
         gen = torch.Generator(device=dev).manual_seed(42)
         geom_stream = ops.rng.reserve(chunk * fe, world * frames // chunk, dev, gen)
-
     ref_events = []
 
-    def step(kernel_events=None, cm_math=None, cm_stats=args.cm_stats):
+    def step(kernel_events=None, cm_math=None, cm_stats=cm_stats):
         ref_ms = ref_ev = None
         if "colormatch" in stages:
             if ops._cm_stats(cm_stats, cm_math, dev) == "device":
@@ -356,7 +397,7 @@ def main():
         if geom_stream is not None:
             plans = (ops.NoisePlan(chunk, geom_stream, chunk0=rank * (frames // chunk)), None, frames // chunk)
         spec = ops.ChainSpec(grain=(0.04, 0.5, chunk) if "grain" in stages else None,
-                             lut=(lut, 10.0) if "lut" in stages else None,
+                             lut=(C.lut, 10.0) if "lut" in stages else None,
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
                              cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
@@ -367,157 +408,216 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank_ms = [elapsed / args.steps * 1e3]
-    if dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        every = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 3) for v in every]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # the timed steps' own output, checked and fingerprinted BEFORE anything else overwrites it (never inside the timed region)
-    verify = digests = None
-    if rank == 0 and not args.no_verify:
-        try:
-            verify = verify_output(ops, x, out, ref, lut, lut_cpu, stages, geom_stream, rank, frames, chunk, dev, args.cm_stats)
-        except Exception as exc:              # a checker problem must not lose the measurement; it is reported as unverified
-            verify = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
-    if args.digest:
-        mine = output_digests(out, chunk)
-        digests = [mine]
-        if dist.is_initialized():
-            digests = [None] * world
-            dist.all_gather_object(digests, mine)
-    # the fast colour-match policy, same data, timed the same way (reported beside the headline, never as `value`)
-    fast_variant = None
-    if "colormatch" in stages and not args.no_fast_variant:
-        step(cm_math="fast", cm_stats=None)
+    def timed(**kw):
+        for _ in range(warmup):
+            step(**kw)
         barrier()
-        fast_events = []
-        f0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(fast_events, cm_math="fast", cm_stats=None)
+        ev = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(ev, **kw)
         barrier()
-        fel = time.perf_counter() - f0
+        el = time.perf_counter() - t0
+        per_rank = [el / steps * 1e3]
         if dist.is_initialized():
-            t = torch.tensor([fel], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            every = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [round(float(v.item()) / steps * 1e3, 3) for v in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fel = float(t.item())
-        fast_variant = {"cm_math": "fast", "value": round(world * frames * H * W * args.steps / fel / 1e6, 1), "unit": "Mpixels/s",
-                        "ms_per_step": round(fel / args.steps * 1e3, 3),
-                        "cm_stats": "fp64 (reference-frame rows split across the ranks, merged by the RCCL all-reduce when N > 1)",
-                        "note": "table-driven powers (<= 0.534 ulp) instead of ocml powf and fp64-accumulated statistics instead of torch's "
-                                "fp32 reductions: a few ulp from the reference, not bit-equal to it (DESIGN.md section 4)"}
+            el = float(t.item())
+        return el, per_rank, ev
 
-    px_rank = frames * H * W
-    value = world * px_rank * args.steps / elapsed / 1e6
-    # per-pass device time from HIP events on the launch stream; the dominant pass carries the roofline object
+    elapsed, per_rank_ms, events = timed()
+    R = {"workload": workload, "dist": pixel_dist, "frames": frames, "H": H, "W": W, "stages": stages, "chunk": chunk, "steps": steps, "warmup": warmup,
+         "elapsed": elapsed, "per_rank_ms": per_rank_ms, "px_rank": frames * H * W, "cm_stats": cm_stats}
+    # the timed steps' own output, checked and fingerprinted BEFORE anything else overwrites it (never inside the timed region)
+    R["verify"] = None
+    if rank == 0 and verify:
+        try:
+            R["verify"] = verify_output(ops, x, out, ref, C.lut, C.lut_cpu, stages, geom_stream, rank, frames, chunk, dev, cm_stats)
+        except Exception as exc:              # a checker problem must not lose the measurement; it is reported as unverified
+            R["verify"] = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
+    R["digests"] = None
+    if digest:
+        mine = output_digests(out, chunk)
+        R["digests"] = [mine]
+        if dist.is_initialized():
+            R["digests"] = [None] * world
+            dist.all_gather_object(R["digests"], mine)
+    # the fast colour-match policy, same data, timed the same way (reported beside the headline, never as `value`)
+    R["fast_variant"] = None
+    if fast_variant and "colormatch" in stages:
+        fel, _pr, _ev = timed(cm_math="fast", cm_stats=None)
+        R["fast_variant"] = {"cm_math": "fast", "value": round(world * frames * H * W * steps / fel / 1e6, 1), "unit": "Mpixels/s",
+                             "ms_per_step": round(fel / steps * 1e3, 3),
+                             "cm_stats": "fp64 (reference-frame rows split across the ranks, merged by the RCCL all-reduce when N > 1)",
+                             "note": "table-driven powers (<= 0.534 ulp) instead of ocml powf and fp64-accumulated statistics instead of torch's "
+                                     "fp32 reductions: a few ulp from the reference, not bit-equal to it (DESIGN.md section 4)"}
+    # per-pass device time from HIP events on the launch stream
     passes = {}
     for name, a, b, nf in events:
         passes.setdefault(name, []).append(a.elapsed_ms(b))
-    pass_ms = {k: sum(v) / args.steps for k, v in passes.items()}          # per step (pieces of a step added up)
-    launches_per_step = {k: len(v) // max(args.steps, 1) for k, v in passes.items()}
-    algo_bpp = {"stats": 12, "apply": 24, "tstats": 12}         # SURVEY.md section 8d; tstats re-reads the Lab image (12 B/px)
-    kern_names = {"stats": ("k_produce_lab, Lab-only form (grain->LUT->Lab pass 1: shared Philox, stores the Lab image; the statistics are reduced from it "
-                            "by k_tstats_frame)" if "grain" in stages else
-                            "k_lab_partials, Lab-only form (rgb->Lab pass 1, stores the Lab image; the statistics are reduced from it by k_tstats_frame)"),
-                  "tstats": "k_tstats_frame (torch's mean / Welford reductions replayed over the stored Lab image)",
-                  "apply": "k_apply_march<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, register-resident wave march)" if "colormatch" in stages
-                  else ("k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)" if "sharpen" in stages and "grain" in stages
-                        else "k_chain_tile / k_chain_pointwise (fused apply pass)")}
-    dom = max(pass_ms, key=pass_ms.get)
-    kern_avg_ms = pass_ms[dom]
-    algo_bytes = algo_bpp[dom] * px_rank
-    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
-    bytes_per_px_chain = 36 if "colormatch" in stages else 24
-    # HBM traffic of the dominant pass from the PMC run committed under profiles/ (rocprofv3 cannot run inside this
-    # process): bytes per pixel measured there x the pixels of one launch here
-    traffic, traffic_note, live_ipp, live_classes = None, None, None, (None, None)
-    key = dom if "colormatch" in stages else "chain3_apply"
-    if rank == 0 and world == 1 and not args.no_live_traffic and args.workload in ("chain4_4k", "chain3_4k"):
-        try:
-            del out, lab_ws                                   # the profiled side process needs ~5 GB of the HBM
-            torch.cuda.empty_cache()
-            summ = live_traffic()
-            live_ipp = summ.get(key, {}).get("valu_lane_instr") or None
-            live_classes = (summ.get(key, {}).get("valu_trans"), summ.get(key, {}).get("valu_int64"))
-            if summ.get(key, {}).get("total"):
-                traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
-                traffic_note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on this box right after the timed region (separate "
-                                f"passes, own process, the same kernels on 16x4K frames): {summ[key]['read']} B/px read + "
-                                f"{summ[key]['written']} B/px written (FETCH_SIZE x2 per the gfx950 calibration; k_lut3d in the same run: "
-                                f"{summ['calibration_k_lut3d']['read']} + {summ['calibration_k_lut3d']['written']} for its known 12 + 12) x this "
-                                "launch's pixels" + ("; the written bytes are the Lab image kept for pass 2, not re-reads" if key == "stats" else ""))
-        except Exception as exc:
-            traffic_note = f"live PMC passes failed ({type(exc).__name__}: {exc}); "
-    try:
-        if traffic is not None or args.workload not in ("chain4_4k", "chain3_4k"):      # the PMC passes cover these two workloads' kernels
-            raise StopIteration
-        tj, tname = _profile_json("r04_pmc_traffic_fetch_write.json", "r03_pmc_traffic_fetch_write.json", "r02_pmc_traffic_fetch_write.json")
-        summ = tj.get("summary", {})
-        if summ.get(key, {}).get("total"):
-            traffic = round(summ[key]["total"] * px_rank / 1e9, 2)
-            traffic_note = (traffic_note or "") + (f"NOT collected in this process (rocprofv3 wraps a process): profiles/{tname}, the same kernels on 16x4K frames: "
-                            f"{summ[key]['read']} B/px read + {summ[key]['written']} B/px written (rocprofv3 --pmc "
-                            "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per the gfx950 calibration) x this launch's pixels"
-                            + ("; the written bytes are the Lab image kept for pass 2 (design choice measured in DESIGN.md section 3: "
-                               "40.3 vs 25.4 Gpix/s against the recomputing form), not re-reads" if key == "stats" else ""))
-    except Exception:
-        pass
-
-    # VALU issue roofline of the same pass (the one that actually binds it): lane-instructions per
-    # pixel from the committed PMC pass (SQ_INSTS_VALU, calibrated on the issue-rate probe) x this run's pixel rate,
-    # against the probe's measured peak for plain fp32 / integer ops
-    issue = None
-    try:
-        recs, iname = _profile_json("r04_pmc_valu_instr_per_px.json", "r03_pmc_valu_instr_per_px.json", "r02_pmc_valu_instr_per_px.json")
-        rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
-        peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
-        # only the kernels the committed PMC pass covers: the two passes of the headline chain and the chain-3 march
-        want = {("chain4_4k", "stats"): "k_produce_lab<3, false>", ("chain4_4k", "apply"): "k_chain_tile<20",
-                ("chain3_4k", "apply"): "k_chain_march<3"}[(args.workload, dom)]
-        ipp = live_ipp if live_ipp else next(r["valu_lane_instr_per_px"] for r in recs if want in r["kernel"])
-        src = ("a rocprofv3 --pmc SQ_INSTS_VALU pass on this box right after the timed region (own process, 16x4K frames)" if live_ipp
-               else f"profiles/{iname} (SQ_INSTS_VALU, not collected in this process)")
-        rate_t = ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
-        weighted = None
-        if live_ipp and live_classes[0] is not None:
-            # issue cost of the measured classes relative to a plain fp32 / integer op (profiles/r02_valu_issue_rate_long.json):
-            # transcendental 3.45x, 64-bit integer multiply-add 1.8x (compare + select pairs, 1.65x, have no counter: not included)
-            w_ipp = ipp + 2.45 * live_classes[0] + 0.8 * live_classes[1]
-            w_rate = w_ipp * px_rank / (kern_avg_ms * 1e-3) / 1e12
-            weighted = {"lane_instr_per_px": round(w_ipp, 1), "of_which_transcendental": live_classes[0], "of_which_int64": live_classes[1],
-                        "achieved": round(w_rate, 2), "frac_of_measured_peak_66p5": round(w_rate / peak_t, 4),
-                        "frac_of_guide_peak_78p6": round(w_rate / 78.6, 4), "unweighted_frac_of_guide_peak_78p6": round(rate_t / 78.6, 4)}
-        issue = {"bound": "valu-issue", "lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t,
-                 "unit": "T lane-instr/s", "frac": round(rate_t / peak_t, 4), "weighted": weighted,
-                 "note": f"lane-instructions per pixel from {src} x this run's pixel rate; "
-                         f"peak = v_fma_f32 at 8 waves/SIMD over >= 17 ms launches (profiles/{rname}); unweighted: v_pk_* / fp64 / "
-                         "v_mad_u64_u32 issue at 1.8x, compare+select pairs 1.65x, transcendentals 3.45x a plain op"}
-    except Exception:
-        pass
-
+    R["pass_ms"] = {k: sum(v) / steps for k, v in passes.items()}          # per step (pieces of a step added up)
+    R["launches_per_step"] = {k: len(v) // max(steps, 1) for k, v in passes.items()}
     # reference-frame statistics: the device form is overlapped with pass 1 in the step, so it is timed on its own here (3 runs, median);
-    # the fp64 / all-reduce form of the fast variant was bracketed by events inside its steps
-    ref_ms_per_step = ref_allreduce_ms = None
-    if "colormatch" in stages:
+    # the fp64 / all-reduce form was bracketed by events inside its steps
+    R["ref_ms_per_step"] = R["ref_allreduce_ms"] = None
+    if "colormatch" in stages and time_reference_stats:
         ts = []
         for _ in range(4):
             a, b = ops.HipEvent(), ops.HipEvent()
             a.record(); ops.reference_stats(ref, step_frames=frames); b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_ms(b))
-        ref_ms_per_step = round(sorted(ts[1:])[1], 4)
-        if ref_events:
-            ref_allreduce_ms = round(sum(a.elapsed_ms(b) for a, b in ref_events) / max(args.steps, 1), 4)
+        R["ref_ms_per_step"] = round(sorted(ts[1:])[1], 4)
+    if ref_events:
+        R["ref_allreduce_ms"] = round(sum(a.elapsed_ms(b) for a, b in ref_events[-steps:]) / max(steps, 1), 4)
+    del x, out, lab_ws, ref
+    torch.cuda.empty_cache()
+    return R
+
+
+def leg_summary(R, world, pmc, pmc_src):
+    """The compact record of a leg for the line's `configs` object: whole-leg rate, the dominant pass and its two roofline fractions --
+    algorithmic bytes against 8 TB/s (`hbm_frac`) and VALU-busy cycles against the 1,024 SIMDs (`valu_busy_frac`; SQ_ACTIVE_INST_VALU per
+    pixel of that kernel from the PMC pass named in `pmc_source` x the pixel rate the pass reached here)."""
+    stages, px = R["stages"], R["px_rank"]
+    ms = R["elapsed"] / R["steps"] * 1e3
+    bpp_chain = 36 if "colormatch" in stages else 24
+    dom = max(R["pass_ms"], key=R["pass_ms"].get)
+    dms = R["pass_ms"][dom]
+    rate = px / (dms * 1e-3) if dms > 0 else 0.0
+    c = pmc.get((R["workload"], dom), {}) if pmc else {}
+    busy = c.get("valu_busy_simd_cycles") or None
+    out = {"workload": R["workload"], "pixels": f"synthetic-{R['dist']}", "frames": R["frames"], "height": R["H"], "width": R["W"], "stages": "+".join(stages),
+           "steps": R["steps"], "warmup": R["warmup"], "ms_per_step": round(ms, 3), "Mpix_s": round(world * px / ms / 1e3, 1),
+           "algorithmic_bytes_per_pixel": bpp_chain, "hbm_frac": round(px / (ms * 1e-3) * bpp_chain / (HBM_PEAK_GBS * 1e9), 4),
+           "passes_ms": {k: round(v, 3) for k, v in R["pass_ms"].items()},
+           "dominant_kernel": _kernel_name(stages, dom), "dominant_kernel_ms": round(dms, 3),
+           "dominant_kernel_hbm_frac": round(ALGO_BPP[dom] * rate / 1e9 / HBM_PEAK_GBS, 4),
+           "valu_busy_frac": round(busy * rate / SIMD_CYCLES_PER_S, 4) if busy else None,
+           "valu_busy_simd_cycles_per_px": busy, "valu_lane_instr_per_px": c.get("valu_lane_instr") or None,
+           "wait_issue_share_of_wave_cycles": c.get("wait_issue_share"), "wait_memory_share_of_wave_cycles": c.get("wait_memory_share"),
+           "hbm_bytes_per_px_measured": c.get("total") or None, "pmc_source": pmc_src if c else None,
+           "verified": None if R["verify"] is None else bool(R["verify"].get("verified"))}
+    if R["verify"] is not None and not R["verify"].get("verified"):
+        out["verify"] = R["verify"]
+    return out
+
+
+def main():
+    args = parse_args()
+    self_launch(args)
+    # stdout carries exactly one line, the JSON: everything else that writes to fd 1 while we run (RCCL prints a
+    # version banner to stdout when a communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    from __graft_entry__ import load_package
+    load_package()
+    from comfyui_vrgamedevgirl_amd import ops, sharding
+    from comfyui_vrgamedevgirl_amd import VRGDG_IV_Adjustments as iv
+    from comfyui_vrgamedevgirl_amd import cube
+    import torch.distributed as dist
+
+    # rank 0 checks its output against the oracle and times the CPU baseline AFTER the timed region while the other ranks wait at the
+    # final barrier: the process group's timeout must cover that (a 4K chunk through the CPU oracle takes tens of seconds)
+    rank, local, world = sharding.init_from_env(timeout_s=3600)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with torchrun --nproc-per-node {args.gpus}, or let "
+                         "bench.py launch itself)")
+    if world > 1:
+        want_backend = os.environ.get("VRGDG_DIST_BACKEND", "nccl")      # gloo only for functional tests on a 1-GPU box
+        if not dist.is_initialized() or dist.get_world_size() != world or dist.get_backend() != want_backend:
+            raise SystemExit("bench.py: RCCL process group did not come up with the requested world size")
+    C = Ctx()
+    C.ops, C.sharding, C.dist, C.rank, C.world = ops, sharding, dist, rank, world
+    C.dev = dev = torch.device("cuda", torch.cuda.current_device())
+    C.lut_cpu = lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
+    C.lut = ops.upload_lut(lut_cpu, dev)
+    H, W, stages = WORKLOADS[args.workload]
+    default_frames = {"grain_lut_1080p": 128, "colormatch_4k": 512}
+    frames = args.frames or default_frames.get(args.workload, 256)      # BASELINE.json configs[1..4]
+
+    M = run_workload(C, args, args.workload, args.dist, frames, args.steps, args.warmup, cm_stats=args.cm_stats, verify=not args.no_verify,
+                     digest=args.digest, fast_variant=not args.no_fast_variant, time_reference_stats=True)
+    # N > 1: a second headline leg whose reference-frame statistics are the fp64 (n, mean, M2) form -- rows split across the ranks, merged
+    # by the RCCL all-reduce INSIDE the timed steps (BASELINE configs[4] names that collective; the default device policy needs none)
+    fp64_leg = None
+    if world > 1 and "colormatch" in stages and not args.no_fp64_leg and (args.cm_stats or "device") == "device":
+        F64 = run_workload(C, args, args.workload, args.dist, frames, args.steps, args.warmup, cm_stats="fp64", verify=not args.no_verify)
+        fp64_leg = {"cm_stats": "fp64 (reference-frame rows split across the ranks, (n, mean, M2) merged by two SUM all-reduces over RCCL inside every step)",
+                    "value": round(world * F64["px_rank"] * args.steps / F64["elapsed"] / 1e6, 1), "unit": "Mpixels/s",
+                    "ms_per_step": round(F64["elapsed"] / args.steps * 1e3, 3), "per_rank_ms_per_step": F64["per_rank_ms"],
+                    "reference_stats_allreduce_ms_per_step": F64["ref_allreduce_ms"],
+                    "verified": None if F64["verify"] is None else bool(F64["verify"].get("verified")),
+                    "note": "arithmetic device-exact, statistics fp64-accumulated: within the statistics band of the reference (tens of ulp(1.0)), "
+                            "not bit-equal to it; checked against the stand-alone operators of this library"}
+
+    elapsed, px_rank = M["elapsed"], M["px_rank"]
+    value = world * px_rank * args.steps / elapsed / 1e6
+    pass_ms = M["pass_ms"]
+    dom = max(pass_ms, key=pass_ms.get)
+    kern_avg_ms = pass_ms[dom]
+    algo_bytes = ALGO_BPP[dom] * px_rank
+    achieved = algo_bytes / (kern_avg_ms * 1e-3) / 1e9 if kern_avg_ms > 0 else 0.0
+    bytes_per_px_chain = 36 if "colormatch" in stages else 24
+
+    # PMC counters of every workload's kernels: live on this box (three rocprofv3 --pmc passes of tools/prof_driver.py in their own
+    # process, right after the timed region), else the committed run of the same command
+    pmc, pmc_src, pmc_err = {}, None, None
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        try:
+            pmc = live_traffic()
+            pmc_src = "rocprofv3 --kernel-trace --pmc on this box right after the timed region (separate passes, own process, the same kernels on 16x4K frames)"
+        except Exception as exc:
+            pmc_err = f"live PMC passes failed ({type(exc).__name__}: {exc}); "
+    if not pmc:
+        pmc, name = committed_pmc()
+        pmc_src = f"NOT collected in this process (rocprofv3 wraps a process): profiles/{name}" if name else None
+    c = pmc.get((args.workload, dom), {})
+    traffic = traffic_note = None
+    if c.get("total"):
+        cal = pmc.get("calibration_k_lut3d", {})
+        traffic = round(c["total"] * px_rank / 1e9, 2)
+        traffic_note = ((pmc_err or "") + f"{pmc_src}: FETCH_SIZE / WRITE_SIZE {c['read']} B/px read + {c['written']} B/px written (FETCH_SIZE x2 per the gfx950 "
+                        f"calibration; k_lut3d in the same run: {cal.get('read')} + {cal.get('written')} for its known 12 + 12) x this launch's pixels"
+                        + ("; the written bytes are the Lab image kept for pass 2, not re-reads" if dom == "stats" and "colormatch" in stages else ""))
+    elif pmc_err:
+        traffic_note = pmc_err
+
+    # The unit that binds the dominant kernel.  Every kernel of this path moves its algorithmic bytes once (traffic above), and none of the
+    # chains reaches the HBM roofline: they are bound by VALU issue.  Two views of it: `valu_busy_frac` = SIMD-cycles with a VALU
+    # instruction executing (SQ_ACTIVE_INST_VALU) per pixel x the pixel rate, against the chip's 1,024 SIMDs x 2.4 GHz; `issue` =
+    # lane-instructions per pixel x the rate against the measured v_fma_f32 peak, weighted by the issue cost of the instruction classes
+    # that have a counter.
+    rate = px_rank / (kern_avg_ms * 1e-3) if kern_avg_ms > 0 else 0.0
+    valu_busy = round(c["valu_busy_simd_cycles"] * rate / SIMD_CYCLES_PER_S, 4) if c.get("valu_busy_simd_cycles") else None
+    issue = None
+    try:
+        rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
+        peak_t = max(r["tera_lane_instr_s"] for r in rates["rows"] if r["instr"] == "v_fma_f32")
+        ipp = c.get("valu_lane_instr")
+        if ipp:
+            rate_t = ipp * rate / 1e12
+            # issue cost of the measured classes relative to a plain fp32 / integer op (profiles/r02_valu_issue_rate_long.json):
+            # transcendental 3.45x, 64-bit integer multiply-add 1.8x (compare + select pairs, 1.65x, have no counter: not included)
+            w_ipp = ipp + 2.45 * (c.get("valu_trans") or 0.0) + 0.8 * (c.get("valu_int64") or 0.0)
+            w_rate = w_ipp * rate / 1e12
+            issue = {"lane_instr_per_px": round(ipp, 1), "achieved": round(rate_t, 2), "peak": peak_t, "unit": "T lane-instr/s",
+                     "frac": round(rate_t / peak_t, 4),
+                     "weighted": {"lane_instr_per_px": round(w_ipp, 1), "of_which_transcendental": c.get("valu_trans"), "of_which_int64": c.get("valu_int64"),
+                                  "achieved": round(w_rate, 2), "frac_of_measured_peak_66p5": round(w_rate / peak_t, 4),
+                                  "frac_of_guide_peak_78p6": round(w_rate / 78.6, 4)},
+                     "note": f"lane-instructions per pixel from {pmc_src} x this run's pixel rate; peak = v_fma_f32 at 8 waves/SIMD over >= 17 ms "
+                             f"launches (profiles/{rname}); v_pk_* / fp64 / v_mad_u64_u32 issue at 1.8x, compare+select pairs 1.65x, transcendentals "
+                             "3.45x a plain op"}
+    except Exception:
+        pass
+    bound = "hbm"
+    if valu_busy is not None and valu_busy > achieved / HBM_PEAK_GBS:
+        bound = "valu-issue"
+
     if rank == 0:
         line = {
             "metric": "Mpixels/s (grain+LUT+colormatch+sharpen) at 4K" if args.workload == "chain4_4k" else f"Mpixels/s ({'+'.join(stages)})",
@@ -525,7 +625,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": f"synthetic-{args.dist} (generated on device, resident in HBM)",
             "config": {"workload": f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)} fused chain, LUT 33^3 (AMD_TealOrange_33.cube, this "
-                                   f"pack's own cube: same size as the reference's Vintage Color.cube), grain chunk {chunk} "
+                                   f"pack's own cube: same size as the reference's Vintage Color.cube), grain chunk {M['chunk']} "
                                    f"(BASELINE configs[4] per-GPU shard)" if args.workload == "chain4_4k"
                        else f"{W}x{H} x{frames} frames/GPU, {'+'.join(stages)}",
                        "frames_per_gpu": frames, "height": H, "width": W, "parallelism": f"frames sharded x{world}",
@@ -537,36 +637,66 @@ def main():
                                    "cube's shape (this pack's AMD_TealOrange_33.cube, not the reference's Vintage Color.cube)"},
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
             "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
-            "per_rank_ms_per_step": per_rank_ms,
-            "reference_stats_ms_per_step": ref_ms_per_step,
+            "per_rank_ms_per_step": M["per_rank_ms"],
+            "reference_stats_ms_per_step": M["ref_ms_per_step"],
             "reference_stats_note": ("device statistics of the whole reference frame on every rank, on a side stream next to pass 1 (timed alone here); "
-                                     "the fast variant's fp64 form -- rows split across the ranks + RCCL all-reduce -- took "
-                                     f"{ref_allreduce_ms} ms per step") if "colormatch" in stages else None,
+                                     "the fp64 form -- rows split across the ranks + RCCL all-reduce -- is timed inside the steps of `fp64_stats_leg` "
+                                     "(N > 1)") if "colormatch" in stages else None,
             "chain_hbm_frac": round(value / world * bytes_per_px_chain * 1e6 / 1e9 / HBM_PEAK_GBS, 4),
-            "roofline": {"bound": "hbm", "kernel": kern_names[dom],
+            "roofline": {"bound": bound, "kernel": _kernel_name(stages, dom),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "valu_busy_frac": valu_busy,
+                         "issue_frac_weighted": issue["weighted"]["frac_of_measured_peak_66p5"] if issue else None,
+                         "bound_note": ("`achieved` / `peak` / `frac` are the contract's HBM figures (algorithmic bytes of the dominant kernel / its HIP-event "
+                                        "time / 8 TB/s).  `bound` names the unit that limits the kernel: its measured HBM traffic is the algorithmic "
+                                        "bytes (`traffic`), so HBM does not bind it; `valu_busy_frac` = SQ_ACTIVE_INST_VALU per pixel x this run's pixel "
+                                        "rate / (1,024 SIMDs x 2.4 GHz) and `issue_frac_weighted` = class-weighted lane-instructions per second / the "
+                                        "measured v_fma_f32 peak are the fractions of the VALU roofline it reaches (DESIGN.md section 5.1)"),
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
-                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": launches_per_step,
+                         "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": M["launches_per_step"],
                          "issue": issue},
         }
+        line["verified"] = None if M["verify"] is None else bool(M["verify"].get("verified"))
+        line["verify"] = M["verify"]
+        if M["digests"] is not None:
+            line["output_sha256_per_rank_per_chunk"] = M["digests"]
+        if M["fast_variant"] is not None:
+            line["fast_variant"] = M["fast_variant"]
+        if fp64_leg is not None:
+            line["fp64_stats_leg"] = fp64_leg
+    # The other single-GPU BASELINE configs and the second pixel distribution ("report both"), each timed the way
+    # the headline is -- every rank would have to take part, so N = 1 only
+    if world == 1 and args.workload == "chain4_4k" and not args.no_configs:
+        n1080 = 128 if args.frames is None else args.frames          # BASELINE's frame counts unless --frames shrinks the run
+        legs = [("chain4_4k", "video", frames), ("chain3_4k", "uniform", frames), ("chain3_4k", "video", frames),
+                ("grain_lut_1080p", "uniform", n1080), ("grain_lut_1080p", "video", n1080), ("colormatch_4k", "uniform", 2 * frames)]
+        cfgs = {"headline": leg_summary(M, world, pmc, pmc_src)}
+        for wl, pd, nf in legs:
+            try:
+                L = run_workload(C, args, wl, pd, nf, max(args.steps // 2, 3), 2, verify=not args.no_verify)
+                cfgs[f"{wl}.{pd}"] = leg_summary(L, world, pmc, pmc_src)
+            except Exception as exc:
+                cfgs[f"{wl}.{pd}"] = {"error": f"{type(exc).__name__}: {exc}"}
+        cfgs["note"] = ("BASELINE.json configs[1] = grain_lut_1080p (128 frames), configs[2] = chain3_4k (256 frames; the pass north_star's >= 60 % target "
+                        "names), configs[3] = colormatch_4k (512 frames), configs[4] per-GPU shard = headline; `pixels` uniform = iid U[0,1) (worst case "
+                        "for the LUT gathers), video = smooth field + N(0, 0.02) texture (SURVEY.md section 8d, D2 / D1).  hbm_frac = Mpix_s x "
+                        "algorithmic_bytes_per_pixel / 8 TB/s; valu_busy_frac of the dominant kernel as in `roofline`; `verified` = first and last RNG "
+                        "chunk against the stand-alone operators and the oracle after the timed steps")
+        line["configs"] = cfgs
+    if rank == 0:
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":
             # what a ComfyUI graph sees: CPU tensors in, CPU tensors out, every node call crossing PCIe both ways -- never `value`
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import host_fed
-                del x
                 torch.cuda.empty_cache()
-                line["host_fed"] = host_fed.measure(frames=8, reps=3)
+                line["host_fed"] = host_fed.measure(frames=8, reps=5)
             except Exception as exc:
                 line["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
-        line["verified"] = None if verify is None else bool(verify.get("verified"))
-        line["verify"] = verify
-        if digests is not None:
-            line["output_sha256_per_rank_per_chunk"] = digests
-        if fast_variant is not None:
-            line["fast_variant"] = fast_variant
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0 only, any N (the other ranks wait at the final barrier; the process group's timeout covers it)
             try:
                 line["cpu_baseline"] = cpu_baseline(stages, args.cpu_frames if H > 1080 else 4 * args.cpu_frames, H, W, lut_cpu)
             except Exception as exc:      # never lose the GPU line to a host-side problem

@@ -131,41 +131,119 @@ _STAGING = _Staging()
 
 # ------------------------------------------------------------------------------------------------------------
 # Adjacent nodes of this pack in one graph: ComfyUI hands node B the very tensor object node A returned.  A's result still
-# exists on the GPU when its download finishes, so the device copy is kept (bounded, weakly keyed by the CPU tensor) and B
-# skips its upload: grain -> LUT -> colour match -> unsharp pays 1 upload + 4 downloads instead of 4 + 4.  The reference's
-# contract is untouched (nodes.py:50, 61, 64-66: CPU tensors in, CPU tensors out); results and generator state are the
-# same bits -- B reads the frames A wrote, from HBM instead of over PCIe.
+# exists on the GPU when its download finishes, so the device copy is kept for a short while (bounded, weakly keyed by the
+# CPU tensor) and B skips its upload: grain -> LUT -> colour match -> unsharp pays 1 upload + 4 downloads instead of 4 + 4.
+# The reference's contract is untouched (nodes.py:50, 61, 64-66: CPU tensors in, CPU tensors out); results and generator
+# state are the same bits -- B reads the frames A wrote, from HBM instead of over PCIe.
 #   * keyed by the CPU tensor OBJECT (weak reference: the device copy dies with it) and validated by data pointer, shape,
-#     dtype and torch's version counter: an in-place change of the intermediate bumps `_version` and B uploads as before;
-#   * bounded: VRGDG_DEVICE_CACHE_GB (default 8) GiB of device copies, oldest dropped first; 0 disables;
-#   * the nodes never write their input frames, so a cached copy can feed any number of readers.
+#     dtype, torch's version counter WHERE THE TENSOR HAS ONE (ComfyUI runs its graph under torch.inference_mode(), whose
+#     tensors do not track versions: reading `_version` raises there) and a content stamp -- CRC-32 of 66 sampled 4 KiB pages
+#     of the host tensor, taken when the download finished and again at lookup (~0.1 ms): a write through an alias the
+#     version counter cannot see (`.numpy()`, cv2, inference tensors) that touches a sampled page drops the copy.  ComfyUI's
+#     own rule -- node inputs are shared cached outputs and must not be written -- is what makes the copy valid; the checks
+#     are the second line, and they are sampled, not exhaustive (VRGDG_DEVICE_CACHE_GB=0 switches the cache off);
+#   * bounded three ways: VRGDG_DEVICE_CACHE_GB (default 4) GiB, at most an eighth of the device memory that is free when
+#     the copy is offered, and VRGDG_DEVICE_CACHE_SECONDS (default 20): a graph's next node arrives within milliseconds, so
+#     copies older than that are dropped by a timer -- ComfyUI's model management never finds HBM held by a graph that
+#     finished long ago.  `release_device_copies()` drops everything at once (a host may call it before loading a model);
+#     a call that finds less free device memory than its pipeline needs drops the cache before it allocates;
+#   * the nodes never write their input frames, so a cached copy can feed any number of readers;
+#   * a failure inside the cache bookkeeping never fails the node: it is swallowed and the frames are uploaded.
 # ------------------------------------------------------------------------------------------------------------
-DEVICE_CACHE_BYTES = int(float(os.environ.get("VRGDG_DEVICE_CACHE_GB", "8")) * (1 << 30))
+DEVICE_CACHE_BYTES = int(float(os.environ.get("VRGDG_DEVICE_CACHE_GB", "4")) * (1 << 30))
+DEVICE_CACHE_SECONDS = float(os.environ.get("VRGDG_DEVICE_CACHE_SECONDS", "20"))
+DEVICE_CACHE_FREE_FRACTION = 0.125
+_STAMP_PAGES = 64
+_STAMP_PAGE_BYTES = 4096
+
+
+def _version_of(t: torch.Tensor):
+    """torch's version counter, or None for tensors that do not track one (inference tensors: reading it raises)."""
+    try:
+        if t.is_inference():
+            return None
+        return t._version
+    except RuntimeError:
+        return None
+
+
+def _content_stamp(t: torch.Tensor) -> int:
+    """CRC-32 over the first, the last and _STAMP_PAGES evenly spread 4 KiB pages of a contiguous CPU tensor's bytes."""
+    import zlib
+    flat = t.detach().reshape(-1).view(torch.uint8)
+    n = int(flat.numel())
+    crc = zlib.crc32(n.to_bytes(8, "little"))
+    if n <= (_STAMP_PAGES + 2) * _STAMP_PAGE_BYTES:
+        return zlib.crc32(memoryview(flat.numpy()), crc)
+    last = n - _STAMP_PAGE_BYTES
+    offs = sorted({0, last, *(((last * k) // (_STAMP_PAGES + 1)) & ~63 for k in range(1, _STAMP_PAGES + 1))})
+    buf = flat.numpy()
+    for o in offs:
+        crc = zlib.crc32(memoryview(buf[o:o + _STAMP_PAGE_BYTES]), crc)
+    return crc
 
 
 class _DeviceCopies:
     def __init__(self):
-        self.lock = threading.Lock()
-        self.entries = {}          # id(cpu tensor) -> dict(ref, ptr, shape, dtype, version, device, pieces=[(s, e, gpu, event)], nbytes)
+        self.lock = threading.RLock()   # re-entrant: the weakref callback below may run inside remember() / lookup() (a GC pass on this thread)
+        self.entries = {}          # id(cpu tensor) -> dict(ref, ptr, shape, dtype, version, stamp, device, born, pieces=[(s, e, gpu, event)], nbytes)
         self.order = []            # ids, oldest first
         self.hits = 0
         self.misses = 0
+        self.errors = 0
+        self._timer = None
 
     def _drop(self, key):
         ent = self.entries.pop(key, None)
         if ent is not None and key in self.order:
             self.order.remove(key)
 
+    def _budget(self, device) -> int:
+        cap = DEVICE_CACHE_BYTES
+        try:
+            free, _total = torch.cuda.mem_get_info(device)
+            held = sum(e["nbytes"] for e in self.entries.values())
+            cap = min(cap, int((free + held) * DEVICE_CACHE_FREE_FRACTION))
+        except Exception:
+            pass
+        return cap
+
+    def _arm_timer(self):
+        if DEVICE_CACHE_SECONDS <= 0 or self._timer is not None:
+            return
+        t = threading.Timer(DEVICE_CACHE_SECONDS, self._expire)
+        t.daemon = True
+        self._timer = t
+        t.start()
+
+    def _expire(self):
+        with self.lock:
+            self._timer = None
+            now = time.monotonic()
+            for key in [k for k, e in self.entries.items() if now - e["born"] >= DEVICE_CACHE_SECONDS]:
+                self._drop(key)
+            if self.entries:
+                self._arm_timer()
+
     def remember(self, cpu: torch.Tensor, device: torch.device, pieces):
+        try:
+            self._remember(cpu, device, pieces)
+        except Exception:              # the cache is an optimisation: it never fails a node
+            self.errors += 1
+
+    def _remember(self, cpu, device, pieces):
         import weakref
         nbytes = sum(int(g.numel()) * g.element_size() for _, _, g, _ in pieces)
-        if DEVICE_CACHE_BYTES <= 0 or nbytes > DEVICE_CACHE_BYTES:
+        if DEVICE_CACHE_BYTES <= 0 or cpu.device.type != "cpu" or not cpu.is_contiguous():
             return
         key = id(cpu)
         with self.lock:
             self._drop(key)
+            budget = self._budget(device)
+            if nbytes > budget:
+                return
             total = sum(e["nbytes"] for e in self.entries.values())
-            while self.order and total + nbytes > DEVICE_CACHE_BYTES:
+            while self.order and total + nbytes > budget:
                 old = self.order[0]
                 total -= self.entries[old]["nbytes"]
                 self._drop(old)
@@ -174,26 +252,43 @@ class _DeviceCopies:
                 with self.lock:
                     self._drop(key)
             self.entries[key] = {"ref": weakref.ref(cpu, gone), "ptr": cpu.data_ptr(), "shape": tuple(cpu.shape), "dtype": cpu.dtype,
-                                 "version": cpu._version, "device": device, "pieces": pieces, "nbytes": nbytes}
+                                 "version": _version_of(cpu), "stamp": _content_stamp(cpu), "device": device, "born": time.monotonic(),
+                                 "pieces": pieces, "nbytes": nbytes}
             self.order.append(key)
+            self._arm_timer()
 
     def lookup(self, cpu: torch.Tensor, device: torch.device):
         """The device pieces of `cpu` if it is, unchanged, a result this process downloaded from `device`; else None."""
         if DEVICE_CACHE_BYTES <= 0:
             return None
+        try:
+            return self._lookup(cpu, device)
+        except Exception:
+            self.errors += 1
+            with self.lock:
+                self._drop(id(cpu))
+            return None
+
+    def _lookup(self, cpu, device):
         with self.lock:
             ent = self.entries.get(id(cpu))
             ok = (ent is not None and ent["ref"]() is cpu and ent["ptr"] == cpu.data_ptr() and ent["shape"] == tuple(cpu.shape) and
-                  ent["dtype"] == cpu.dtype and ent["version"] == cpu._version and ent["device"] == device)
+                  ent["dtype"] == cpu.dtype and ent["device"] == device and ent["version"] == _version_of(cpu) and
+                  (DEVICE_CACHE_SECONDS <= 0 or time.monotonic() - ent["born"] < DEVICE_CACHE_SECONDS) and
+                  ent["stamp"] == _content_stamp(cpu))
             if not ok:
                 if ent is not None:
-                    self._drop(id(cpu))           # changed since the download: the device copy is stale
+                    self._drop(id(cpu))           # changed since the download (or too old): the device copy is stale
                 self.misses += 1
                 return None
             self.hits += 1
             self.order.remove(id(cpu))
             self.order.append(id(cpu))
             return ent["pieces"]
+
+    def held_bytes(self) -> int:
+        with self.lock:
+            return sum(e["nbytes"] for e in self.entries.values())
 
     def clear(self):
         with self.lock:
@@ -202,6 +297,14 @@ class _DeviceCopies:
 
 
 _DEVICE_COPIES = _DeviceCopies()
+
+
+def release_device_copies() -> int:
+    """Drop every device copy kept for adjacent nodes (bytes released to torch's allocator).  For hosts that want the HBM back at once --
+    e.g. before loading a model; the copies also expire by themselves after VRGDG_DEVICE_CACHE_SECONDS."""
+    n = _DEVICE_COPIES.held_bytes()
+    _DEVICE_COPIES.clear()
+    return n
 
 
 def _device_frames(pieces, s: int, e: int, compute):
@@ -331,6 +434,16 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
     n_lanes = min(len(devices), len(pieces))
     cached = _DEVICE_COPIES.lookup(images, devices[0]) if n_lanes == 1 else None      # an unchanged result of a previous node: already in HBM
+    if _DEVICE_COPIES.held_bytes():
+        # device copies kept for adjacent nodes never stand in the way of a call's own pipeline (pieces in flight: input + output +
+        # the kernels' workspaces): short of memory, they go first
+        try:
+            free, _total = torch.cuda.mem_get_info(devices[0])
+            free += torch.cuda.memory_reserved(devices[0]) - torch.cuda.memory_allocated(devices[0])
+            if free < 4 * PIPE_DEPTH * per * (in_fb + out_fb):
+                release_device_copies()
+        except Exception:
+            pass
     produced = []
     with _STAGING.lock:
         lanes = []

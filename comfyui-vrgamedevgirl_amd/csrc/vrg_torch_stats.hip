@@ -24,6 +24,7 @@
 //
 // oracle/torch_device_reduce.py restates the same algorithm in numpy; both are held bit-equal to torch on the device
 // (tests/golden/torch_reduce_truth.npz collected on the MI355X; tests/test_gpu_parity.py compares with torch directly).
+#include <atomic>
 #include "vrg_tstats_body.hpp"
 
 namespace vrg {
@@ -459,12 +460,17 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
             // one accumulator per lane: eight 7-wave workgroups per frame + torch's block as the finishing kernel
             TsLanes* recs = reinterpret_cast<TsLanes*>(scratch);
             const size_t lds = (size_t)(n / 1024 + 2) * sizeof(float2);
-            static bool attr_set = false;
-            if (!attr_set) {
+            // the attribute belongs to the function ON A DEVICE: once per device of this process (a bit per device index; a GPU beyond
+            // 64 sets it on every call), set by whichever host thread gets there first -- setting it twice is harmless
+            static std::atomic<uint64_t> attr_devices{0};
+            int device = 0;
+            if (hipGetDevice(&device) != hipSuccess) return VRG_ERR_LAUNCH;
+            const uint64_t bit = (device >= 0 && device < 64) ? (1ull << device) : 0;
+            if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tstats_lanes<VRG_TS_LANES_DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         TS_LANES_MAX_STEPS * (int)sizeof(float2)) != hipSuccess)
                     return VRG_ERR_LAUNCH;
-                attr_set = true;
+                attr_devices.fetch_or(bit, std::memory_order_release);
             }
             hipLaunchKernelGGL((k_tstats_lanes<VRG_TS_LANES_DEPTH>), dim3((unsigned)(64 * ((frames + 7) / 8))), dim3(448), lds, st, lab, n, frames, recs);
             hipLaunchKernelGGL(k_tstats_lanes_finish, dim3((unsigned)frames), dim3(512), 0, st, recs, cm.bw, cm.bh, factor, eps, out);

@@ -693,6 +693,90 @@ def device_stats_status(device=None) -> dict:
 
 def _device_stats_selfcheck(device) -> None:
     device_stats_selfcheck(device)
+    if os.environ.get("VRGDG_SELFCHECK", "1") != "0":
+        toolchain_selfcheck(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# Toolchain coupling, checked at first use: two fast forms rest on measurements of ONE ROCm build --
+#   * dev_pow_ziv's rounding test carries half-widths calibrated against this build's ocml logarithm (tools/ziv_calibration.json);
+#     another ocml could make it accept a wrongly rounded power;
+#   * the steady rows of the wave march issue their LUT gathers as inline-assembly LDS-DMA with hand-counted `vmcnt` waits
+#     (csrc/vrg_march.hip); a compiler that schedules other memory operations between them breaks the count.
+# The first colour match / fused chain on a device compares (a) dev_pow_ziv at its three call sites with torch.pow -- ocml's powf --
+# on that device over 3 x 2^20 arguments of the call sites' domains, the neighbourhood of 1.0 included, and (b) the march with the
+# LDS-tile kernels (vrg_chain_desc.variant 2 against 1) on a geometry whose rows are steady.  (b) failing switches the automatic
+# choice to the tile kernels for the process (same results, slower) and warns; (a) failing warns and is reported by
+# `toolchain_status()` -- the powers then differ from the reference's by an ulp in rare lanes.
+# ------------------------------------------------------------------------------------------------
+_TOOLCHAIN = {}              # device index -> {"pow": bool, "march": bool}
+_POW_SITES = ((12, 2.4, 0.0625, 2.0), (13, 1.0 / 2.4, 0.0031308, 4.0), (14, 1.0 / 3.0, 0.008856, 4.0))
+
+
+def _pow_probe_arguments(lo: float, hi: float, device) -> torch.Tensor:
+    a, b = np.float32(lo).view(np.uint32), np.float32(hi).view(np.uint32)
+    n = 1 << 20
+    bits = (int(a) + (np.arange(n, dtype=np.uint64) * (int(b) - int(a)) // (n - 1))).astype(np.uint32)
+    near1 = (np.float32(1.0).view(np.uint32) + np.arange(-4096, 4096, dtype=np.int64)).astype(np.uint32)      # saturated pixels: x ~ 1
+    return torch.from_numpy(np.concatenate([bits, near1]).view(np.float32)).to(device)
+
+
+def toolchain_selfcheck(device, force: bool = False) -> dict:
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    with _STATE_LOCK:
+        if key in _TOOLCHAIN and not force:
+            return _TOOLCHAIN[key]
+        _TOOLCHAIN[key] = {"pow": True, "march": True}         # re-entrancy: the probes below run fused_chain themselves
+    dev = torch.device("cuda", key)
+    res = {"pow": True, "march": True}
+    with torch.cuda.device(key):
+        lib = _hip.lib()
+        for op, y, lo, hi in _POW_SITES:
+            x = _pow_probe_arguments(lo, hi, dev)
+            got = torch.empty_like(x)
+            _hip.check(lib.vrg_debug_cm_math(_hip.ptr(x), _hip.ptr(got), x.numel(), op, _f32(y), _hip.current_stream()), "vrg_debug_cm_math")
+            res["pow"] = res["pow"] and bool(torch.equal(got, torch.pow(x, y)))
+        g = torch.Generator(device=dev).manual_seed(20260926)
+        frames = torch.rand((2, 512, 512, 3), generator=g, device=dev)       # one RNG chunk of 2 frames: full-grid Philox geometry, steady rows
+        axis = np.linspace(0.0, 1.0, 33, dtype=np.float32)
+        bb, gg, rr = np.meshgrid(axis, axis, axis, indexing="ij")             # [b][g][r] -> (r, g, b): a smooth non-identity grade
+        table = np.stack([rr ** 1.25, 0.9 * gg + 0.1 * bb, bb * bb], axis=-1).astype(np.float32)
+        lut = upload_lut({"lut": torch.from_numpy(table), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}, dev)
+        outs = []
+        for variant in (2, 1):
+            gen = torch.Generator(device=dev).manual_seed(7)
+            spec = ChainSpec(grain=(0.04, 0.5, 2), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False), variant=variant)
+            outs.append(fused_chain(frames, spec, generator=gen))
+        res["march"] = bool(torch.equal(outs[0], outs[1]))
+    with _STATE_LOCK:
+        _TOOLCHAIN[key] = res
+    if not (res["pow"] and res["march"]):
+        import warnings
+        what = []
+        if not res["march"]:
+            what.append("the wave-march kernel disagrees with the tile kernels (hand-counted waits of its LDS-DMA gathers): fused chains take the "
+                        "tile kernels in this process")
+        if not res["pow"]:
+            what.append("dev_pow_ziv disagrees with this ROCm's powf (its rounding test is calibrated against ROCm 7.0's ocml): colour match may "
+                        "differ from the reference by an ulp in rare pixels")
+        warnings.warn("comfyui-vrgamedevgirl_amd: built or run with another toolchain than the one its fast forms were measured on -- "
+                      + "; ".join(what) + " (ops.toolchain_status())", RuntimeWarning)
+    return res
+
+
+def toolchain_status(device=None) -> dict:
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    res = toolchain_selfcheck(device)
+    return {"pow_equals_ocml": res["pow"], "march_equals_tile_kernels": res["march"], "hip": torch.version.hip, "torch": torch.__version__}
+
+
+def _auto_variant(device) -> int:
+    """vrg_chain_desc.variant for the automatic choice: 0, or 1 (tile kernels) where the march failed its self-check on this device."""
+    if os.environ.get("VRGDG_SELFCHECK", "1") == "0":
+        return 0
+    return 0 if toolchain_selfcheck(device)["march"] else 1
 
 
 @_on_device
@@ -982,6 +1066,11 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             segments.append((F - tail.chunk_frames, tail.chunk_frames, tail))
     lib = _hip.lib()
     st = _hip.current_stream()
+    if spec.variant == 0:
+        v = _auto_variant(x.device)            # first use on a device: the toolchain self-check (a few ms, once)
+        if v:
+            import dataclasses
+            spec = dataclasses.replace(spec, variant=v)
     device_stats = spec.colormatch is not None and _cm_stats(spec.cm_stats, spec.cm_math, x.device) == "device"
     lab_full = img_ms_full = None
     if device_stats:

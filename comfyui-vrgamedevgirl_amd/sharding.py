@@ -77,8 +77,10 @@ def reference_stats_sharded(reference_image: torch.Tensor, rank: int, world: int
     return ops.finalize_stats(merged.to(reference_image.device))
 
 
-def init_from_env(backend: Optional[str] = None):
-    """torchrun-style initialisation: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env."""
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None):
+    """torchrun-style initialisation: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env.  `timeout_s`: the process
+    group's collective timeout (default: torch's -- 10 minutes for RCCL); a caller whose rank 0 works alone for long between two
+    collectives (bench.py: output check + CPU baseline before the final barrier) sets it explicitly."""
     import os
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,6 +99,9 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         kwargs = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}      # bind the RCCL communicator to this rank's GPU
+        if timeout_s is not None:
+            import datetime
+            kwargs["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)

@@ -258,3 +258,54 @@ def test_colour_match_node_hands_whole_statistics_calls_to_every_piece(pkg, monk
     seen.clear()
     (out,) = node.match_color(x[:2], torch.zeros((3, 4, 4, 3)), 1.0, 1)       # one-frame chunks: 3 calls of one frame each, per frame
     assert out.shape[0] == 6 and seen == [(6, [1] * 6)]
+
+
+def test_device_copy_cache_under_inference_mode_and_alias_writes(pkg, monkeypatch):
+    """ComfyUI runs every node under torch.inference_mode(): such tensors track no version counter (reading `_version` raises), so the
+    cache of device copies validates them by its content stamp instead; a write through a numpy alias that the version counter cannot
+    see drops the copy where it touches a sampled page; the weak-reference callback may run while the (re-entrant) lock is held; a
+    failure inside the bookkeeping never reaches the node (ADVICE round 4, high + medium + low)."""
+    import gc
+    from comfyui_vrgamedevgirl_amd import _devices as D
+    cpu = torch.device("cpu")
+    c = D._DeviceCopies()
+    monkeypatch.setattr(c, "_budget", lambda device: 1 << 30)
+    monkeypatch.setattr(D, "DEVICE_CACHE_SECONDS", 0.0)            # no timer thread in this test
+    with torch.inference_mode():
+        t = torch.rand(8, 64, 64, 3)
+        with pytest.raises(RuntimeError):
+            t._version
+        assert D._version_of(t) is None
+        c.remember(t, cpu, [(0, 8, torch.empty(16), None)])
+        assert c.errors == 0 and id(t) in c.entries
+        assert c.lookup(t, cpu) is not None and c.hits == 1
+        t.numpy()[0, 0, 0, 0] += 1.0                               # alias write: no version counter anywhere
+        assert c.lookup(t, cpu) is None and id(t) not in c.entries
+    u = torch.rand(4, 32, 32, 3)
+    c.remember(u, cpu, [(0, 4, torch.empty(16), None)])
+    u[3, 31, 31, 2] += 1.0                                          # ordinary tensor: the version counter sees every in-place op
+    assert c.lookup(u, cpu) is None
+    # sampled stamp: first and last page always covered
+    big = torch.rand(64, 256, 256, 3)
+    s0 = D._content_stamp(big)
+    big.numpy()[-1, -1, -1, -1] += 1.0
+    assert D._content_stamp(big) != s0
+    # the weak-reference callback takes the lock remember() / lookup() hold: re-entrant
+    v = torch.rand(2, 8, 8, 3)
+    c.remember(v, cpu, [(0, 2, torch.empty(4), None)])
+    key = id(v)
+    with c.lock:
+        del v
+        gc.collect()
+    assert key not in c.entries
+    # expiry: copies older than DEVICE_CACHE_SECONDS are not handed out
+    monkeypatch.setattr(D, "DEVICE_CACHE_SECONDS", 1e-9)
+    monkeypatch.setattr(c, "_arm_timer", lambda: None)
+    w = torch.rand(2, 8, 8, 3)
+    c.remember(w, cpu, [(0, 2, torch.empty(4), None)])
+    assert c.lookup(w, cpu) is None
+    # a failing stamp never fails the caller
+    monkeypatch.setattr(D, "_content_stamp", lambda t: (_ for _ in ()).throw(ValueError("boom")))
+    c.remember(w, cpu, [(0, 2, torch.empty(4), None)])
+    assert c.errors >= 1 and c.lookup(w, cpu) is None
+    assert D.release_device_copies() >= 0

@@ -39,6 +39,8 @@ if which == "traffic":
     lab_ws = torch.empty_like(x)
     ops.fused_chain(x, specs["chain4"], generator=gen, out=out, lab_workspace=lab_ws)
     ops.fused_chain(x, specs["chain3"], generator=gen, out=out)
+    ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0)), generator=gen, out=out)      # bench leg grain_lut_1080p's kernel
+    ops.fused_chain(x, ops.ChainSpec(colormatch=(ref_ms, 1.0)), out=out, lab_workspace=lab_ws)             # bench leg colormatch_4k's three passes
     ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 42, 0)      # k_sharpen_grain: 12 + 12 B/px if the row re-reads stay in L2
     torch.cuda.synchronize()
     print("done traffic")
