@@ -11,8 +11,8 @@ batch: reference-frame statistics, the statistics pass over the batch, and the f
 per-GPU work is fixed, value = all ranks' pixels / max time.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the step, timed with HIP events on the stream
-it is launched on: the contract's HBM figures plus the unit that actually binds it (`bound`, `valu_busy_frac`,
-`issue_frac_weighted`).  `configs` (N = 1) holds the other single-GPU BASELINE configs as legs of the same run, each timed
+it is launched on: the contract's HBM figures plus the unit that actually binds it (`bound`, `valu_busy_frac`;
+`issue` has the terms).  `configs` (N = 1) holds the other single-GPU BASELINE configs as legs of the same run, each timed
 the way the headline is, on both synthetic pixel distributions: chain3_4k x256 (configs[2]), grain_lut_1080p x128
 (configs[1]), colormatch_4k x512 (configs[3]), and the headline on video-like pixels -- with ms_per_step, Mpixels/s, the
 dominant kernel, its HBM and VALU-busy fractions and `verified` (first / last RNG chunk against the oracle after the timed
@@ -144,8 +144,8 @@ PASS_KERNELS = {
     ("chain4_4k", "apply"): ("k_apply_march<",),
     ("chain4_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
     ("chain3_4k", "apply"): ("k_chain_march<3, true",),
-    ("grain_lut_1080p", "apply"): ("k_chain_pointwise", "k_chain_tile<3", "k_chain_march<3, false"),
-    ("colormatch_4k", "stats"): ("k_lab_partials", "k_rgb_lab", "k_produce_lab<0"),
+    ("grain_lut_1080p", "apply"): ("k_chain_pointwise<3",),
+    ("colormatch_4k", "stats"): ("k_lab_partials<0, true>",),
     ("colormatch_4k", "apply"): ("k_apply_march<",),
     ("colormatch_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
 }
@@ -174,7 +174,7 @@ def live_traffic(timeout_s=150):
     try:
         for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), sq):
             out = os.path.join(tmp, counters[0])
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", VRGDG_SELFCHECK="0")      # (the first-use self-check would launch the same kernels on tiny frames)
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
             subprocess.run([exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "-o", "p", "--",
@@ -477,10 +477,33 @@ def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_sta
     return R
 
 
+VALU_PEAK_T = 66.47       # T lane-instr/s: v_fma_f32 at 8 waves/SIMD over >= 17 ms launches on this chip (profiles/r02_valu_issue_rate_long.json; 78.6 by the clock)
+
+
+def valu_fractions(c, rate_px_s):
+    """Two readings of "how busy is the VALU" for a kernel with PMC record `c` running at `rate_px_s` pixels per second:
+      valu_busy_frac            = class-weighted lane-instructions per second / the measured v_fma_f32 peak.  Weights = measured issue cost
+                                  relative to a plain fp32 / integer op: transcendental 3.45x, 64-bit integer multiply-add 1.8x
+                                  (profiles/r02_valu_issue_rate_long.json; v_pk_* and compare+select pairs, 1.8x / 1.65x, have no counter: not
+                                  included, so this is a lower bound of the issue time);
+      sq_active_inst_valu_x4    = SQ_ACTIVE_INST_VALU x 4 per pixel x the rate / (1,024 SIMDs x 2.4 GHz) -- rocprof's "VALUBusy" formula.  On
+                                  gfx950 the counter advances ~1.02 per VALU wave-instruction whatever the instruction (4.88 for 4.76
+                                  instructions per pixel in the march, 10.94 for 10.74 in pass 1), i.e. it counts instructions in quad-cycle
+                                  clothing while a SIMD-32 issues a wave64 instruction in 2 cycles: the formula reads 128 % for pass 1 and
+                                  222 % for rgb->Lab.  Reported for transparency; not a roofline."""
+    ipp = c.get("valu_lane_instr")
+    if not ipp:
+        return None, None
+    w = ipp + 2.45 * (c.get("valu_trans") or 0.0) + 0.8 * (c.get("valu_int64") or 0.0)
+    busy = c.get("valu_busy_simd_cycles")
+    return round(w * rate_px_s / 1e12 / VALU_PEAK_T, 4), (round(busy * rate_px_s / SIMD_CYCLES_PER_S, 4) if busy else None)
+
+
 def leg_summary(R, world, pmc, pmc_src):
     """The compact record of a leg for the line's `configs` object: whole-leg rate, the dominant pass and its two roofline fractions --
-    algorithmic bytes against 8 TB/s (`hbm_frac`) and VALU-busy cycles against the 1,024 SIMDs (`valu_busy_frac`; SQ_ACTIVE_INST_VALU per
-    pixel of that kernel from the PMC pass named in `pmc_source` x the pixel rate the pass reached here)."""
+    algorithmic bytes against 8 TB/s (`hbm_frac`) and class-weighted VALU issue against the measured peak (`valu_busy_frac`, see
+    valu_fractions; instruction counts per pixel of that kernel from the PMC pass named in `pmc_source` x the pixel rate the pass reached
+    here)."""
     stages, px = R["stages"], R["px_rank"]
     ms = R["elapsed"] / R["steps"] * 1e3
     bpp_chain = 36 if "colormatch" in stages else 24
@@ -488,15 +511,14 @@ def leg_summary(R, world, pmc, pmc_src):
     dms = R["pass_ms"][dom]
     rate = px / (dms * 1e-3) if dms > 0 else 0.0
     c = pmc.get((R["workload"], dom), {}) if pmc else {}
-    busy = c.get("valu_busy_simd_cycles") or None
+    vfrac, x4 = valu_fractions(c, rate)
     out = {"workload": R["workload"], "pixels": f"synthetic-{R['dist']}", "frames": R["frames"], "height": R["H"], "width": R["W"], "stages": "+".join(stages),
            "steps": R["steps"], "warmup": R["warmup"], "ms_per_step": round(ms, 3), "Mpix_s": round(world * px / ms / 1e3, 1),
            "algorithmic_bytes_per_pixel": bpp_chain, "hbm_frac": round(px / (ms * 1e-3) * bpp_chain / (HBM_PEAK_GBS * 1e9), 4),
            "passes_ms": {k: round(v, 3) for k, v in R["pass_ms"].items()},
            "dominant_kernel": _kernel_name(stages, dom), "dominant_kernel_ms": round(dms, 3),
            "dominant_kernel_hbm_frac": round(ALGO_BPP[dom] * rate / 1e9 / HBM_PEAK_GBS, 4),
-           "valu_busy_frac": round(busy * rate / SIMD_CYCLES_PER_S, 4) if busy else None,
-           "valu_busy_simd_cycles_per_px": busy, "valu_lane_instr_per_px": c.get("valu_lane_instr") or None,
+           "valu_busy_frac": vfrac, "sq_active_inst_valu_x4_frac": x4, "valu_lane_instr_per_px": c.get("valu_lane_instr") or None,
            "wait_issue_share_of_wave_cycles": c.get("wait_issue_share"), "wait_memory_share_of_wave_cycles": c.get("wait_memory_share"),
            "hbm_bytes_per_px_measured": c.get("total") or None, "pmc_source": pmc_src if c else None,
            "verified": None if R["verify"] is None else bool(R["verify"].get("verified"))}
@@ -592,7 +614,7 @@ def main():
     # lane-instructions per pixel x the rate against the measured v_fma_f32 peak, weighted by the issue cost of the instruction classes
     # that have a counter.
     rate = px_rank / (kern_avg_ms * 1e-3) if kern_avg_ms > 0 else 0.0
-    valu_busy = round(c["valu_busy_simd_cycles"] * rate / SIMD_CYCLES_PER_S, 4) if c.get("valu_busy_simd_cycles") else None
+    valu_busy, valu_x4 = valu_fractions(c, rate)
     issue = None
     try:
         rates, rname = _profile_json("r02_valu_issue_rate_long.json", "r01_valu_issue_rate.json")
@@ -646,13 +668,13 @@ def main():
             "roofline": {"bound": bound, "kernel": _kernel_name(stages, dom),
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "valu_busy_frac": valu_busy,
-                         "issue_frac_weighted": issue["weighted"]["frac_of_measured_peak_66p5"] if issue else None,
+                         "valu_busy_frac": valu_busy, "sq_active_inst_valu_x4_frac": valu_x4,
                          "bound_note": ("`achieved` / `peak` / `frac` are the contract's HBM figures (algorithmic bytes of the dominant kernel / its HIP-event "
                                         "time / 8 TB/s).  `bound` names the unit that limits the kernel: its measured HBM traffic is the algorithmic "
-                                        "bytes (`traffic`), so HBM does not bind it; `valu_busy_frac` = SQ_ACTIVE_INST_VALU per pixel x this run's pixel "
-                                        "rate / (1,024 SIMDs x 2.4 GHz) and `issue_frac_weighted` = class-weighted lane-instructions per second / the "
-                                        "measured v_fma_f32 peak are the fractions of the VALU roofline it reaches (DESIGN.md section 5.1)"),
+                                        "bytes (`traffic`), so HBM does not bind it; `valu_busy_frac` = class-weighted VALU lane-instructions per second "
+                                        "/ the measured v_fma_f32 peak (66.5 T/s; `issue` has the terms) is the fraction of the VALU roofline it reaches; "
+                                        "`sq_active_inst_valu_x4_frac` is rocprof's VALUBusy formula, which exceeds 1 on gfx950 (the counter advances once "
+                                        "per instruction, a SIMD-32 issues a wave64 instruction in 2 cycles): reported, not used (DESIGN.md section 5.1)"),
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": M["launches_per_step"],
@@ -675,7 +697,8 @@ def main():
         cfgs = {"headline": leg_summary(M, world, pmc, pmc_src)}
         for wl, pd, nf in legs:
             try:
-                L = run_workload(C, args, wl, pd, nf, max(args.steps // 2, 3), 2, verify=not args.no_verify)
+                # (a 1080p step is 3 ms: one host hiccup inside five of them shows -- those legs take four times the steps)
+                L = run_workload(C, args, wl, pd, nf, max(args.steps // 2, 3) * (4 if WORKLOADS[wl][0] <= 1080 else 1), 3, verify=not args.no_verify)
                 cfgs[f"{wl}.{pd}"] = leg_summary(L, world, pmc, pmc_src)
             except Exception as exc:
                 cfgs[f"{wl}.{pd}"] = {"error": f"{type(exc).__name__}: {exc}"}

@@ -19,7 +19,7 @@ STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
 ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NoiseDesc(C.Structure):

@@ -5,9 +5,7 @@
 
 namespace vrg {
 
-#ifndef VRG_APPLY_ROWS
 #define VRG_APPLY_ROWS 60     /* rows per strip segment, a multiple of 3 (the row registers rotate by name) */
-#endif
 constexpr int APPLY_ROWS = VRG_APPLY_ROWS;
 constexpr int APPLY_COLS = 62;                    // output columns per wave
 static_assert(APPLY_ROWS % 3 == 0, "APPLY_ROWS must be a multiple of 3");
@@ -28,9 +26,7 @@ struct AmRow { float l[3], c[3], r[3]; };               // one processed row: le
 // compiler's memory counter stays exact (a store inside an exec-masked block merges to `s_waitcnt vmcnt(0)` at the join), and the
 // next row is requested BEFORE the current row's ~450 instructions of colour transfer instead of after them: the request lands under
 // that arithmetic where it used to be waited for ~100 instructions after its issue (one exposed L2 / HBM latency per row and wave).
-#ifndef VRG_APPLY_EARLY_LOAD
 #define VRG_APPLY_EARLY_LOAD 1
-#endif
 template <int STAGES, class MATH, bool GENERAL = true>
 __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid, const px3* __restrict__ in, px3* __restrict__ out, int32_t H, int32_t W,
                                                  int32_t strips_x, int32_t segs_y, uint32_t total_waves, const ChainK& D, const MATH& PT) {

@@ -41,11 +41,7 @@ static int launch_apply_march_t(const float* in, float* out, int64_t frames, int
         const uint32_t groups = (total + 3u) / 4u;
         const uint32_t blocks = ((groups + 7u) / 8u) * 8u;
         // frames of at least one strip x one segment and below 2 GiB: the form without conditional blocks (vrg_apply_body.hpp)
-#ifdef VRG_APPLY_FORCE_GENERAL      /* A/B only */
-        if (false)
-#else
         if (W >= APPLY_COLS && H >= APPLY_ROWS && ppf * 12 < ((int64_t)1 << 31))
-#endif
             hipLaunchKernelGGL((k_apply_march<STAGES, false>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<const px3*>(in) + f0 * ppf,
                                reinterpret_cast<px3*>(out) + f0 * ppf, H, W, strips_x, segs_y, total, d);
         else

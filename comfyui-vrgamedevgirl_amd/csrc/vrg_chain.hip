@@ -74,9 +74,7 @@ __global__ __launch_bounds__(256) void k_chain_pointwise4(const px3* __restrict_
 // tile plus a one-pixel halo is staged in LDS as three planes (conflict-free row reads), then every
 // thread produces 8 output pixels.  Halo recompute: (34*66)/(32*64) = 1.096x.
 // ----------------------------------------------------------------------------------------------
-#ifndef VRG_TILE_H
 #define VRG_TILE_H 32
-#endif
 constexpr int TILE_H = VRG_TILE_H, TILE_W = 64;
 constexpr int TILE_ROWS = TILE_H / 4;      // rows per thread: 4 row groups of 64 columns in a 256-thread block
 constexpr int HALO_H = TILE_H + 2, HALO_W = TILE_W + 2;
@@ -104,9 +102,7 @@ __global__ __launch_bounds__(256) void k_chain_tile(const typename IO::elem* __r
     const bool zero = D.zero_border != 0;
     const FrameCtx FC = frame_ctx<STAGES>(D, f);
 
-#ifndef VRG_TILE_PRELOAD
 #define VRG_TILE_PRELOAD 1
-#endif
     constexpr int N_IT = (HALO_H * HALO_W + 255) / 256;
     if (VRG_TILE_PRELOAD && !(STAGES & VRG_STAGE_COLORMATCH) && !((STAGES & VRG_STAGE_GRAIN) && !(STAGES & VRG_STAGE_LUT))) {      // (grain -> sharpen alone measured 5 % slower with it)
         // light pre stages: all of this thread's tile + halo pixels are requested first, branch-free (coordinates clamped into the frame
@@ -377,11 +373,7 @@ static int launch_chain(const void* in, void* out, int64_t frames, int32_t H, in
             const uint32_t total = (uint32_t)(tpf * nf);
             const uint32_t blocks = ((total + 7u) / 8u) * 8u;
             hipLaunchKernelGGL((k_chain_tile<STAGES, IO>), dim3(blocks), dim3(256), 0, st, src, dst, H, W, tx, (int32_t)tpf, total, d);
-#ifndef VRG_NO_POINTWISE4           /* (macro: A/B only) */
         } else if ((STAGES & VRG_STAGE_COLORMATCH) && !(STAGES & VRG_STAGE_GRAIN) && std::is_same<IO, IoF32>::value && ppf * 12 < ((int64_t)1 << 31)) {
-#else
-        } else if (false) {
-#endif
             launch_pointwise4<STAGES, IO>(src, dst, ppf, nf, d, st);
         } else {
             hipLaunchKernelGGL((k_chain_pointwise<STAGES, IO>), dim3((uint32_t)((ppf + 255) / 256), (uint32_t)nf), dim3(256), 0, st,
@@ -546,12 +538,10 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
     }
     // (LUT ->) colour match -> stencil without a grain stage -- pass 2 of the headline chain: the apply march (variant 0 and 2; 1 forces
     // the LDS-tile kernel for A/B and cross-checks).  Frames whose statistics groups it cannot keep together fall through.
-#ifndef VRG_NO_APPLY_MARCH
     if ((desc->variant & 0xff) != 1 && apply_march_applicable(desc->stages, height, width)) {
         const int rc = launch_apply_march(in, out, frames, height, width, D, desc->stages, desc->cm_math == VRG_CM_MATH_FAST, (hipStream_t)stream);
         if (rc != VRG_ERR_UNSUPPORTED) return rc;
     }
-#endif
     if ((desc->variant & 0xff) == 0 && desc->stages == VRG_STAGE_LUT && lut_lds_applicable(desc->lut_size, frames * height * width))
         return launch_lut_lds(in, out, frames * (int64_t)height * width, D.lut, false, (hipStream_t)stream);   // small cube: table in LDS
 #define CALL(S) launch_chain<S>(in, out, frames, height, width, D, sharpen, (hipStream_t)stream)

@@ -1,5 +1,23 @@
 // vrg_common.hpp -- kernel-side parameter blocks shared by the translation units of libvrgdg_hip.so
 #pragma once
+
+// The tuning constants and the A/B or ablation switches that rounds 1-4 passed with -D are FIXED in the product sources (plain #defines
+// next to their measurements; the march's and the wrong-pixel ablations are gone altogether).  Nothing in this library is selected by a
+// command-line macro: a -D of one of the old names is a build error, so that no flag can turn the product into another -- or a
+// wrong-answer -- library.  Variants for A/B runs are separate source files under tools/ab/ (tools/build_variant.py --source, which
+// defines VRG_LAB_VARIANT_SOURCE for that one file: the frozen round-4 march still takes its -DVRG_MARCH_... switches that way).
+#if !defined(VRG_LAB_VARIANT_SOURCE) && (defined(VRG_APPLY_EARLY_LOAD) || defined(VRG_APPLY_ROWS) || defined(VRG_FLAT_ROWS) || defined(VRG_GRAIN_NT) || \
+    defined(VRG_PRODUCE_MAX_WAVES_LABONLY) || defined(VRG_PRODUCE_WAVES) || defined(VRG_PRODUCE_WAVES_LABONLY) || defined(VRG_PR_PIPE) || \
+    defined(VRG_PR_SUBS) || defined(VRG_SG_PIPE) || defined(VRG_TILE_H) || defined(VRG_TILE_PRELOAD) || \
+    defined(VRG_TS_LANES) || defined(VRG_TS_LANES_DEPTH) || defined(VRG_TS_LANES_MAX_FRAMES) || defined(VRG_TS_LANES_MEAN_DEPTH) || \
+    defined(VRG_TS_MARKSTEIN) || defined(VRG_TS_ROWS_DEPTH) || defined(VRG_TS_ROWS_MAX_FRAMES) || defined(VRG_TS_SPLIT_DEPTH) || \
+    defined(VRG_TS_SPLIT_MAX_FRAMES) || defined(VRG_TS_WHOLE_DEPTH) || defined(VRG_ZIV_REL) || defined(VRG_MARCH_FAST) || \
+    defined(VRG_MARCH_MIN_WAVES) || defined(VRG_MARCH_FINITE) || defined(VRG_MARCH_ABLATE) || defined(VRG_MARCH_QUAD) || \
+    defined(VRG_MARCH_ENDIO) || defined(VRG_MARCH_ROTATE) || defined(VRG_MARCH_TAPS_UNFOLD) || defined(VRG_MARCH_FAST_FLAT) || \
+    defined(VRG_MARCH_EDGE_SHARED) || defined(VRG_MARCH_FAST_LDS) || defined(VRG_NO_POINTWISE4) || defined(VRG_NO_APPLY_MARCH) || \
+    defined(VRG_NO_FLAT_STENCIL) || defined(VRG_APPLY_FORCE_GENERAL) || defined(VRG_ABLATE_GATHER) || defined(VRG_NO_DIVT_FASTPATH))
+#error "comfyui-vrgamedevgirl_amd: tuning / ablation macros are not build options of the product sources (see the note above this line)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -132,6 +150,11 @@ inline LutParams make_lut(const float* cells, int n, const float dmin[3], const 
                           float blend, float one_minus_blend) {
     LutParams P;
     P.cells = cells; P.n = n; P.top = (float)(n - 1);
+    if (lut_cell_major(n)) {
+        P.q_cells = cells + lut_record_floats(n); P.q_rec_stride = LUT_CELL_FLOATS; P.q_row_stride = (n - 1) * LUT_CELL_FLOATS;
+    } else {
+        P.q_cells = cells; P.q_rec_stride = LUT_REC_FLOATS; P.q_row_stride = n * LUT_REC_FLOATS;
+    }
     P.unit_domain = 1;
     for (int c = 0; c < 3; ++c) {
         P.dmin[c] = dmin[c];

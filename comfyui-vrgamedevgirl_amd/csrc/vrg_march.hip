@@ -21,29 +21,13 @@
 // Without a grain stage the same kernel runs with a synthetic G = 48 rows (siblings = four row bands).
 #include "vrg_chain_stages.hpp"
 
-#ifndef VRG_MARCH_FAST
-#define VRG_MARCH_FAST 1      /* 0: every row takes the general step (round 3's kernel) */
-#endif
-#ifndef VRG_MARCH_MIN_WAVES
-#define VRG_MARCH_MIN_WAVES 3   /* waves per SIMD the register allocation must leave room for (launch bound) */
-#endif
-#ifndef VRG_MARCH_FINITE
-#define VRG_MARCH_FINITE 1    /* behind a LUT stage the rows are finite values in [0, 1]: the mean's Inf / NaN pass-through and the final clamp's NaN pass-through of the steady rows are dropped (same bits for finite data) */
-#endif
-#ifndef VRG_MARCH_ABLATE
-#define VRG_MARCH_ABLATE 0    /* TIMING ABLATIONS of the steady rows (wrong pixels; tools/build_variant.py): 1 = no table reads (same arithmetic on register values), 2 = no noise synthesis, 4 = the non-steady rows of a fast wave skipped */
-#endif
-#ifndef VRG_MARCH_QUAD
-#define VRG_MARCH_QUAD 1      /* steady rows: the LUT gathers as quad-cooperative LDS-DMA (see lut_issue_dma) instead of six 16-byte loads per lane */
-#endif
-#ifndef VRG_MARCH_ENDIO
-#define VRG_MARCH_ENDIO 1     /* steady rows: the next row's pixel loads and the four stores are issued at the END of the row step, so that between the gathers' issue and their use no other memory operation sits in the (in-order) memory counter */
-#endif
-#ifndef VRG_MARCH_ROTATE
-#define VRG_MARCH_ROTATE 0    /* the NEXT row's noise is synthesised in three pieces between the gathers' issue and their use */
-#endif
-
+// The variants this kernel was chosen from (round 3's general row step for every row, per-lane gathers, loads / stores at the head of the
+// row, rotated noise synthesis, timing ablations with wrong pixels, ...) are NOT compile-time switches of the product source: the
+// round-4 source with all of them is tools/ab/r04/vrg_march.hip (build: tools/build_variant.py <name> --unit vrg_march.hip --source
+// tools/ab/r04/vrg_march.hip -DVRG_MARCH_...=...), their measurements LABNOTES.md I.2 / I.9 / I.11.
 namespace vrg {
+
+constexpr int MARCH_MIN_WAVES = 3;      // waves per SIMD the register allocation must leave room for (launch bound of the 4-wave form)
 
 struct MarchK {
     int32_t H, W, E;        // E = 3*W
@@ -68,22 +52,11 @@ __device__ __forceinline__ float lane_next(float v) {   // value held by lane+1
 
 // the same shifts for operands of an add (steady rows): no `old` value and bound_ctrl, so that the backend can fold the shift into
 // the add's first operand (v_add_f32_dpp) -- the lane at the wave's end reads 0.0, and it is a halo lane whose result is dropped
-#ifndef VRG_MARCH_TAPS_UNFOLD
-#define VRG_MARCH_TAPS_UNFOLD 0
-#endif
 __device__ __forceinline__ float tap_prev(float v) {
-#if VRG_MARCH_TAPS_UNFOLD
-    return lane_prev(v);
-#else
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
-#endif
 }
 __device__ __forceinline__ float tap_next(float v) {
-#if VRG_MARCH_TAPS_UNFOLD
-    return lane_next(v);
-#else
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
-#endif
 }
 
 __device__ __forceinline__ int64_t floor_div64(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
@@ -100,7 +73,7 @@ __global__ void k_selftest_lanes(float* out) {
 // stages the cube's node table in LDS (dynamic shared memory, one float4 per node) and the gathers of the LUT stage
 // become ds_read_b128 -- the L1 / L2 gather path that holds the global-table form at ~65 Gpix/s is not used at all.
 template <int STAGES, bool SHARPEN, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MARCH_MIN_WAVES : 1) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? MARCH_MIN_WAVES : 1) void k_chain_march(const float* __restrict__ in, float* __restrict__ out, MarchK M, ChainK D) {
     static_assert(!(STAGES & VRG_STAGE_COLORMATCH), "colour-match chains run on the tile / point-wise kernels");
     extern __shared__ __attribute__((aligned(16))) float march_lut_nodes[];
     const f32x4* lut_nodes = nullptr;
@@ -109,11 +82,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
         lut_nodes = reinterpret_cast<const f32x4*>(march_lut_nodes);
     }
     if (WAVES != 4) __syncthreads();
-    // LDS landing zone of the quad-cooperative gathers (steady rows, VRG_MARCH_QUAD): per wave two slots of six 1040-byte rounds
-#ifndef VRG_MARCH_FAST_FLAT
-#define VRG_MARCH_FAST_FLAT 1    /* the steady-row body for chains WITHOUT a stencil as well (grain -> LUT): no taps, no row history, rows stored as they are computed */
-#endif
-    constexpr bool QUADP = (VRG_MARCH_QUAD != 0) && (VRG_MARCH_FAST != 0) && (SHARPEN || VRG_MARCH_FAST_FLAT) && (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
+    // LDS landing zone of the quad-cooperative gathers (steady rows of grain -> LUT chains over a global table): per wave two slots of six
+    // 1040-byte rounds
+    constexpr bool QUADP = (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
     constexpr int Q_ROUND = 1040, Q_SLOT = 6 * Q_ROUND;
     __shared__ __attribute__((aligned(16))) char quad_slots[QUADP ? 4 * 2 * Q_SLOT : 16];
 
@@ -200,9 +171,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
         float nz[3][4], nx[2][4];
         bool fast = false;
         const int b0 = rowbase - q0s;
-#ifndef VRG_MARCH_EDGE_SHARED
-#define VRG_MARCH_EDGE_SHARED 1   /* rows that leave the Philox quarter (priming rows, the ragged first / last row): shared calls of the neighbouring quarter instead of one call per element */
-#endif
         // Rows that are not wholly inside the job's Philox quarter.  Element `rel` (relative to sibling m's quarter) below 0 lies in the
         // PREVIOUS quarter -- component m - 1 of the same call for m >= 1, component 3 of call k - 1 for m = 0, subsequence rel + G --, at or
         // above G in the NEXT one (component m + 1, or component 0 of call k + 1 for m = 3, subsequence rel - G): the same sharing as in
@@ -214,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
         if (STAGES & VRG_STAGE_GRAIN) {
             fast = (b0 >= 0) && ((uint32_t)(b0 + 3 * 63 + 4) < G);
             const bool own = (b0 + 3 * 63 + 4 >= 0) && (b0 < (int)G);        // some element of the row lies in the quarter
-            if (fast || (VRG_MARCH_EDGE_SHARED && own)) {
+            if (fast || own) {
                 const uint32_t idx0 = (uint32_t)b0 + 3u * (uint32_t)lane;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -233,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     nx[0][m] = lane_next(nz[0][m]);
                     nx[1][m] = lane_next(nz[1][m]);
                 }
-            } else if (VRG_MARCH_EDGE_SHARED) {
+            } else {
                 shared_edge = true;
                 const bool prev = b0 < 0;                                       // wave-uniform: the row reaches into the previous quarter (else the next)
                 const uint32_t idxb = (uint32_t)b0 + (prev ? G : 0u - G) + 3u * (uint32_t)lane;
@@ -399,11 +367,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
     // arithmetic and no exec-masked block in the loop, exact memory counters.  Same device functions (philox_for, box_muller,
     // grain_pixel, lut_axis, lut_fetch_finish, unsharp arithmetic) in the same order: bit-identical to the general step.
     // ------------------------------------------------------------------------------------------------------------------------
-#ifndef VRG_MARCH_FAST_LDS
-#define VRG_MARCH_FAST_LDS 1    /* the steady-row body for the 12-wave form as well (cube of at most 21^3 staged in LDS: the gathers are eight ds_read_b128 per pixel) */
-#endif
-    constexpr bool FASTP = (VRG_MARCH_FAST != 0) && (SHARPEN || VRG_MARCH_FAST_FLAT) && (STAGES & VRG_STAGE_GRAIN) &&
-                           (WAVES == 4 || (VRG_MARCH_FAST_LDS != 0 && (STAGES & VRG_STAGE_LUT)));
+    // (chains without a stencil run the same body minus the taps and the row history; the 12-wave form -- cube of at most 21^3 staged in
+    // LDS -- runs it with eight ds_read_b128 per pixel in the place of the gathers)
+    constexpr bool FASTP = (STAGES & VRG_STAGE_GRAIN) && (WAVES == 4 || (STAGES & VRG_STAGE_LUT));
     bool fast_wave = false;
     if (FASTP) {
         bool ok = M.s[0] == 0 && M.s[1] == 1 && M.s[2] == 2 && M.s[3] == 0 && M.numel < (1 << 29) && r_last - r_first >= 4;
@@ -441,7 +407,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
             }
         }
         if (!steady) {
-            if (!((VRG_MARCH_ABLATE & 4) && fast_wave))       // timing ablation: the non-steady rows of a fast wave are skipped (wrong pixels)
             general_row(rho, rowbase);
             ++rho;
             rowbase += E;
@@ -467,33 +432,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
             const char* const quad_a1 = quad_my + (4 + ((lane & 3) >> 1)) * Q_ROUND + ((lane & ~3) + 2 * (lane & 1)) * 16;
             int rows_done = 0;
             bool more = true;
-            constexpr bool FINITE = VRG_MARCH_FINITE && (STAGES & VRG_STAGE_LUT);       // the stencil's inputs are LUT outputs: finite, in [0, 1]
+            // behind a LUT stage the stencil's inputs are finite values in [0, 1]: the mean's Inf / NaN pass-through and the final clamp's NaN
+            // pass-through are dropped there (same bits for finite data)
+            constexpr bool FINITE = (STAGES & VRG_STAGE_LUT) != 0;
             // one Philox call + its two Box-Muller pairs: the normals of elements idx0 + j of the four siblings
             auto noise_call = [&](uint32_t idx0, int j, float nzj[4]) {
-                if (VRG_MARCH_ABLATE & 2) {
-                    nzj[0] = xin[0].r + (float)j; nzj[1] = xin[1].g; nzj[2] = xin[2].b; nzj[3] = xin[3].r + (float)idx0;
-                    return;
-                }
                 const u32x4 r = philox_for(seed, idx0 + (uint32_t)j, ctr);
                 const f32x2 a = box_muller(r.x, r.y);
                 const f32x2 b = box_muller(r.z, r.w);
                 nzj[0] = a.x; nzj[1] = a.y; nzj[2] = b.x; nzj[3] = b.y;
             };
             float nz[3][4];
-            if (VRG_MARCH_ROTATE) {
-                const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
-            }
             while (more) {
-                // ---- the next row's pixels (row offset in an SGPR)
-                u3 xraw[4];
-                if (!VRG_MARCH_ENDIO) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 0);
-                }
+                u3 xraw[4];           // the next row's pixels, requested at the END of this row step (see there)
                 // ---- noise: three Philox calls per lane, twelve normals
-                if (!VRG_MARCH_ROTATE) {
+                {
                     const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
@@ -511,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     grain_pixel(x, nrm[m], D.I, D.S, D.T, V[m]);
                 }
                 const int out_soff = (SHARPEN ? rowbase - E : rowbase) * 4;
-                // Quad-cooperative LDS-DMA gather (VRG_MARCH_QUAD): a pixel's 96-byte record run is fetched by the FOUR lanes of its quad --
+                // Quad-cooperative LDS-DMA gather: a pixel's 96-byte record run is fetched by the FOUR lanes of its quad --
                 // round p = 0..3: the quad's lanes read the first 64 bytes of the run of the quad's pixel p (one 64-byte segment per quad
                 // and instruction: the texture unit looks up ONE tag for the four lanes where the per-lane form looks up four), rounds 4 / 5
                 // the last 32 bytes of two pixels each -- and the LDS-DMA lays each round out lane-linear (lane * 16 bytes), so pixel 4q+j
@@ -519,12 +472,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                 // transposition costs no VALU and no VGPR, and 2.9 instead of 6.4 L1 accesses per pixel (profiles/r04_probe_gather_pmc.json).
                 // The DMA instructions are inline assembly (the compiler neither counts them nor knows they write the LDS): issue and wait
                 // statements carry a memory clobber, the waits are counted by hand -- between the issue of a sibling's six rounds and their
-                // use only the next sibling's six rounds are issued (VRG_MARCH_ENDIO moves the row's other memory operations to its end).
+                // use only the next sibling's six rounds are issued (the row's other memory operations sit at its end).
                 auto lut_issue_dma = [&](int m) {
                     F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
                     F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
                     F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
-                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (LUT_REC_FLOATS * 4);
+                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.q_row_stride + F[m & 1].R.cell * P.q_rec_stride) * 4;
                     const int ql16 = (lane & 3) * 16, qh16 = 64 + (lane & 1) * 16;
                     const int v0 = __builtin_amdgcn_update_dpp(0, cell, 0x00, 0xf, 0xf, false) + ql16;   // quad_perm [0,0,0,0]
                     const int v1 = __builtin_amdgcn_update_dpp(0, cell, 0x55, 0xf, 0xf, false) + ql16;   // [1,1,1,1]
@@ -543,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                                  "s_mov_b32 m0, %13\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %7\n\t"
                                  "s_mov_b32 m0, %0"
                                  : "=&s"(keep)
-                                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "s"(P.cells), "s"(l0), "s"(l0 + Q_ROUND), "s"(l0 + 2 * Q_ROUND),
+                                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "s"(P.q_cells), "s"(l0), "s"(l0 + Q_ROUND), "s"(l0 + 2 * Q_ROUND),
                                    "s"(l0 + 3 * Q_ROUND), "s"(l0 + 4 * Q_ROUND), "s"(l0 + 5 * Q_ROUND)
                                  : "memory");
                 };
@@ -558,17 +511,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     F[m & 1].hi[2] = *reinterpret_cast<const f32x4*>(s1 + 16);
                 };
                 auto lut_issue = [&](int m) {
-                    if (VRG_MARCH_ABLATE & 1) {
-                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            F[m & 1].lo[ch] = f32x4{V[m][0], V[m][1], V[m][2], V[m][ch]};
-                            F[m & 1].hi[ch] = f32x4{V[m][2], V[m][1], V[m][0], V[m][ch]};
-                        }
-                        return;
-                    }
                     if (QUADP) { lut_issue_dma(m); return; }
                     if ((STAGES & VRG_STAGE_LUT) && WAVES != 4) {       // node table in LDS: the eight corners of the cell, laid out as the record form has them
                         F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
@@ -622,40 +564,30 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                         U[m][c] = Mi[m][c];
                         Mi[m][c] = Dn[c];
                     }
-                    if (!VRG_MARCH_ENDIO) {
-                        __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])}, rs_out,
-                                                              st_voff[m], out_soff, 0);
-                        asm volatile("s_nop 1" ::: "memory");        // see the note at the row-end stores
-                    } else
-                        resq[m] = u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])};
+                    resq[m] = u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])};
                 };
-                // the gathers of sibling m + 1 are in flight while sibling m is interpolated, sharpened and stored; with ROTATE a third of
-                // the next row's noise synthesis (independent of everything here) sits between each issue and the first use of its data
-                const uint32_t idx0n = (uint32_t)(rowbase + E - q0s) + 3u * (uint32_t)lane;
-                float nzn[3][4];
-                static_assert(!QUADP || VRG_MARCH_ENDIO, "the hand-counted waits of the quad form assume that the row's other memory operations sit at its end");
+                // the gathers of sibling m + 1 are in flight while sibling m is interpolated, sharpened and stored.  The hand-counted waits
+                // of the quad form rest on the row's other memory operations sitting at its end: nothing but the next sibling's six rounds
+                // enters the (in-order) memory counter between a sibling's issue and its use.
                 lut_issue(0);
                 lut_issue(1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 0, nzn[0]); __builtin_amdgcn_sched_barrier(0); }
-                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(0); }
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(0); }
                 finish_emit(0);
                 __builtin_amdgcn_sched_barrier(0);
                 lut_issue(2);
                 __builtin_amdgcn_sched_barrier(0);
-                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 1, nzn[1]); __builtin_amdgcn_sched_barrier(0); }
-                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(1); }
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(1); }
                 finish_emit(1);
                 __builtin_amdgcn_sched_barrier(0);
                 lut_issue(3);
                 __builtin_amdgcn_sched_barrier(0);
-                if (VRG_MARCH_ROTATE) { noise_call(idx0n, 2, nzn[2]); __builtin_amdgcn_sched_barrier(0); }
-                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(2); }
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(2); }
                 finish_emit(2);
                 __builtin_amdgcn_sched_barrier(0);
-                if (QUADP && !(VRG_MARCH_ABLATE & 1)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lut_read_dma(3); }
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lut_read_dma(3); }
                 finish_emit(3);
-                if (VRG_MARCH_ENDIO) {
+                {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 0);
@@ -667,12 +599,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && VRG_MARCH_FAST) ? VRG_MA
                     // write right behind the store (profiles/r04_noslp_dpp_fold_diff.log): pad by hand
                     asm volatile("s_nop 1" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                if (VRG_MARCH_ROTATE) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) nz[j][i] = nzn[j][i];
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) xin[m] = px3{__uint_as_float(xraw[m].x), __uint_as_float(xraw[m].y), __uint_as_float(xraw[m].z)};

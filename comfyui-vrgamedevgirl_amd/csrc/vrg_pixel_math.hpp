@@ -244,8 +244,27 @@ struct alignas(16) f32x4 { float x, y, z, w; };
 
 constexpr int LUT_REC_FLOATS = 12;
 
+// Cubes of at most LUT_CELL_MAJOR_MAX_N^3 carry a SECOND copy of the same records behind the record table, cell-major:
+//   [(N-1)][(N-1)][(N-1)][32]  -- one 128-byte ALIGNED record per cell: records r0 and r0 + 1 side by side + 8 floats of padding, so that a
+//                                 pixel's run is ONE cache line where the record form's 96 bytes at a 48-byte granule straddle a line for 5 of
+//                                 8 alignments (1.6 lines per pixel).  (N-1)^3 128 B = 1.77 MB at 25^3 (8 of the reference's 12 cubes): L2
+//                                 resident beside the streaming frames; 4.2 MB at 33^3 is not (measured slower there, LABNOTES I.1).
+// Only the QUAD-COOPERATIVE fetch of the march's steady rows reads it (q_cells / q_rec_stride / q_row_stride below, which describe the record
+// table itself for larger cubes): on incoherent pixels that fetch is bound by L2 -> L1 lines per pixel and gains 18 % (96 -> 113 Gpix/s
+// fetch-only, profiles/r05_probe_gather_25.json); six 16-byte requests PER LANE into one aligned record are slower than into the record form
+// (89 against 110 Gpix/s, same file), so every other kernel keeps reading `cells`.
+// A pixel's run starts at q_cells + (b0 (N-1) + g0) q_row_stride + r0 q_rec_stride floats in either layout and is read the same way.
+constexpr int LUT_CELL_FLOATS = 32;
+constexpr int LUT_CELL_MAJOR_MAX_N = 28;
+VRG_HD bool lut_cell_major(int n) { return n <= LUT_CELL_MAJOR_MAX_N; }
+VRG_HD long long lut_record_floats(int n) { return (((long long)(n - 1) * (n - 1) * n * LUT_REC_FLOATS) + 31) / 32 * 32; }      // padded to a whole line
+VRG_HD long long lut_table_floats(int n) { return lut_record_floats(n) + (lut_cell_major(n) ? (long long)(n - 1) * (n - 1) * (n - 1) * LUT_CELL_FLOATS : 0); }
+
 struct LutParams {
     const float* cells;  // [(N-1)][(N-1)][N][12]
+    const float* q_cells;   // what the quad-cooperative fetch reads: the cell-major copy (cubes up to 28^3) or `cells`
+    int q_rec_stride;       // floats between the runs of neighbouring red cells there
+    int q_row_stride;       // floats between (b0, g0) rows there
     int n;               // N
     float top;           // (float)(N-1)
     float dmin[3];
@@ -307,20 +326,11 @@ VRG_HD void lut_fetch_issue(const LutParams& P, const float x[3], LutFetch& F) {
     F.B = lut_axis(x[2], P.dmin[2], P.span[2], P.unit_domain, P.top);
     const int nc = P.n - 1;
     const f32x4* q = reinterpret_cast<const f32x4*>(P.cells + (size_t)((F.B.cell * nc + F.G.cell) * P.n + F.R.cell) * LUT_REC_FLOATS);
-#if defined(VRG_ABLATE_GATHER)      /* timing ablation only (tools/build_variant.py): no table reads, same arithmetic */
-    (void)q;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        F.lo[ch] = f32x4{x[0], x[1], x[2], x[ch]};
-        F.hi[ch] = f32x4{x[2], x[1], x[0], x[ch]};
-    }
-#else
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         F.lo[ch] = q[ch];      // red node r0: (g0,b0) (g0,b1) (g1,b0) (g1,b1)
         F.hi[ch] = q[3 + ch];  // red node r0 + 1
     }
-#endif
 }
 
 VRG_HD void lut_fetch_finish(const LutFetch& F, float y[3]) {
@@ -840,9 +850,7 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 // (v = 1.0 -> q = 0.9999995, 2 % of the lanes of a graded frame) sit there, and without it pass 1 ran the transcription in every
 // wave (VRG_ZIV_REL = 0: 928 instead of 709 instructions per pixel).  (The +-delta additions and ocml's own last roundings are
 // five orders of magnitude smaller.)
-#ifndef VRG_ZIV_REL
 #define VRG_ZIV_REL 1
-#endif
 VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
 #if VRG_ZIV_REL
     const float a = __builtin_fabsf(Lh), b = __builtin_fabsf(Eh);
@@ -921,7 +929,7 @@ VRG_HD float cm_div_scalar(float x, float, float, float rc_dev, const DevMath&) 
 // sequence (~10 instructions plus v_rcp_f32, 13 issue slots) otherwise -- 6 slots instead of 13 for every ordinary pixel.
 VRG_HD float cm_div_tensor(float x, float c, float rc, const PowTables&) { return div_const(x, c, rc); }
 VRG_HD float cm_div_tensor(float x, float c, float rc, const DevMath&) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(VRG_NO_DIVT_FASTPATH)
+#if defined(__HIP_DEVICE_COMPILE__)
     const bool proven = ((__builtin_fabsf(x) - 1e-30f) <= (1e30f - 1e-30f)) | (x == 0.0f);
     if (__builtin_amdgcn_ballot_w64(!proven) == 0) return div_const(x, c, rc);
 #else

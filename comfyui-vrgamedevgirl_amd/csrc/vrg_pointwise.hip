@@ -43,9 +43,7 @@ __global__ __launch_bounds__(256) void k_noise(float* __restrict__ out, NoiseK n
 // neighbours outside the block's range (per sibling range) are produced by the general per-element
 // routine on 8 lanes.
 // ----------------------------------------------------------------------------------------------
-#ifndef VRG_GRAIN_NT
 #define VRG_GRAIN_NT 0
-#endif
 constexpr int GRAIN_IPT = 4;                    // subsequences per thread
 constexpr int GRAIN_N = 256 * GRAIN_IPT;        // subsequences per block
 
@@ -247,9 +245,7 @@ __global__ __launch_bounds__(256) void k_sharpen_grain(const float* __restrict__
         col_out = col;
     };
 
-#ifndef VRG_SG_PIPE
 #define VRG_SG_PIPE 0         /* 1: request run ii + 1's rows before run ii is computed (81 instead of 58 VGPRs); measured equal (6.71 / 6.82 against 6.75 / 6.80 ms per 128 4K frames, profiles/r03_sharpen_grain_fused_issue.log): the kernel does not wait on its loads */
-#endif
     SgRaw qq[2];
     uint32_t vv[2];
     int32_t yy[2], cc[2];
@@ -521,6 +517,21 @@ __global__ __launch_bounds__(256) void k_lut_build_cells(const float* __restrict
     const int r = rec % n, g0 = (rec / n) % nc, b0 = rec / (n * nc);
     float v[LUT_REC_FLOATS];
     lut_build_record(table, n, b0, g0, r, v);
+    if (lut_cell_major(n)) {
+        // the cell-major twin behind the record table: record r is the first half of cell r (r < N - 1) and the second half of cell
+        // r - 1 (r > 0); the 8 floats behind them are zeroed
+        float* row = cells + lut_record_floats(n) + (size_t)(b0 * nc + g0) * nc * LUT_CELL_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const f32x4 q = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            if (r < nc) reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[i] = q;
+            if (r > 0) reinterpret_cast<f32x4*>(row + (size_t)(r - 1) * LUT_CELL_FLOATS)[3 + i] = q;
+        }
+        if (r < nc) {
+            reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[6] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[7] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
     f32x4* dst = reinterpret_cast<f32x4*>(cells + (size_t)rec * LUT_REC_FLOATS);
 #pragma unroll
     for (int i = 0; i < 3; ++i) dst[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
@@ -802,7 +813,8 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
 int64_t vrg_lut_cells_floats(int32_t lut_size) {
     if (lut_size < 2 || lut_size > 256) return 0;
     const int64_t nc = lut_size - 1;
-    return nc * nc * lut_size * LUT_REC_FLOATS;
+    (void)nc;
+    return (int64_t)vrg::lut_table_floats(lut_size);          // the record table + (cubes up to 28^3) its cell-major twin (vrg_pixel_math.hpp)
 }
 
 int vrg_lut_prepare_f32(const float* lut, int32_t lut_size, float* cells, void* stream) {

@@ -111,9 +111,11 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch_r4(const px3* __restrict_
     const float top = (float)(n - 1);
     const LutAxis R = lut_axis(v.r, 0.f, 1.f, 1, top), G = lut_axis(v.g, 0.f, 1.f, 1, top), B = lut_axis(v.b, 0.f, 1.f, 1, top);
     const int nc = n - 1;
-    const int cell = (B.cell * nc + G.cell) * n + R.cell;
+    // MODE 19: mode 12's quad-cooperative LDS-DMA over the CELL-MAJOR table (one 128-byte aligned record per cell: one line per pixel)
+    constexpr int QSTRIDE = MODE == 19 ? 32 : 12;
+    const int cell = MODE == 19 ? (B.cell * nc + G.cell) * nc + R.cell : (B.cell * nc + G.cell) * n + R.cell;
     float acc = 0.0f;
-    if (MODE >= 13) {
+    if (MODE >= 13 && MODE <= 18) {
         // the six 16-byte pieces per lane (mode 0's requests) with cache-policy bits on the loads: 13 none (the inline-assembly baseline),
         // 14 sc0, 15 sc1, 16 nt, 17 sc0 sc1, 18 sc0 sc1 nt -- does any of them make the L1 ask the L2 for less than a whole 128-byte line?
         const float* q = cells + (size_t)cell * 12;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void k_dbg_lut_fetch_r4(const px3* __restrict_
             for (int rnd = 0; rnd < 6; ++rnd) {
                 const int served = dbg_quad_bcast(cell, rnd);
                 const int chunk = rnd < 4 ? ql : 4 + (ql & 1);
-                __builtin_amdgcn_global_load_lds((dbg_gptr)(cells + (size_t)served * 12 + chunk * 4), (dbg_lptr)(my + rnd * DBG_ROUND_BYTES), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((dbg_gptr)(cells + (size_t)served * QSTRIDE + chunk * 4), (dbg_lptr)(my + rnd * DBG_ROUND_BYTES), 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int q4 = lane & ~3;
@@ -470,7 +472,7 @@ int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float 
 }
 
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream) {
-    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 18) return VRG_ERR_BAD_ARG;
+    if (!in || !out || !cells || pixels <= 0 || lut_size < 2 || mode < 0 || mode > 19) return VRG_ERR_BAD_ARG;
     const uint32_t blocks = (uint32_t)((pixels + 255) / 256);
     const vrg::px3* src = reinterpret_cast<const vrg::px3*>(in);
     if (mode >= 9) {
@@ -484,7 +486,8 @@ int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float
             case 15: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<15>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
             case 16: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
             case 17: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<17>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
-            default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<18>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            case 18: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<18>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
+            default: hipLaunchKernelGGL(vrg::k_dbg_lut_fetch_r4<19>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, out, pixels, cells, lut_size); break;
         }
         VRG_CHECK_LAUNCH();
         return VRG_OK;

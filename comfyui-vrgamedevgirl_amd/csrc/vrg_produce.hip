@@ -19,9 +19,7 @@
 
 namespace vrg {
 
-#ifndef VRG_PRODUCE_MAX_WAVES_LABONLY
 #define VRG_PRODUCE_MAX_WAVES_LABONLY 8   /* cap on the workgroups per CU (= waves per SIMD) of the Lab-only form; 8 = none.  Measured with LDS padding, 64 frames: 4 / 5 / 6 per CU = 8.02 / 7.64 / 7.54 ms (profiles/r04_ab_pass1_occupancy.json): the six that 80 VGPRs allow are the fastest */
-#endif
 template <int STAGES, bool TWO_PART, bool STATS = true>
 __global__ __launch_bounds__(256, TWO_PART ? 1 : (STATS ? VRG_PRODUCE_WAVES : VRG_PRODUCE_WAVES_LABONLY)) void k_produce_lab(const float* __restrict__ in, float* __restrict__ lab_out, ProduceK P, ChainK D,
                                                       const float* __restrict__ pivots, double* __restrict__ rec,

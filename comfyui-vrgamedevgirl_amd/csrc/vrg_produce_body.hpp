@@ -6,9 +6,7 @@
 namespace vrg {
 
 constexpr int PR_SUB = 768;      // subsequences per sub-range = 256 pixels per sibling
-#ifndef VRG_PR_SUBS
 #define VRG_PR_SUBS 8
-#endif
 constexpr int PR_SUBS = VRG_PR_SUBS;       // sub-ranges per block
 constexpr int PR_RUN = PR_SUB * PR_SUBS;
 
@@ -35,12 +33,8 @@ __device__ __forceinline__ bool run_crosses_frame(const ProduceK& P, int64_t A) 
     return ((uint32_t)A / (uint32_t)P.fe) != ((uint32_t)last / (uint32_t)P.fe);
 }
 
-#ifndef VRG_PRODUCE_WAVES
 #define VRG_PRODUCE_WAVES 4   /* device-policy kernel: 130 -> 127 VGPRs, 4 waves per SIMD, statistics pass -7 % (A/B) */
-#endif
-#ifndef VRG_PRODUCE_WAVES_LABONLY
 #define VRG_PRODUCE_WAVES_LABONLY 4
-#endif
 // STATS = false: the Lab image only (the statistics are then torch's own reductions over that image, vrg_torch_stats.hip): no
 // accumulators, no records, and a run that crosses a frame boundary needs no second instantiation.
 inline void produce_geometry(const ChainK& D, int64_t frames, int64_t fe, ProduceK& P) {
@@ -127,9 +121,7 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
 #pragma unroll
             for (int c = 0; c < 3; ++c) { s1[m][part][c] = 0.0; s2[m][part][c] = 0.0; }
 
-#ifndef VRG_PR_PIPE
 #define VRG_PR_PIPE 1     /* Lab-only form: 1 = pixels requested before the noise synthesis, 2 = and the LUT gathers pipelined, 3 = two siblings before, two after the barrier */
-#endif
     constexpr bool PIPE = VRG_PR_PIPE && !STATS && (STAGES & VRG_STAGE_GRAIN) && !(STAGES & VRG_STAGE_COLORMATCH);
     constexpr bool HAS_LUT = (STAGES & VRG_STAGE_LUT) != 0;
     for (int sub = 0; sub < PR_SUBS; ++sub) {

@@ -43,9 +43,7 @@ __global__ __launch_bounds__(256) void k_stencil3x3(const float* __restrict__ in
 // two priming rows of a strip segment are re-read from L2.  Same arithmetic as every other stencil kernel of the library
 // (stencil_value), so results are bit-identical.  Needs W*C % 4 == 0 and 16-byte aligned frames; instantiated for C = 3 and 4.
 // ----------------------------------------------------------------------------------------------
-#ifndef VRG_FLAT_ROWS
 #define VRG_FLAT_ROWS 36      /* rows per strip segment: a multiple of 3 (the row registers rotate by name three steps per trip) */
-#endif
 constexpr int FLAT_ROWS = VRG_FLAT_ROWS;
 static_assert(FLAT_ROWS % 3 == 0, "FLAT_ROWS must be a multiple of 3");
 
@@ -218,15 +216,11 @@ extern "C" int vrg_stencil3x3_f32(const float* in, float* out, int64_t frames, i
     // RGB / RGBA frames with whole float4 vectors per row and 16-byte aligned bases: the streaming flat march
     const bool flat_ok = (channels == 3 || channels == 4) && ((int64_t)width * channels) % 4 == 0 && (int64_t)width * channels / 4 <= 0x7fffffff / 64 &&
                          ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-#ifndef VRG_NO_FLAT_STENCIL
     if (flat_ok) {
         hipStream_t st = (hipStream_t)stream;
         if (channels == 3) return launch_stencil_flat<3>(in, out, frames, height, width, op, border, strength, st);
         return launch_stencil_flat<4>(in, out, frames, height, width, op, border, strength, st);
     }
-#else
-    (void)flat_ok;
-#endif
     if (channels == 3 && (int64_t)height * width <= 0x7fffffff / 3) {
         // RGB frames: the LDS-tiled kernel of the fused chain with only the stencil stage enabled
         // (each input byte leaves HBM once and is re-read from LDS, not from L1/L2)

@@ -194,15 +194,9 @@ struct TsLaneRec { float mean, m2; int cnt; int pad; };
 struct TsLanes { TsLaneRec w[3][2][512]; float m[3][512]; };
 constexpr int TS_LANES_MAX_STEPS = 16384;            // table entries (LDS: 8 bytes each) -- frames up to 16.7 M pixels
 
-#ifndef VRG_TS_LANES_DEPTH
 #define VRG_TS_LANES_DEPTH 8      /* Welford steps (one 4-byte load per lane each) requested ahead.  8 = a 12 KB window shared by the six Welford waves in the CU's 32 KB L1; 16 / 32 / 48 measured SLOWER (0.95 / 0.91 / 2.3 ms per 4K frame against 0.76-0.79: the window falls out of the L1, then out of the registers) -- profiles/r04_bench_stats_lanes_depths.json */
-#endif
-#ifndef VRG_TS_LANES_MEAN_DEPTH
 #define VRG_TS_LANES_MEAN_DEPTH 12   /* mean rounds (48 bytes per lane each) requested ahead (16: more than 256 registers, 2.1 ms) */
-#endif
-#ifndef VRG_TS_LANES_MAX_FRAMES
 #define VRG_TS_LANES_MAX_FRAMES 2    /* one 4K frame 0.78 ms against the half-block form's 1.12 (-30 %); 4-16 frames: equal; 32: the half-block form wins (1.25 against 1.6) */
-#endif
 
 template <bool FUSED, bool FAST, int DEPTH>
 static __device__ __forceinline__ bool ts_lane_chain(const float* __restrict__ ub, uint32_t lane_bytes, int steps, bool extra, const float2* __restrict__ tab,
@@ -407,24 +401,14 @@ static int ts_launch_planes(const float* lab_call, int64_t n, int64_t o0, int64_
     return VRG_OK;
 }
 
-#ifndef VRG_TS_SPLIT_MAX_FRAMES
 #define VRG_TS_SPLIT_MAX_FRAMES 64
-#endif
 constexpr int64_t TS_SPLIT_MAX_FRAMES = VRG_TS_SPLIT_MAX_FRAMES;
 
 // `count` reference calls of `b` frames each, starting at `lab` / `out`
-#ifndef VRG_TS_ROWS_DEPTH       /* rounds of loads in flight per thread: half-block form / four-workgroup form / whole-frame form */
-#define VRG_TS_ROWS_DEPTH 4
-#endif
-#ifndef VRG_TS_SPLIT_DEPTH
+#define VRG_TS_ROWS_DEPTH 4   /* rounds of loads in flight per thread: half-block form / four-workgroup form / whole-frame form */
 #define VRG_TS_SPLIT_DEPTH 2
-#endif
-#ifndef VRG_TS_WHOLE_DEPTH
 #define VRG_TS_WHOLE_DEPTH 1
-#endif
-#ifndef VRG_TS_ROWS_MAX_FRAMES
 #define VRG_TS_ROWS_MAX_FRAMES 32
-#endif
 constexpr int64_t TS_ROWS_MAX_FRAMES = VRG_TS_ROWS_MAX_FRAMES;
 
 static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, float eps, float* out, int num_mp, void* scratch, int64_t scratch_bytes,
@@ -452,9 +436,7 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
         // for the four-workgroup form (64 frames 1.85 ms against 1.98; four: 2.75), the plain one-round loop for the HBM-bound whole-frame
         // form (256 frames 4.4 ms; branch-free 5.5, two / four rounds 6.3 / 6.7): profiles/r03_stats_prefetch_depth_ab.log.
         // up to 32 frames (and a caller-supplied scratch buffer): eight half-block workgroups per frame, one wave per SIMD
-#ifndef VRG_TS_LANES
 #define VRG_TS_LANES 1
-#endif
         if (VRG_TS_LANES && prefer_lanes && frames <= VRG_TS_LANES_MAX_FRAMES && scratch && scratch_bytes >= frames * (int64_t)sizeof(TsLanes) && cm.bh == cw.bh &&
             n / 1024 + 2 <= TS_LANES_MAX_STEPS && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0) {
             // one accumulator per lane: eight 7-wave workgroups per frame + torch's block as the finishing kernel

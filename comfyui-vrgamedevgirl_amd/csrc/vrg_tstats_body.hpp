@@ -272,9 +272,7 @@ static __device__ __forceinline__ bool ts_accumulate(const float* __restrict__ b
     return bad;
 }
 
-#ifndef VRG_TS_MARKSTEIN
 #define VRG_TS_MARKSTEIN 1
-#endif
 // Counts up to which q' == delta / n is established by enumeration (vrg_selftest_welford_division over every count x every fp32
 // significand: tests/test_gpu_parity.py sweeps a sample of counts, tools/welford_division_sweep.py all of them -- profiles/).
 constexpr int64_t TS_MARKSTEIN_MAX_COUNT = 1 << 20;

@@ -366,7 +366,7 @@ def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensi
 
 @dataclass
 class DeviceLut:
-    table: torch.Tensor        # record table on the device: (N-1)^2 * N records of 12 fp32 (vrg_lut_prepare_f32)
+    table: torch.Tensor        # the table as vrg_lut_prepare_f32 lays it out (record form, or cell-major for cubes up to 28^3): opaque to Python
     size: int                  # N
     domain_min: tuple
     domain_max: tuple

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 6
+#define VRG_ABI_VERSION 7
 
 enum vrg_status {
     VRG_OK = 0,
@@ -116,7 +116,10 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
  * [N][N][N][3] indexed [blue][green][red], as _parse_cube_file returns it) into the gather-friendly
  * form the kernels read -- (N-1)^2*N records of 12 floats, one per (b0, g0, red node), the four (g,b)
  * corner values of each channel copied verbatim -- so that a pixel fetches one contiguous 96-byte
- * run (red nodes r0, r0+1) instead of eight scattered corners.  `cells` must hold vrg_lut_cells_floats(N) floats, 16-byte aligned.  2 <= N <= 256.
+ * run (red nodes r0, r0+1) instead of eight scattered corners.  Behind that table, cubes of at most 28^3 get a cell-major twin --
+ * one 128-byte record per (b0, g0, r0) cell = the same two records side by side + padding, one cache line per pixel -- which the
+ * quad-cooperative fetch of the fused march reads (the table is opaque to the caller: the library derives the layout from N).
+ * `cells` must hold vrg_lut_cells_floats(N) floats, 128-byte aligned (16 suffices for cubes above 28^3).  2 <= N <= 256.
  * `channels` >= 3; channels beyond RGB are copied through.  blend_mode: 1 = LUT only (blend>=1),
  * 2 = fl(fl(x*one_minus_blend) + fl(y*blend)).  (blend <= 0 is the caller's no-op.)
  * ------------------------------------------------------------------------------------------- */

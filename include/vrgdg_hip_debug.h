@@ -50,7 +50,7 @@ int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32
  * mode 0: 6 x 16 B per lane; 1: 3 x 16 B; 2: quad-cooperative 64-B fetches; 3: 64-B records; 4: cell-major 128-B aligned records;
  * 5 / 6: channel split -- one / two channels of the node table in LDS (8 ds_read per pixel), the rest gathered (4 / 2 x 16 B);
  * 9-12: one piece / pieces 0 and 5 / the six pieces by LDS-DMA / quad-cooperative LDS-DMA; 13-18: mode 0's requests with cache-policy
- * bits on the loads (none, sc0, sc1, nt, sc0 sc1, sc0 sc1 nt). */
+ * bits on the loads (none, sc0, sc1, nt, sc0 sc1, sc0 sc1 nt); 19: mode 12 over the cell-major table of mode 4. */
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
 /* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
  * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,

@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header(hip):
 
 def test_versions_and_error_strings(hip):
     lib = hip.load_library()
-    assert lib.vrg_abi_version() == 6
+    assert lib.vrg_abi_version() == 7 == hip.ABI_VERSION
     assert lib.vrg_error_string(0) == b"ok"
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8

@@ -309,3 +309,25 @@ def test_device_copy_cache_under_inference_mode_and_alias_writes(pkg, monkeypatc
     c.remember(w, cpu, [(0, 2, torch.empty(4), None)])
     assert c.errors >= 1 and c.lookup(w, cpu) is None
     assert D.release_device_copies() >= 0
+
+
+def test_product_sources_have_no_command_line_switches(pkg):
+    """the A/B and ablation switches (among them VRG_MARCH_ABLATE: wrong pixels) are not build options of the
+    product sources -- no `#ifndef VRG_*` knob is left in the kernels, and a -D of one of the old names stops the build."""
+    import glob
+    import shutil
+    import subprocess
+    from conftest import PKG_DIR, ROOT
+    csrc = os.path.join(PKG_DIR, "csrc")
+    knobs = 0
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")):
+        with open(path) as fh:
+            knobs += sum(1 for line in fh if line.startswith("#ifndef VRG_") and "VRG_HW_LOG2" not in line)
+    assert knobs == 0
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    for macro in ("VRG_MARCH_ABLATE=1", "VRG_APPLY_FORCE_GENERAL", "VRG_TILE_H=16"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-D" + macro, "-fsyntax-only",
+                            os.path.join(csrc, "vrg_api.hip")], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "not build options of the product sources" in r.stderr, macro

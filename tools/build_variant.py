@@ -40,6 +40,8 @@ def one(src):
         path = tmp
     try:
         flags = list(be.EXTRA_FLAGS.get(src, ())) if (unit_flags or src != unit) else []
+        if tmp:
+            flags.append("-DVRG_LAB_VARIANT_SOURCE")        # a file that is not product source: vrg_common.hpp lets its -D switches through
         subprocess.run([be._hipcc(), *cflags, *flags, *extra, "-I", be.INCLUDE, "-x", "hip", "-c", path, "-o", obj], check=True)
     finally:
         if tmp:

@@ -293,25 +293,28 @@ def kernel_bench(ops, frames_4k, iters, match=""):
             from comfyui_vrgamedevgirl_amd import _hip
             probe = torch.empty((px,), dtype=torch.float32, device=dev)
             wide = torch.zeros(((lut33.size - 1) ** 2 * lut33.size * 16 + 16,), dtype=torch.float32, device=dev)   # 64-B records for mode 3
-            wide[:-16].view(-1, 16)[:, :12] = lut33.table.view(-1, 12)
             nc = lut33.size - 1
-            recs = lut33.table.view(nc * nc, lut33.size, 12)
+            raw33 = lut33.nodes
+            recs = torch.stack([raw33[db:db + nc, dg:dg + nc, :, ch] for ch in range(3) for dg in (0, 1) for db in (0, 1)], dim=-1).reshape(nc * nc, lut33.size, 12).contiguous()
+            rec_table = recs.reshape(-1).contiguous()
+            wide[:-16].view(-1, 16)[:, :12] = recs.view(-1, 12)
+            nc = lut33.size - 1
             cellmajor = torch.zeros((nc * nc, nc, 32), dtype=torch.float32, device=dev)     # 128-B aligned record per cell (mode 4)
             cellmajor[:, :, :12] = recs[:, :-1]
             cellmajor[:, :, 12:24] = recs[:, 1:]
             cellmajor = cellmajor.reshape(-1).contiguous()
             for src_name, src in (("uniform", x), ("smooth", smooth)):
-                for mode, tab in ((0, lut33.table), (1, lut33.table), (2, lut33.table), (3, wide), (4, cellmajor)):
+                for mode, tab in ((0, rec_table), (1, rec_table), (2, rec_table), (3, wide), (4, cellmajor)):
                     cases.append((f"probe lut fetch mode {mode} {src_name}", 16, (lambda m=mode, t=tab, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
                         _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), lut33.size, m, _hip.current_stream()), "probe"))))
                 # channel split: one (33^3, 32^3) / two (25^3) channels of the node table in LDS, the rest gathered
                 for nsz in (25, 28, 30, 32):      # cell-major 128-byte records (mode 4) against the 48-byte record runs (mode 0), by cube size
-                    for mode, tab in ((0, lut33.table), (4, cellmajor)):
+                    for mode, tab in ((0, rec_table), (4, cellmajor)):
                         cases.append((f"probe lut cellmajor-vs-records n={nsz} mode {mode} {src_name}", 16, (lambda m=mode, n_=nsz, t=tab, s_=src: _hip.check(
                             _hip.lib().vrg_debug_lut_fetch(_hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(t), n_, m, _hip.current_stream()), "probe"))))
                 for nsz, mode in ((33, 5), (32, 5), (25, 6), (25, 5), (25, 0), (17, 6), (33, 7), (33, 8), (25, 7), (25, 8), (17, 7)):
                     cases.append((f"probe lut split n={nsz} mode {mode} {src_name}", 16, (lambda m=mode, n_=nsz, s_=src: _hip.check(_hip.lib().vrg_debug_lut_fetch(
-                        _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(lut33.table), n_, m, _hip.current_stream()), "probe"))))
+                        _hip.ptr(s_), _hip.ptr(probe), px, _hip.ptr(rec_table), n_, m, _hip.current_stream()), "probe"))))
         for name, bpp, fn in cases:
             if match and match not in name:
                 continue
