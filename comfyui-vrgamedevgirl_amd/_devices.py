@@ -105,7 +105,7 @@ class _Staging:
     guarded by a lock because nodes and routes may enter from different host threads."""
 
     def __init__(self):
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()          # re-entrant: a LazyFrames touched inside a streaming call downloads on the same thread
         self.buffers = {}      # (direction, slot) -> pinned uint8 tensor
         self.streams = {}      # device index -> (h2d, d2h)
 
@@ -307,6 +307,194 @@ def release_device_copies() -> int:
     return n
 
 
+# ------------------------------------------------------------------------------------------------------------
+# Lazy download.  With the device copy kept (above) the upload of the next node is gone; its own DOWNLOAD is not: grain -> LUT ->
+# colour match -> unsharp still crosses PCIe four times for results nobody reads on the host.  So a node's result is handed to ComfyUI
+# as `LazyFrames`: a CPU torch.Tensor (subclass) over page-locked storage whose download has NOT been queued yet.
+#   * The next node of this pack takes the frames from HBM (the pending pieces) and never touches the host buffer.
+#   * ANY other use -- a torch function or Tensor method that can see data (`.numpy()`, `.cpu()`, `.to()`, indexing, iteration, `torch.cat`,
+#     `data_ptr()`, `untyped_storage()`, pickling, `__array__`, DLPack, printing) -- goes through `__torch_function__`, which first
+#     downloads the frames (asynchronous copies on the download stream, then one wait) and then runs the call on the plain tensor.
+#     Shape / dtype / device / stride / numel questions do not download.
+#   * A result nobody has touched for VRGDG_LAZY_SECONDS (default 2) is downloaded by a timer; so is the oldest one when the pending
+#     results outgrow the device-copy budget.  After its download a result is an ordinary entry of the device-copy cache above.
+#   * What this cannot see: native code that reads a tensor's memory WITHOUT going through a torch API (a pybind11 extension taking
+#     at::Tensor directly).  ComfyUI core and the usual image nodes (PreviewImage / SaveImage / VAEEncode: `.cpu().numpy()`, `.to(device)`,
+#     iteration) all do go through it.  VRGDG_LAZY_DOWNLOAD=0 restores the eager download for a graph that holds such a node.
+# The reference's contract (CPU tensors in, CPU tensors out: nodes.py:50, 61-66) is kept: the object IS a CPU tensor with the result's
+# bits -- they are fetched when first asked for.  Four node calls in a graph: 1 upload + 1 download instead of 1 + 4.
+# ------------------------------------------------------------------------------------------------------------
+LAZY_DOWNLOAD = os.environ.get("VRGDG_LAZY_DOWNLOAD", "1") != "0"
+LAZY_SECONDS = float(os.environ.get("VRGDG_LAZY_SECONDS", "2"))
+
+
+class _Pending:
+    """The device pieces of a result whose host copy has not been made yet."""
+
+    def __init__(self, host: torch.Tensor, device: torch.device, pieces, nbytes: int):
+        self.host, self.device, self.pieces, self.nbytes = host, device, pieces, nbytes
+        self.lock = threading.Lock()
+        self.done = False
+        self.born = time.monotonic()
+        self.owner = None            # weak reference to the LazyFrames handed out
+
+    def materialise(self):
+        with self.lock:
+            if self.done:
+                return
+            with torch.cuda.device(self.device):
+                with _STAGING.lock:
+                    _h2d, d2h, _own = _STAGING.side_streams(self.device, 0)
+                ev = None
+                with torch.cuda.stream(d2h):
+                    for s, e, gpu, ran in self.pieces:
+                        d2h.wait_event(ran)
+                        self.host[s:e].copy_(gpu, non_blocking=True)
+                        gpu.record_stream(d2h)
+                    ev = torch.cuda.Event()
+                    ev.record(d2h)
+                ev.synchronize()
+            self.done = True
+        _LAZY.forget(self)
+        owner = self.owner() if self.owner is not None else None
+        if owner is not None:
+            _DEVICE_COPIES.remember(owner, self.device, self.pieces)       # from here on: an ordinary, validated device copy
+
+
+class _LazyRegistry:
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.pending = []            # oldest first
+        self._timer = None
+        self.downloads_skipped = 0   # results consumed on the device and never downloaded (statistics for tests / tools)
+
+    def add(self, p: "_Pending", budget: int):
+        over = []
+        with self.lock:
+            self.pending.append(p)
+            total = sum(q.nbytes for q in self.pending)
+            while len(self.pending) > 1 and total > budget:
+                q = self.pending.pop(0)
+                total -= q.nbytes
+                over.append(q)
+            self._arm()
+        for q in over:                # outside the registry lock: a download waits on the device
+            q.materialise()
+
+    def forget(self, p):
+        with self.lock:
+            if p in self.pending:
+                self.pending.remove(p)
+
+    def _arm(self):
+        if LAZY_SECONDS <= 0 or self._timer is not None or not self.pending:
+            return
+        t = threading.Timer(LAZY_SECONDS, self._sweep)
+        t.daemon = True
+        self._timer = t
+        t.start()
+
+    def _sweep(self):
+        with self.lock:
+            self._timer = None
+            now = time.monotonic()
+            due = [p for p in self.pending if now - p.born >= LAZY_SECONDS and (p.owner is None or p.owner() is not None)]
+            self.pending = [p for p in self.pending if p not in due and (p.owner is None or p.owner() is not None)]
+        for p in due:
+            try:
+                p.materialise()
+            except Exception:
+                pass
+        with self.lock:
+            self._arm()
+
+
+_LAZY = _LazyRegistry()
+
+_NO_DOWNLOAD = None
+
+
+def _metadata_only():
+    """Tensor attributes / methods that say nothing about the data: asking them does not download a LazyFrames."""
+    global _NO_DOWNLOAD
+    if _NO_DOWNLOAD is None:
+        T = torch.Tensor
+        fns = set()
+        for name in ("shape", "dtype", "device", "ndim", "is_cuda", "is_cpu", "requires_grad", "layout", "is_sparse", "is_quantized", "is_meta",
+                     "names", "grad", "grad_fn", "is_leaf", "_version", "itemsize", "nbytes", "is_nested", "is_mkldnn", "is_xpu", "is_mps"):
+            prop = getattr(T, name, None)
+            if prop is not None and hasattr(prop, "__get__"):
+                fns.add(prop.__get__)
+        for name in ("size", "dim", "ndimension", "numel", "nelement", "element_size", "is_contiguous", "stride", "storage_offset", "is_pinned",
+                     "is_inference", "is_floating_point", "is_complex", "is_signed", "__len__", "get_device", "is_shared", "type", "has_names",
+                     "is_same_size", "is_set_to", "__hash__", "is_coalesced", "is_neg", "is_conj"):
+            fn = getattr(T, name, None)
+            if fn is not None:
+                fns.add(fn)
+        _NO_DOWNLOAD = fns
+    return _NO_DOWNLOAD
+
+
+class LazyFrames(torch.Tensor):
+    """A node result on the host whose download happens at first use (see the note above)."""
+
+    @staticmethod
+    def __new__(cls, host: torch.Tensor, pending: "_Pending"):
+        t = torch.Tensor._make_subclass(cls, host, False)
+        t._vrg_pending = pending
+        return t
+
+    def _vrg_wait(self):
+        p = getattr(self, "_vrg_pending", None)
+        if p is not None:
+            p.materialise()
+            self._vrg_pending = None
+
+    def _vrg_plain(self) -> torch.Tensor:
+        """The same storage as a plain torch.Tensor (after the download)."""
+        self._vrg_wait()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    def __deepcopy__(self, memo):
+        return self._vrg_plain().clone()
+
+    def __reduce_ex__(self, proto):
+        return self._vrg_plain().__reduce_ex__(proto)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func not in _metadata_only() or (func is torch.Tensor.type and (len(args) > 1 or kwargs)):
+            stack = [args, kwargs]
+            while stack:
+                a = stack.pop()
+                if isinstance(a, LazyFrames):
+                    a._vrg_wait()
+                elif isinstance(a, (list, tuple)):
+                    stack.extend(a)
+                elif isinstance(a, dict):
+                    stack.extend(a.values())
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def pending_of(t):
+    """The not-yet-downloaded device pieces behind `t` (a LazyFrames nobody has read on the host), else None."""
+    if isinstance(t, LazyFrames):
+        p = getattr(t, "_vrg_pending", None)
+        if p is not None and not p.done:
+            return p
+    return None
+
+
+def materialise(t):
+    """Download `t` now if it is a pending LazyFrames (what any host-side use does implicitly); returns `t`."""
+    if isinstance(t, LazyFrames):
+        t._vrg_wait()
+    return t
+
+
 def _device_frames(pieces, s: int, e: int, compute):
     """Frames [s, e) out of cached device pieces [(ps, pe, gpu, ran_event)] on stream `compute`: a view when one piece holds them,
     one device-side concatenation otherwise."""
@@ -415,25 +603,38 @@ def _event():
 
 
 def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
-    images = images.contiguous()
+    pend_in = pending_of(images) if len(devices) == 1 else None      # a result of a previous node that is still on the GPU only
+    if pend_in is not None and (pend_in.device != devices[0] or not images.is_contiguous()):
+        pend_in = None
+    if pend_in is None:
+        images = materialise(images).contiguous()
     F = int(images.shape[0])
     out_dtype = out_dtype or images.dtype
-    if F == 0 or images[0].numel() == 0:
-        return torch.empty(images.shape, dtype=out_dtype)
-    out_fb = images[0].numel() * torch.empty((), dtype=out_dtype).element_size()
-    in_fb = images[0].numel() * images.element_size()
+    frame_numel = 1
+    for d in images.shape[1:]:
+        frame_numel *= int(d)
+    if F == 0 or frame_numel == 0:
+        return torch.empty(tuple(images.shape), dtype=out_dtype)
+    out_fb = frame_numel * torch.empty((), dtype=out_dtype).element_size()
+    in_fb = frame_numel * images.element_size()
     pin_out = F * out_fb <= PIN_LIMIT_BYTES
     try:
-        out = torch.empty(images.shape, dtype=out_dtype, pin_memory=pin_out)
+        out = torch.empty(tuple(images.shape), dtype=out_dtype, pin_memory=pin_out)
     except RuntimeError:                      # the host refused to page-lock that much: pageable result + ring
         if not pin_out:
             raise
         pin_out = False
-        out = torch.empty(images.shape, dtype=out_dtype)
+        out = torch.empty(tuple(images.shape), dtype=out_dtype)
     per = piece_frames(F, max(in_fb, out_fb), multiple_of)
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
     n_lanes = min(len(devices), len(pieces))
-    cached = _DEVICE_COPIES.lookup(images, devices[0]) if n_lanes == 1 else None      # an unchanged result of a previous node: already in HBM
+    if pend_in is not None:
+        cached = pend_in.pieces                # never downloaded, so nobody can have changed it: the frames are read where they are
+        _LAZY.downloads_skipped += 1
+    else:
+        cached = _DEVICE_COPIES.lookup(images, devices[0]) if n_lanes == 1 else None      # an unchanged result of a previous node: already in HBM
+    # the result stays on the GPU until somebody asks for it on the host (LazyFrames): one lane, page-locked result, inside the budget
+    lazy_out = (LAZY_DOWNLOAD and n_lanes == 1 and pin_out and DEVICE_CACHE_BYTES > 0 and F * out_fb <= _DEVICE_COPIES._budget(devices[0]))
     if _DEVICE_COPIES.held_bytes():
         # device copies kept for adjacent nodes never stand in the way of a call's own pipeline (pieces in flight: input + output +
         # the kernels' workspaces): short of memory, they go first
@@ -457,6 +658,8 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
         depth = min(PIPE_DEPTH * n_lanes, len(pieces))
         ring = None if pin_out else [_STAGING.pinned(("out", k), per * out_fb) for k in range(depth)]
         stage_in = cached is None and PAGEABLE_UPLOAD == "ring" and images.device.type == "cpu" and not images.is_pinned()
+        if lazy_out:
+            depth = len(pieces)                 # nothing retires: every piece's result stays in HBM
         in_rings = [_UploadRing(_STAGING, li) for li in range(n_lanes)] if stage_in else None
         pending = []                    # (slot, s, e, d2h_done_event, keep_alive)
         caller = torch.cuda.current_stream(lanes[0][0])
@@ -503,11 +706,14 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                     if up is not None:
                         compute.wait_event(up)
                     gpu_out = fn(gpu_in, s)                             # kernels on this lane's compute stream
-                    if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != tuple(images[s:e].shape) or not gpu_out.is_contiguous():
+                    if gpu_out.dtype != out_dtype or tuple(gpu_out.shape) != (e - s,) + tuple(images.shape[1:]) or not gpu_out.is_contiguous():
                         gpu_out = gpu_out.to(out_dtype).contiguous()
                     gpu_in.record_stream(compute)
                     ran = _event()
                     ran.record(compute)
+                if lazy_out:
+                    produced.append((s, e, gpu_out, ran))
+                    continue
                 dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
                 with torch.cuda.stream(d2h):
                     d2h.wait_event(ran)
@@ -526,6 +732,14 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
             for r in in_rings:
                 r.drain()
         # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
+    if lazy_out:
+        import weakref
+        p = _Pending(out, devices[0], produced, F * out_fb)
+        res = LazyFrames(out, p)
+        # a result dropped unread takes its device pieces with it at once (the registry's reference is the only other one)
+        p.owner = weakref.ref(res, lambda _r, pr=weakref.ref(p): _LAZY.forget(pr()) if pr() is not None else None)
+        _LAZY.add(p, _DEVICE_COPIES._budget(devices[0]))
+        return res
     if n_lanes == 1 and produced:
         _DEVICE_COPIES.remember(out, devices[0], produced)       # the next node of this pack may be handed `out`: its frames are still in HBM
     return out

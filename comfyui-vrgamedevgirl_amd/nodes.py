@@ -20,8 +20,16 @@ def _float_widget(default, lo, hi, step):
     return ("FLOAT", {"default": default, "min": lo, "max": hi, "step": step})
 
 
+def _frame_numel(images: torch.Tensor) -> int:
+    """Elements of one frame, from the shape alone (indexing a result of a previous node of this pack would download it: _devices.LazyFrames)."""
+    n = 1
+    for d in images.shape[1:]:
+        n *= int(d)
+    return n
+
+
 def _frames_bytes(images: torch.Tensor) -> int:
-    return int(images[0].numel()) * 4 if images.shape[0] else 0
+    return _frame_numel(images) * 4 if images.shape[0] else 0
 
 
 #: False selects the plain sequential upload / run / download per group (kept for A/B measurements)
@@ -82,7 +90,7 @@ class FastFilmGrain:
                 return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step, plans=plans)
             return run_d
 
-        many = images.ndim == 4 and images.shape[0] > 0 and not ops.oversize_chunks(int(images.shape[0]), int(images[0].numel()), step)
+        many = images.ndim == 4 and images.shape[0] > 0 and not ops.oversize_chunks(int(images.shape[0]), _frame_numel(images), step)
         return (_run_grouped(images, run, multiple_of=step, fn_for_device=run_on if many else None),)
 
 

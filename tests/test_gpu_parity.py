@@ -1504,13 +1504,14 @@ def test_pageable_frames_through_the_page_locked_ring_equal_the_runtime_copy(pkg
     _devices._STAGING.buffers.clear()
 
 
-def test_adjacent_nodes_skip_the_reupload_and_a_mutated_intermediate_is_uploaded_again(pkg, ops, dev):
+def test_adjacent_nodes_skip_the_reupload_and_a_mutated_intermediate_is_uploaded_again(pkg, ops, dev, monkeypatch):
     """Two nodes of this pack one after the other in a graph: ComfyUI hands the second the very tensor the first returned, whose frames
     are still in HBM -- the second node reads them there instead of uploading them again (_devices._DEVICE_COPIES).  Same bits as the
     plain path, same generator state; an intermediate changed in place (torch's version counter) is uploaded like any other tensor; the
     device copy dies with the CPU tensor."""
     import gc
     from comfyui_vrgamedevgirl_amd import nodes, _devices
+    monkeypatch.setattr(_devices, "LAZY_DOWNLOAD", False)          # eager downloads: the cache of device copies on its own (lazy: the test below)
     cache = _devices._DEVICE_COPIES
     cache.clear()
     x = _rand((6, 90, 160, 3), 77)
@@ -1567,40 +1568,128 @@ def test_toolchain_selfcheck_passes_on_this_build_and_a_failed_march_falls_back(
     assert torch.equal(got, want)
 
 
-def test_nodes_under_inference_mode_as_comfyui_runs_them(pkg, ops, dev):
+@pytest.mark.parametrize("lazy", [True, False])
+def test_nodes_under_inference_mode_as_comfyui_runs_them(pkg, ops, dev, monkeypatch, lazy):
     """ComfyUI executes every node inside torch.inference_mode() (and the reference's _apply_effects_batch does the same): host-fed node
-    calls, the device-copy cache between adjacent nodes included, give the bits of the plain path there (reading
-    `_version` of an inference tensor raised after every kernel had run)."""
+    calls, the hand-over of device frames between adjacent nodes included (lazy download / device-copy cache), give the bits of the plain
+    path there (reading `_version` of an inference tensor raised after every kernel had run)."""
     from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+    monkeypatch.setattr(_devices, "LAZY_DOWNLOAD", lazy)
     cache = _devices._DEVICE_COPIES
     cache.clear()
     x = _rand((6, 90, 160, 3), 78)
     torch.manual_seed(321)
-    want_a = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0]
-    want_b = nodes.FastUnsharpSharpen().apply_unsharp(want_a.clone(), 0.7, False)[0]
-    want_c = nodes.ColorMatchToReference().match_color(want_b.clone(), x[:1], 0.8, 2)[0]
+    want_a = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0].clone()
+    want_b = nodes.FastUnsharpSharpen().apply_unsharp(want_a.clone(), 0.7, False)[0].clone()
+    want_c = nodes.ColorMatchToReference().match_color(want_b.clone(), x[:1], 0.8, 2)[0].clone()
     cache.clear()
     e0 = cache.errors
+    handed_over = lambda: cache.hits + _devices._LAZY.downloads_skipped
     with torch.inference_mode():
         xi = x.clone()
         torch.manual_seed(321)
         a = nodes.FastFilmGrain().apply_grain(xi, 0.05, 0.4, 2)[0]
-        assert a.is_inference() and id(a) in cache.entries
-        h0 = cache.hits
+        assert a.is_inference() and a.device.type == "cpu" and tuple(a.shape) == tuple(x.shape)
+        assert (_devices.pending_of(a) is not None) if lazy else (id(a) in cache.entries)
+        h0 = handed_over()
         b = nodes.FastUnsharpSharpen().apply_unsharp(a, 0.7, False)[0]
-        assert cache.hits == h0 + 1
+        assert handed_over() == h0 + 1
         c = nodes.ColorMatchToReference().match_color(b, xi[:1], 0.8, 2)[0]
-        assert cache.hits == h0 + 2
+        assert handed_over() == h0 + 2
         lut_names = [n for n in iv.VRGDG_LUTS.INPUT_TYPES()["required"]["lut_name"][0] if n.endswith(".cube")]
         d = iv.VRGDG_LUTS().apply_lut(c, lut_names[0], "auto", 7.5)[0]
         assert tuple(d.shape) == tuple(x.shape)
+        if lazy:
+            assert _devices.pending_of(a) is not None and _devices.pending_of(b) is not None      # consumed on the device: never downloaded
         a.numpy()[:] = 0.5                                                      # whole-tensor write through an alias: the copy is stale
-        h1 = cache.hits
+        h1 = handed_over()
         z = nodes.FastUnsharpSharpen().apply_unsharp(a, 0.7, False)[0]
-        assert cache.hits == h1
+        assert handed_over() == h1
+        assert torch.equal(torch.full_like(z, 0.5), z)                          # unsharp of a constant frame is the frame
+        assert torch.equal(b, want_b) and torch.equal(c, want_c)                # (reading them downloads them)
     assert cache.errors == e0
-    assert torch.equal(a.new_tensor(0.5).expand_as(z), z)                       # unsharp of a constant frame is the frame
-    assert torch.equal(b, want_b) and torch.equal(c, want_c)
+    cache.clear()
+
+
+def test_lazy_download_four_nodes_in_a_graph_cross_pcie_twice(pkg, ops, dev, monkeypatch):
+    """grain -> LUT -> colour match -> unsharp as ComfyUI runs them: every node hands the next a CPU tensor.  With the lazy download
+    (_devices.LazyFrames) the three intermediates stay in HBM -- 1 upload + 1 download instead of 1 + 4 -- and every result still has the
+    eager path's bits whenever and however it is read: torch ops, numpy, iteration, slicing, pickling; shape questions do not download;
+    a result nobody reads is downloaded by the timer and becomes an ordinary cached device copy; dropping a never-read result frees it."""
+    import gc
+    import pickle
+    import time
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+    cache = _devices._DEVICE_COPIES
+    x = _rand((6, 72, 128, 3), 79)
+    ref = _rand((1, 30, 40, 3), 80)
+    lut_name = "AMD_WarmFilm_25.cube"
+
+    def graph(t):
+        r = [nodes.FastFilmGrain().apply_grain(t, 0.05, 0.4, 2)[0]]
+        r.append(iv.VRGDG_LUTS().apply_lut(r[-1], lut_name, "auto", 8.0)[0])
+        r.append(nodes.ColorMatchToReference().match_color(r[-1], ref, 0.9, 3)[0])
+        r.append(nodes.FastUnsharpSharpen().apply_unsharp(r[-1], 0.6, False)[0])
+        return r
+
+    monkeypatch.setattr(_devices, "LAZY_DOWNLOAD", False)
+    cache.clear()
+    torch.manual_seed(11)
+    want = [w.clone() for w in graph(x)]
+    state = torch.cuda.get_rng_state(dev)
+    monkeypatch.setattr(_devices, "LAZY_DOWNLOAD", True)
+    monkeypatch.setattr(_devices, "LAZY_SECONDS", 30.0)
+    cache.clear()
+    skipped0 = _devices._LAZY.downloads_skipped
+    torch.manual_seed(11)
+    got = graph(x)
+    assert torch.equal(torch.cuda.get_rng_state(dev), state)
+    assert _devices._LAZY.downloads_skipped == skipped0 + 3
+    for g in got:
+        assert isinstance(g, torch.Tensor) and g.device.type == "cpu" and g.dtype == torch.float32 and tuple(g.shape) == tuple(x.shape)
+        assert g.is_contiguous() and g.numel() == x.numel() and len(g) == 6 and g.stride() == x.stride()
+        assert _devices.pending_of(g) is not None                            # none of that downloaded anything
+    # every way of reading a result downloads it first
+    assert torch.equal(got[3], want[3]) and _devices.pending_of(got[3]) is None
+    assert np.array_equal(got[2].numpy(), want[2].numpy()) and _devices.pending_of(got[2]) is None
+    assert all(torch.equal(f, w) for f, w in zip(got[1], want[1])) and _devices.pending_of(got[1]) is None      # iteration (PreviewImage / SaveImage)
+    assert torch.equal(pickle.loads(pickle.dumps(got[0])), want[0]) and _devices.pending_of(got[0]) is None
+    # a downloaded result is an ordinary device copy: the next node still skips its upload, and an in-place change is seen
+    h = cache.hits
+    again = nodes.FastUnsharpSharpen().apply_unsharp(got[2], 0.6, False)[0]
+    assert cache.hits == h + 1 and torch.equal(again, want[3])
+    got[2].mul_(0.5)
+    h = cache.hits
+    changed = nodes.FastUnsharpSharpen().apply_unsharp(got[2], 0.6, False)[0]
+    assert cache.hits == h and torch.equal(changed, nodes.FastUnsharpSharpen().apply_unsharp(want[2] * 0.5, 0.6, False)[0])
+    # slices, .to(), torch.cat on a pending result
+    torch.manual_seed(11)
+    got = graph(x)
+    assert torch.equal(got[3][2:4], want[3][2:4]) and torch.equal(torch.cat([got[2], got[2]])[6:], want[2])
+    assert torch.equal(got[1].to(dev).cpu(), want[1]) and torch.equal(got[0].permute(0, 3, 1, 2), want[0].permute(0, 3, 1, 2))
+    # nobody reads it: the timer downloads it, after which it sits in the device-copy cache
+    monkeypatch.setattr(_devices, "LAZY_SECONDS", 0.2)
+    torch.manual_seed(11)
+    lonely = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0]
+    p = _devices.pending_of(lonely)
+    assert p is not None
+    deadline = time.time() + 10.0
+    while not p.done and time.time() < deadline:
+        time.sleep(0.05)
+    assert p.done and id(lonely) in cache.entries and torch.equal(lonely, want[0])
+    # dropped unread: the device pieces go with it
+    monkeypatch.setattr(_devices, "LAZY_SECONDS", 30.0)
+    torch.manual_seed(11)
+    unread = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0]
+    p = _devices.pending_of(unread)
+    before = torch.cuda.memory_allocated(dev)
+    del unread
+    gc.collect()
+    _devices._LAZY._sweep()
+    assert p not in _devices._LAZY.pending
+    del p
+    gc.collect()
+    assert torch.cuda.memory_allocated(dev) < before
     cache.clear()
 
 

@@ -24,6 +24,7 @@ ap.add_argument("--cases", default="chain3,chain3_video")
 ap.add_argument("--frames", type=int, default=64)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--json", default="")
+ap.add_argument("--lut", default="AMD_TealOrange_33.cube", help="cube under the package's LUTS/ for the chain cases")
 a = ap.parse_args()
 if a.rounds < 5:
     raise SystemExit("ab_interleaved: fewer than 5 rounds is not an A/B")
@@ -44,7 +45,7 @@ if need_video:
     xv = bench.make_frames(F, H, W, dev, 1234, "video")
 out = torch.empty_like(x)
 ws = torch.empty_like(x) if "chain4" in a.cases else None
-lut = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube")), dev)
+lut = ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, a.lut)), dev)
 gen = torch.Generator(device=dev)
 
 
@@ -134,7 +135,7 @@ for rnd in range(a.rounds + 1):          # round 0 = warm-up + the bit compariso
                 continue
             for k, v in res.items():
                 times.setdefault(k, {}).setdefault(name, []).append(v)
-report = {"device": torch.cuda.get_device_name(0), "frames": F, "rounds": a.rounds, "libs": [n for n, _ in libs], "metrics": {}, "bit_identical": {}}
+report = {"device": torch.cuda.get_device_name(0), "lut": a.lut, "frames": F, "rounds": a.rounds, "libs": [n for n, _ in libs], "metrics": {}, "bit_identical": {}}
 for case, d in bits.items():
     base = d[libs[0][0]]
     report["bit_identical"][case] = {n: (v == base) for n, v in d.items()}

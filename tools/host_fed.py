@@ -17,7 +17,7 @@ def measure(frames=16, H=2160, W=3840, reps=3):
     import statistics
     from __graft_entry__ import load_package
     load_package()
-    from comfyui_vrgamedevgirl_amd import nodes, VRGDG_IV_Adjustments as iv
+    from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
     reps = max(3, int(reps))
     g = torch.Generator().manual_seed(3)
     x = torch.rand((frames, H, W, 3), generator=g)
@@ -26,7 +26,9 @@ def measure(frames=16, H=2160, W=3840, reps=3):
     nbytes = x.numel() * 4
 
     def once(fn):
-        t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0; del r
+        # the result is READ on the host inside the timed region (what the node after it would do if it were not one of this pack):
+        # a node of this pack hands out its result before the download (_devices.LazyFrames), materialise() is that first host access
+        t0 = time.perf_counter(); r = fn(); _devices.materialise(r); torch.cuda.synchronize(); dt = time.perf_counter() - t0; del r
         return dt
 
     cases = [("FastFilmGrain (bs 4)", lambda t: nodes.FastFilmGrain().apply_grain(t, 0.04, 0.5, 4)[0]),
@@ -43,7 +45,17 @@ def measure(frames=16, H=2160, W=3840, reps=3):
     for name, fn in cases:
         for label, src in (("pageable input", x), ("page-locked input", xp)):
             runs.append((name, label, (lambda f=fn, s_=src: f(s_))))
-    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls (each crosses PCIe both ways)", "pageable input", lambda: chain(x)))
+    def chain_eager(t):
+        old = _devices.LAZY_DOWNLOAD
+        _devices.LAZY_DOWNLOAD = False
+        try:
+            return chain(t)
+        finally:
+            _devices.LAZY_DOWNLOAD = old
+    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls in a graph (intermediates stay in HBM: 1 upload + 1 download)", "pageable input",
+                 lambda: chain(x)))
+    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls, every result downloaded at once (VRGDG_LAZY_DOWNLOAD=0: 1 upload + 4 downloads)",
+                 "pageable input", lambda: chain_eager(x)))
     for _, _, fn in runs:          # warm-up: the first call page-locks the result buffer
         once(fn)
     times = [[] for _ in runs]
