@@ -338,27 +338,31 @@ class _Pending:
         self.born = time.monotonic()
         self.owner = None            # weak reference to the LazyFrames handed out
 
+    def _download(self):
+        """Queue the copies of the pieces on the download stream and wait for the last one."""
+        with torch.cuda.device(self.device):
+            with _STAGING.lock:
+                _h2d, d2h, _own = _STAGING.side_streams(self.device, 0)
+            with torch.cuda.stream(d2h):
+                for s, e, gpu, ran in self.pieces:
+                    d2h.wait_event(ran)
+                    self.host[s:e].copy_(gpu, non_blocking=True)
+                    gpu.record_stream(d2h)
+                ev = torch.cuda.Event()
+                ev.record(d2h)
+            ev.synchronize()
+
     def materialise(self):
-        with self.lock:
+        with self.lock:                  # (self.host is the plain tensor under the LazyFrames: nothing in here re-enters __torch_function__)
             if self.done:
                 return
-            with torch.cuda.device(self.device):
-                with _STAGING.lock:
-                    _h2d, d2h, _own = _STAGING.side_streams(self.device, 0)
-                ev = None
-                with torch.cuda.stream(d2h):
-                    for s, e, gpu, ran in self.pieces:
-                        d2h.wait_event(ran)
-                        self.host[s:e].copy_(gpu, non_blocking=True)
-                        gpu.record_stream(d2h)
-                    ev = torch.cuda.Event()
-                    ev.record(d2h)
-                ev.synchronize()
+            self._download()
             self.done = True
         _LAZY.forget(self)
         owner = self.owner() if self.owner is not None else None
         if owner is not None:
-            _DEVICE_COPIES.remember(owner, self.device, self.pieces)       # from here on: an ordinary, validated device copy
+            owner._vrg_pending = None    # an ordinary tensor from here on -- BEFORE the cache looks at it (its stamp reads the data through torch)
+            _DEVICE_COPIES.remember(owner, self.device, self.pieces)       # ... and an ordinary, validated device copy
 
 
 class _LazyRegistry:

@@ -150,11 +150,6 @@ inline LutParams make_lut(const float* cells, int n, const float dmin[3], const 
                           float blend, float one_minus_blend) {
     LutParams P;
     P.cells = cells; P.n = n; P.top = (float)(n - 1);
-    if (lut_cell_major(n)) {
-        P.q_cells = cells + lut_record_floats(n); P.q_rec_stride = LUT_CELL_FLOATS; P.q_row_stride = (n - 1) * LUT_CELL_FLOATS;
-    } else {
-        P.q_cells = cells; P.q_rec_stride = LUT_REC_FLOATS; P.q_row_stride = n * LUT_REC_FLOATS;
-    }
     P.unit_domain = 1;
     for (int c = 0; c < 3; ++c) {
         P.dmin[c] = dmin[c];

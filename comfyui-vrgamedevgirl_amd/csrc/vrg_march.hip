@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? MARCH_MIN_WAVES : 1) void 
                     F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
                     F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
                     F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
-                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.q_row_stride + F[m & 1].R.cell * P.q_rec_stride) * 4;
+                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (LUT_REC_FLOATS * 4);
                     const int ql16 = (lane & 3) * 16, qh16 = 64 + (lane & 1) * 16;
                     const int v0 = __builtin_amdgcn_update_dpp(0, cell, 0x00, 0xf, 0xf, false) + ql16;   // quad_perm [0,0,0,0]
                     const int v1 = __builtin_amdgcn_update_dpp(0, cell, 0x55, 0xf, 0xf, false) + ql16;   // [1,1,1,1]
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? MARCH_MIN_WAVES : 1) void 
                                  "s_mov_b32 m0, %13\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %7\n\t"
                                  "s_mov_b32 m0, %0"
                                  : "=&s"(keep)
-                                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "s"(P.q_cells), "s"(l0), "s"(l0 + Q_ROUND), "s"(l0 + 2 * Q_ROUND),
+                                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "s"(P.cells), "s"(l0), "s"(l0 + Q_ROUND), "s"(l0 + 2 * Q_ROUND),
                                    "s"(l0 + 3 * Q_ROUND), "s"(l0 + 4 * Q_ROUND), "s"(l0 + 5 * Q_ROUND)
                                  : "memory");
                 };

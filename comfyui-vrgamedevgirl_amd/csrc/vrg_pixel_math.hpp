@@ -244,27 +244,11 @@ struct alignas(16) f32x4 { float x, y, z, w; };
 
 constexpr int LUT_REC_FLOATS = 12;
 
-// Cubes of at most LUT_CELL_MAJOR_MAX_N^3 carry a SECOND copy of the same records behind the record table, cell-major:
-//   [(N-1)][(N-1)][(N-1)][32]  -- one 128-byte ALIGNED record per cell: records r0 and r0 + 1 side by side + 8 floats of padding, so that a
-//                                 pixel's run is ONE cache line where the record form's 96 bytes at a 48-byte granule straddle a line for 5 of
-//                                 8 alignments (1.6 lines per pixel).  (N-1)^3 128 B = 1.77 MB at 25^3 (8 of the reference's 12 cubes): L2
-//                                 resident beside the streaming frames; 4.2 MB at 33^3 is not (measured slower there, LABNOTES I.1).
-// Only the QUAD-COOPERATIVE fetch of the march's steady rows reads it (q_cells / q_rec_stride / q_row_stride below, which describe the record
-// table itself for larger cubes): on incoherent pixels that fetch is bound by L2 -> L1 lines per pixel and gains 18 % (96 -> 113 Gpix/s
-// fetch-only, profiles/r05_probe_gather_25.json); six 16-byte requests PER LANE into one aligned record are slower than into the record form
-// (89 against 110 Gpix/s, same file), so every other kernel keeps reading `cells`.
-// A pixel's run starts at q_cells + (b0 (N-1) + g0) q_row_stride + r0 q_rec_stride floats in either layout and is read the same way.
-constexpr int LUT_CELL_FLOATS = 32;
-constexpr int LUT_CELL_MAJOR_MAX_N = 28;
-VRG_HD bool lut_cell_major(int n) { return n <= LUT_CELL_MAJOR_MAX_N; }
-VRG_HD long long lut_record_floats(int n) { return (((long long)(n - 1) * (n - 1) * n * LUT_REC_FLOATS) + 31) / 32 * 32; }      // padded to a whole line
-VRG_HD long long lut_table_floats(int n) { return lut_record_floats(n) + (lut_cell_major(n) ? (long long)(n - 1) * (n - 1) * (n - 1) * LUT_CELL_FLOATS : 0); }
-
+// (Round 5 measured a cell-major twin of this table -- one 128-byte aligned record per cell, ONE line per pixel -- for cubes up to 28^3,
+// read by the march's quad-cooperative fetch: the fetch alone gains 18 % on a 25^3 cube (96 -> 113 Gpix/s, profiles/r05_probe_gather_25.json),
+// the fused kernel LOSES 3-5 % (profiles/r05_ab_cellmajor_25.json: 2.6x the table bytes in the L2 beside the streaming frames).  Not kept.)
 struct LutParams {
     const float* cells;  // [(N-1)][(N-1)][N][12]
-    const float* q_cells;   // what the quad-cooperative fetch reads: the cell-major copy (cubes up to 28^3) or `cells`
-    int q_rec_stride;       // floats between the runs of neighbouring red cells there
-    int q_row_stride;       // floats between (b0, g0) rows there
     int n;               // N
     float top;           // (float)(N-1)
     float dmin[3];

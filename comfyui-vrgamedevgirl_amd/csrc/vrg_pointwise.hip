@@ -491,6 +491,179 @@ __global__ __launch_bounds__(256) void k_sharpen_grain_u8(const uint32_t* __rest
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same pass for ANY frame size and alignment (round 5): widths that are not a multiple of 4 (854, 1366), rows shorter than a block's
+// 1024 bytes, frames whose byte count is not a multiple of 4 (so that later frames start off the dword grid), down to 1 x 1 -- everything
+// k_sharpen_grain_u8 above leaves to the three-kernel route.  Same geometry (a thread owns four consecutive bytes of each of the block's
+// four sibling runs; the previous / next four bytes come from the neighbouring lanes by one DPP shift), but in FLAT BYTE space of the
+// whole batch instead of on the frame's dword grid:
+//   * the bytes above / below byte a are bytes a - E / a + E (E = 3 W bytes per row) whatever the row alignment: three UNALIGNED dword loads
+//     per run and thread (the hardware takes them; windows that would leave the batch are fetched from a clamped address and shifted into
+//     place -- the bytes that do not exist are never used, see below);
+//   * row and column are per BYTE (one 32-bit division per thread and run, a conditional step per byte): a thread's four bytes may
+//     straddle a row end, several of them when rows are shorter than four bytes;
+//   * the border rules are applied per byte on the assembled 3 x 3 window -- left / right first, then top / bottom, which is
+//     np.pad(mode="edge") (the corner tap is the pixel itself) resp. avg_pool2d's zero padding -- in wave-uniform branches only the waves
+//     that touch a border take;
+//   * a frame's last bytes (a byte count that is no multiple of 4) are stored byte by byte: the next frame's first bytes are its own.
+// Every tap that an edge rule replaces may hold garbage (another frame's bytes, zeros of a clamped window): it never reaches the
+// arithmetic.  Same device functions in the same order as the fast kernel: byte-identical to it and to the three-kernel route.
+// ----------------------------------------------------------------------------------------------
+template <bool ZERO>
+__global__ __launch_bounds__(256) void k_sharpen_grain_u8_any(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, NoiseK nk, int32_t H,
+                                                               int32_t E, uint32_t fe, int64_t total_bytes, uint32_t groups_per_frame,
+                                                               uint32_t total_blocks, float strength, float I, float S, float T) {
+    __shared__ float sn[4][GRAIN_N + 8];
+    const uint32_t per_xcd = (total_blocks + 7u) >> 3;
+    const uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || b >= total_blocks) return;
+    const uint32_t G = nk.G;
+    const uint32_t segs = (G + GRAIN_N - 1) / GRAIN_N;
+    const uint32_t bpf = segs * groups_per_frame;
+    const uint32_t frame = b / bpf;
+    const uint32_t rem = b - frame * bpf;
+    const uint32_t k = rem / segs;
+    const uint32_t idx_base = (rem - k * segs) * GRAIN_N;
+    const uint32_t valid_n = (G - idx_base) < (uint32_t)GRAIN_N ? (G - idx_base) : (uint32_t)GRAIN_N;
+    const uint32_t tid = threadIdx.x, t4 = tid * GRAIN_IPT;
+    const int lane = (int)(tid & 63u);
+    const uint64_t seed = chunk_seed(nk, frame);
+    const uint64_t off = chunk_offset(nk, frame);
+    const uint64_t ctr = (off >> 2) + k;
+    const int64_t fbase = (int64_t)frame * (int64_t)fe;               // the frame's first byte in the batch
+    const uint32_t a_first = 4u * G * k + idx_base;                    // frame-relative byte (= element) of run 0's first element in this block
+
+    // bytes [g, g + 4) of the batch; positions outside it read as unspecified values
+    auto load4 = [&](int64_t g) -> uint32_t {
+        const int64_t hi = total_bytes - 4;
+        const int64_t lo = g < 0 ? 0 : (g > hi ? hi : g);
+        uint32_t d;
+        __builtin_memcpy(&d, in + lo, 4);
+        const int sh = (int)(g - lo);                                  // > 0: the wanted window starts above the loaded one
+        if (sh > 0) d = sh >= 4 ? 0u : d >> (8 * sh);
+        else if (sh < 0) d = sh <= -4 ? 0u : d << (8 * (-sh));
+        return d;
+    };
+    struct Raw { uint32_t own[3], halo[3]; uint32_t a0; int32_t y0, c0; };
+    auto request = [&](int ii, Raw& q) {
+        q.a0 = a_first + G * (uint32_t)ii + 4u * tid;
+        const uint32_t a = q.a0 < fe ? q.a0 : (fe - 1u);               // (threads past the frame compute nothing that is stored)
+        q.y0 = (int32_t)(a / (uint32_t)E);
+        q.c0 = (int32_t)(a - (uint32_t)q.y0 * (uint32_t)E);
+        const int64_t g = fbase + (int64_t)q.a0;
+        const int64_t hoff = lane == 0 ? -4 : (lane == 63 ? 4 : 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int64_t gr = g + (int64_t)(r - 1) * E;
+            q.own[r] = load4(gr);
+            q.halo[r] = load4(gr + hoff);
+        }
+    };
+
+    Raw q;
+    request(0, q);                                                    // in flight under the Philox rounds
+
+    float nz[GRAIN_IPT][4];
+#pragma unroll
+    for (int j = 0; j < GRAIN_IPT; ++j) {
+        const u32x4 r = philox_for(seed, idx_base + t4 + j, ctr);
+        const f32x2 a = box_muller(r.x, r.y);
+        const f32x2 bb = box_muller(r.z, r.w);
+        nz[j][0] = a.x; nz[j][1] = a.y; nz[j][2] = bb.x; nz[j][3] = bb.y;
+    }
+    if (t4 < valid_n) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) *reinterpret_cast<float4*>(&sn[ii][4 + t4]) = make_float4(nz[0][ii], nz[1][ii], nz[2][ii], nz[3][ii]);
+    }
+    const int64_t group_base = (int64_t)4 * G * k + idx_base;
+    if (tid < 16) {                                                   // the two normals on either side of the block's four runs
+        const int ii = (int)(tid >> 2);
+        const int right = (int)((tid >> 1) & 1), d = (int)(tid & 1);
+        const int64_t li = group_base + (int64_t)G * ii + (right ? (int64_t)valid_n + d : -1 - d);
+        float nv = 0.0f;
+        if (li >= 0 && li < (int64_t)fe) nv = torch_randn_element(seed, off, G, (uint64_t)li);
+        sn[ii][right ? 4 + valid_n + d : 3 - d] = nv;
+    }
+    __syncthreads();
+    if (t4 >= valid_n) return;                                        // whole waves
+
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        if (ii > 0) request(ii, q);
+        if (a_first + G * (uint32_t)ii >= fe) continue;               // block-uniform: this run starts past the frame
+        // per byte: column (in bytes) and row, and which border rules apply
+        int32_t colk[4], yk[4];
+        bool lft[4], rgt[4], top[4], bot[4];
+        bool any_lr = false, any_tb = false;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            int32_t c = q.c0 + kk, y = q.y0;
+            if (c >= E) { c -= E; y += 1; }                            // E >= 3: at most one row end inside c0 + 3
+            if (c >= E) { c -= E; y += 1; }                            // (E == 3: two)
+            colk[kk] = c; yk[kk] = y;
+            lft[kk] = c < 3; rgt[kk] = c >= E - 3; top[kk] = y == 0; bot[kk] = y >= H - 1;
+            any_lr = any_lr || lft[kk] || rgt[kk];
+            any_tb = any_tb || top[kk] || bot[kk];
+        }
+        const bool row_end_here = __builtin_amdgcn_ballot_w64(any_lr) != 0;
+        const bool frame_edge_here = __builtin_amdgcn_ballot_w64(any_tb) != 0;
+        float o[3][4], pl[3][3], nr[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t ow = q.own[r], hw = q.halo[r];
+            const uint32_t prev = sg_shr_u(hw, ow), next = sg_shl_u(hw, ow);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[r][i] = unit_from_u8((uint8_t)(ow >> (8 * i)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pl[r][i] = unit_from_u8((uint8_t)(prev >> (8 * (1 + i))));
+                nr[r][i] = unit_from_u8((uint8_t)(next >> (8 * i)));
+            }
+        }
+        int jj = (int)(q.a0 % 3u);                                     // position of the first byte in its pixel: 0 = B, 1 = G, 2 = R
+        uint32_t packed = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float p[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                p[r][0] = kk >= 3 ? o[r][kk >= 3 ? kk - 3 : 0] : pl[r][kk < 3 ? kk : 0];
+                p[r][1] = o[r][kk];
+                p[r][2] = kk < 1 ? o[r][kk < 1 ? kk + 3 : 0] : nr[r][kk >= 1 ? kk - 1 : 0];
+            }
+            if (row_end_here) {                                       // left / right first ...
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    p[r][0] = lft[kk] ? (ZERO ? 0.0f : p[r][1]) : p[r][0];
+                    p[r][2] = rgt[kk] ? (ZERO ? 0.0f : p[r][1]) : p[r][2];
+                }
+            }
+            if (frame_edge_here) {                                    // ... then top / bottom: the corner tap of the replicate border is the pixel itself
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    p[0][j] = top[kk] ? (ZERO ? 0.0f : p[1][j]) : p[0][j];
+                    p[2][j] = bot[kk] ? (ZERO ? 0.0f : p[1][j]) : p[2][j];
+                }
+            }
+            const float x = stencil_value(0, p, strength, ZERO ? 1 : 0);
+            const float n_own = sn[ii][4 + t4 + kk + 2 - 2 * jj];     // element 3 p + 2 - jj of byte 3 p + jj
+            const float n_green = sn[ii][4 + t4 + kk + 1 - jj];       // element 3 p + 1
+            const float res = grain_element(x, n_own, n_green, 2 - jj, I, S, T);
+            packed |= (uint32_t)u8_from_unit(res) << (8 * kk);
+            jj = (jj == 2) ? 0 : jj + 1;
+        }
+        uint8_t* dst = out + fbase + (int64_t)q.a0;
+        if (q.a0 + 4u <= fe) {
+            __builtin_memcpy(dst, &packed, 4);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (q.a0 + (uint32_t)kk < fe) dst[kk] = (uint8_t)(packed >> (8 * kk));
+        }
+        (void)colk; (void)yk;
+    }
+}
+
 // Noise-injection form: out = grain(x, noise) with caller-supplied normals (one pixel per thread).
 __global__ __launch_bounds__(256) void k_grain_injected(const px3* __restrict__ in, const px3* __restrict__ nz,
                                                          px3* __restrict__ out, int64_t pixels, float I, float S, float T) {
@@ -517,21 +690,6 @@ __global__ __launch_bounds__(256) void k_lut_build_cells(const float* __restrict
     const int r = rec % n, g0 = (rec / n) % nc, b0 = rec / (n * nc);
     float v[LUT_REC_FLOATS];
     lut_build_record(table, n, b0, g0, r, v);
-    if (lut_cell_major(n)) {
-        // the cell-major twin behind the record table: record r is the first half of cell r (r < N - 1) and the second half of cell
-        // r - 1 (r > 0); the 8 floats behind them are zeroed
-        float* row = cells + lut_record_floats(n) + (size_t)(b0 * nc + g0) * nc * LUT_CELL_FLOATS;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const f32x4 q = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-            if (r < nc) reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[i] = q;
-            if (r > 0) reinterpret_cast<f32x4*>(row + (size_t)(r - 1) * LUT_CELL_FLOATS)[3 + i] = q;
-        }
-        if (r < nc) {
-            reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[6] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            reinterpret_cast<f32x4*>(row + (size_t)r * LUT_CELL_FLOATS)[7] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-    }
     f32x4* dst = reinterpret_cast<f32x4*>(cells + (size_t)rec * LUT_REC_FLOATS);
 #pragma unroll
     for (int i = 0; i < 3; ++i) dst[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
@@ -760,8 +918,10 @@ int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_
     if (frames == 0) return VRG_OK;
     const int64_t frame_elems = (int64_t)height * width * 3;
     const bool aligned = (reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) % 4 == 0;
-    if (nd->chunk_frames != 1 || width % 4 != 0 || (int64_t)width * 3 / 4 < 256 || frame_elems > 0x7fffffffll || !aligned)
-        return VRG_ERR_UNSUPPORTED;                                   // the caller converts and runs the fp32 entry points
+    // several frames per noise chunk: the enhancer seeds every frame on its own (reference :233-276), nothing calls that; a batch of less than
+    // four bytes (one 1 x 1 frame) has no dword to load: the caller converts and runs the fp32 entry points
+    if (nd->chunk_frames != 1 || frame_elems > 0x7fffffffll || frames * frame_elems < 4) return VRG_ERR_UNSUPPORTED;
+    const bool fast = width % 4 == 0 && (int64_t)width * 3 / 4 >= 256 && aligned;      // rows on the frame's dword grid, at most one row end per block
     const NoiseK nk = make_noise(nd, frame_elems);
     const uint64_t groups = (uint64_t)((frame_elems + 4 * (int64_t)nk.G - 1) / (4 * (int64_t)nk.G));
     const uint64_t per_frame = groups * ((nk.G + GRAIN_N - 1) / GRAIN_N);
@@ -773,6 +933,23 @@ int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_
         nkk.chunk0 += f0;
         const uint32_t total = (uint32_t)(per_frame * (uint64_t)nf);
         const uint32_t blocks = ((total + 7u) / 8u) * 8u;
+        if (!fast) {
+            // any width, any alignment: flat byte space of the batch (k_sharpen_grain_u8_any); the windows may reach into the neighbouring
+            // frames of the WHOLE batch, so the kernel gets the batch's base and the launch's first frame through the chunk index
+            NoiseK nka = nk;
+            nka.chunk0 += f0;
+            const uint8_t* base = in + f0 * frame_elems;
+            uint8_t* obase = out + f0 * frame_elems;
+            const int64_t reach = (frames - f0) * frame_elems;       // bytes addressable from `base` upwards (windows below it are clamped)
+            if (border == VRG_BORDER_ZERO)
+                hipLaunchKernelGGL((k_sharpen_grain_u8_any<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, obase, nka, height, width * 3,
+                                   (uint32_t)frame_elems, reach, (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+            else
+                hipLaunchKernelGGL((k_sharpen_grain_u8_any<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, base, obase, nka, height, width * 3,
+                                   (uint32_t)frame_elems, reach, (uint32_t)groups, total, strength, intensity, sat, one_minus_sat);
+            VRG_CHECK_LAUNCH();
+            continue;
+        }
         const uint32_t* src = reinterpret_cast<const uint32_t*>(in + f0 * frame_elems);
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + f0 * frame_elems);
         if (border == VRG_BORDER_ZERO)
@@ -813,8 +990,7 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
 int64_t vrg_lut_cells_floats(int32_t lut_size) {
     if (lut_size < 2 || lut_size > 256) return 0;
     const int64_t nc = lut_size - 1;
-    (void)nc;
-    return (int64_t)vrg::lut_table_floats(lut_size);          // the record table + (cubes up to 28^3) its cell-major twin (vrg_pixel_math.hpp)
+    return nc * nc * lut_size * LUT_REC_FLOATS;
 }
 
 int vrg_lut_prepare_f32(const float* lut, int32_t lut_size, float* cells, void* stream) {

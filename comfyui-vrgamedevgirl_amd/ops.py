@@ -306,8 +306,9 @@ def sharpen_then_seeded_grain(images: torch.Tensor, sharpen_strength: float, zer
 
 def _sharpen_then_seeded_grain_u8(frames_bgr, sharpen_strength, zero_border, grain_intensity, saturation_mix, seed, frame_start):
     """Decoded uint8 B,G,R frames in and out: ``_tensor_to_frames(_apply_effects_batch(_frames_to_tensor(frames)))`` of the enhancer's
-    render loop (VRGDG_StandaloneVideoEnhancerNodes.py:417-421) as one kernel (vrg_sharpen_grain_u8, 3 + 3 B/px).  Frame sizes the
-    kernel refuses, or a call with one of the two effects off, take the converter -> fp32 -> converter route: the same bytes."""
+    render loop (VRGDG_StandaloneVideoEnhancerNodes.py:417-421) as one kernel (vrg_sharpen_grain_u8, 3 + 3 B/px; any width, height and
+    alignment since round 5).  A batch of fewer than four bytes, or a call with one of the two effects off, takes the converter -> fp32 ->
+    converter route: the same bytes."""
     x = _check_frames(frames_bgr, "frames", channels=3, dtype=torch.uint8)
     F, H, W, _ = x.shape
     if F == 0:
@@ -366,7 +367,7 @@ def film_grain_injected(images: torch.Tensor, noise: torch.Tensor, grain_intensi
 
 @dataclass
 class DeviceLut:
-    table: torch.Tensor        # the table as vrg_lut_prepare_f32 lays it out (record form, or cell-major for cubes up to 28^3): opaque to Python
+    table: torch.Tensor        # record table on the device: (N-1)^2 * N records of 12 fp32 (vrg_lut_prepare_f32)
     size: int                  # N
     domain_min: tuple
     domain_max: tuple

@@ -97,8 +97,10 @@ int vrg_sharpen_grain_f32(const float* in, float* out, int64_t frames, int32_t h
  * _tensor_to_frames(_apply_effects_batch(_frames_to_tensor(frames))) (VRGDG_StandaloneVideoEnhancerNodes.py:311-324, 278-294,
  * 417-421) as ONE kernel moving 3 + 3 B/px: v / 255 at the load, unsharp (border as above), per-frame-seeded grain,
  * clip(x * 255, 0, 255) truncated to uint8 at the store.  out = vrg_f32rgb_to_u8bgr(vrg_sharpen_grain_f32(vrg_u8bgr_to_f32rgb(in)))
- * byte for byte.  in != out.  VRG_ERR_UNSUPPORTED (the caller runs that three-kernel route) unless width % 4 == 0,
- * width * 3 / 4 >= 256, chunk_frames == 1 and both pointers are 4-byte aligned. */
+ * byte for byte.  in != out.  Any width, height and pointer alignment (ABI v7: frames with width % 4 == 0, width * 3 / 4 >= 256 and
+ * 4-byte aligned pointers run on the frame's dword grid; everything else -- 854 x 480, 1366 x 768, thumbnails, frames that start off a
+ * dword -- in flat byte space with unaligned dword accesses, same bytes).  VRG_ERR_UNSUPPORTED (the caller runs that three-kernel
+ * route) only for chunk_frames != 1 and for a batch of fewer than four bytes. */
 int vrg_sharpen_grain_u8(const uint8_t* in, uint8_t* out, int64_t frames, int32_t height, int32_t width,
                          float strength, int32_t border, float intensity, float sat, float one_minus_sat,
                          const vrg_noise_desc* noise, void* stream);
@@ -116,10 +118,7 @@ int vrg_grain_injected_f32(const float* in, const float* noise, float* out, int6
  * [N][N][N][3] indexed [blue][green][red], as _parse_cube_file returns it) into the gather-friendly
  * form the kernels read -- (N-1)^2*N records of 12 floats, one per (b0, g0, red node), the four (g,b)
  * corner values of each channel copied verbatim -- so that a pixel fetches one contiguous 96-byte
- * run (red nodes r0, r0+1) instead of eight scattered corners.  Behind that table, cubes of at most 28^3 get a cell-major twin --
- * one 128-byte record per (b0, g0, r0) cell = the same two records side by side + padding, one cache line per pixel -- which the
- * quad-cooperative fetch of the fused march reads (the table is opaque to the caller: the library derives the layout from N).
- * `cells` must hold vrg_lut_cells_floats(N) floats, 128-byte aligned (16 suffices for cubes above 28^3).  2 <= N <= 256.
+ * run (red nodes r0, r0+1) instead of eight scattered corners.  `cells` must hold vrg_lut_cells_floats(N) floats, 16-byte aligned.  2 <= N <= 256.
  * `channels` >= 3; channels beyond RGB are copied through.  blend_mode: 1 = LUT only (blend>=1),
  * 2 = fl(fl(x*one_minus_blend) + fl(y*blend)).  (blend <= 0 is the caller's no-op.)
  * ------------------------------------------------------------------------------------------- */

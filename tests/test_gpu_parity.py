@@ -203,7 +203,12 @@ def test_seeded_per_frame_grain_is_batch_invariant_and_matches_oracle(pkg, ops, 
 
 @pytest.mark.parametrize("zero_border", [False, True], ids=["replicate", "zero"])
 @pytest.mark.parametrize("shape", [(3, 37, 344, 3), (2, 64, 1024, 3), (2, 90, 500, 3), (2, 5, 4096, 3), (1, 1, 2048, 3), (2, 1080, 1920, 3),
-                                   (1, 2160, 3840, 3)], ids=lambda s: "x".join(map(str, s)))
+                                   (1, 2160, 3840, 3),
+                                   # round 5, any width / alignment (k_sharpen_grain_u8_any): widths off the dword grid, rows shorter than a
+                                   # block, frames whose byte count is no multiple of 4, down to 1 x 1
+                                   (3, 480, 854, 3), (2, 768, 1366, 3), (2, 20, 56, 3), (2, 20, 346, 3), (3, 37, 343, 3), (2, 33, 342, 3),
+                                   (5, 1, 1, 3), (4, 7, 5, 3), (3, 2, 1, 3), (2, 1, 9, 3), (1, 3, 2, 3), (3, 5, 7, 3), (2, 1, 2, 3), (7, 2, 2, 3),
+                                   (2, 64, 85, 3)], ids=lambda s: "x".join(map(str, s)))
 def test_fused_sharpen_then_seeded_grain_equals_the_two_kernels(pkg, ops, dev, shape, zero_border):
     """vrg_sharpen_grain_f32 (the enhancer's sharpen -> per-frame-seeded grain order in one pass, grain geometry leading) against the
     stencil kernel followed by the grain kernel -- each of which is held to the oracle elsewhere -- bit for bit: row ends inside a wave
@@ -1745,7 +1750,8 @@ def test_u8_sharpen_then_seeded_grain_equals_the_converter_route(pkg, ops, dev, 
     import ctypes as C
     g = torch.Generator().manual_seed(sum(shape) + int(zero_border))
     frames = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
-    frames[0, 0, :8] = torch.tensor([0, 255, 1, 254, 128, 127, 255, 0], dtype=torch.uint8)[:, None]      # saturated codes on a border
+    nb = min(8, shape[2])
+    frames[0, 0, :nb] = torch.tensor([0, 255, 1, 254, 128, 127, 255, 0], dtype=torch.uint8)[:nb, None]      # saturated codes on a border
     x = frames.to(dev)
     route = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(x), 0.6, zero_border, 0.05, 0.4, 1234, 17))
     got = ops.sharpen_then_seeded_grain(x, 0.6, zero_border, 0.05, 0.4, 1234, 17)
@@ -1772,26 +1778,25 @@ def test_u8_sharpen_then_seeded_grain_equals_the_converter_route(pkg, ops, dev, 
 
 
 def test_u8_sharpen_grain_refuses_what_it_does_not_take(pkg, ops, dev):
-    """Widths not a multiple of 4 or below 344, several frames per noise chunk, in-place, one effect off: the entry point says so and the
-    operator returns the converter route's bytes."""
+    """What is left of the refusals after round 5 (any width, height and alignment is taken now): several frames per noise chunk (the
+    enhancer seeds every frame on its own), a batch of fewer than four bytes (one 1 x 1 frame), in-place -- the entry point says so and the
+    operator returns the converter route's bytes; one effect off takes the reference's early returns."""
     from comfyui_vrgamedevgirl_amd import _hip, rng
     import ctypes as C
     lib = _hip.lib()
-    for shp in ((2, 20, 56, 3), (2, 20, 346, 3)):
-        g = torch.Generator().manual_seed(shp[2])
-        x = torch.randint(0, 256, shp, generator=g, dtype=torch.uint8).to(dev)
-        out = torch.empty_like(x)
-        d = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 3, dev)).desc()
-        args = (shp[0], shp[1], shp[2], 0.5, 0, 0.04, 0.5, 0.5, C.byref(d), _hip.current_stream())
-        assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(out), *args) == _hip.VRG_ERR_UNSUPPORTED
-        assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(x), *args) == _hip.VRG_ERR_BAD_ARG
-        want = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(x), 0.5, False, 0.04, 0.5, 3, 0))
-        assert torch.equal(ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 3, 0), want)
     g = torch.Generator().manual_seed(1)
     x = torch.randint(0, 256, (2, 20, 512, 3), generator=g, dtype=torch.uint8).to(dev)
     d = ops.NoisePlan(2, rng.per_frame_seeded(x.numel(), 3, dev)).desc()
     assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(torch.empty_like(x)), 2, 20, 512, 0.5, 0, 0.04, 0.5, 0.5, C.byref(d),
                                     _hip.current_stream()) == _hip.VRG_ERR_UNSUPPORTED
+    d1 = ops.NoisePlan(1, rng.per_frame_seeded(x[0].numel(), 3, dev)).desc()
+    assert lib.vrg_sharpen_grain_u8(_hip.ptr(x), _hip.ptr(x), 2, 20, 512, 0.5, 0, 0.04, 0.5, 0.5, C.byref(d1), _hip.current_stream()) == _hip.VRG_ERR_BAD_ARG
+    one = torch.tensor([[[[7, 200, 90]]]], dtype=torch.uint8, device=dev)                  # 3 bytes: no dword to load
+    d3 = ops.NoisePlan(1, rng.per_frame_seeded(3, 3, dev)).desc()
+    assert lib.vrg_sharpen_grain_u8(_hip.ptr(one), _hip.ptr(torch.empty_like(one)), 1, 1, 1, 0.5, 0, 0.04, 0.5, 0.5, C.byref(d3),
+                                    _hip.current_stream()) == _hip.VRG_ERR_UNSUPPORTED
+    want = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(one), 0.5, False, 0.04, 0.5, 3, 0))
+    assert torch.equal(ops.sharpen_then_seeded_grain(one, 0.5, False, 0.04, 0.5, 3, 0), want)
     for strength, intensity in ((0.0, 0.05), (0.6, 0.0), (0.0, 0.0)):       # one effect (or both) off: the reference's early returns
         y = ops.frames_u8_to_f32(x)
         if strength > 0:
@@ -1799,6 +1804,32 @@ def test_u8_sharpen_grain_refuses_what_it_does_not_take(pkg, ops, dev):
         if intensity > 0:
             y = ops.film_grain_seeded_frames(y, intensity, 0.5, 3, 0)
         assert torch.equal(ops.sharpen_then_seeded_grain(x, strength, True, intensity, 0.5, 3, 0), ops.f32_to_frames_u8(y))
+
+
+def test_u8_sharpen_grain_off_the_dword_grid(pkg, ops, dev):
+    """Frames that do not start on a dword (a slice of a batch whose frames hold an odd number of bytes) and whose windows reach into
+    neighbouring frames of a larger allocation: the bytes of the converter route, and nothing outside the frames is written."""
+    g = torch.Generator().manual_seed(5)
+    for shape in ((6, 5, 7, 3), (5, 3, 343, 3), (4, 9, 1, 3)):
+        big = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).to(dev)
+        x = big[1:-1]
+        assert x.data_ptr() % 4 != 0 or shape[1] * shape[2] * 3 % 4 == 0
+        for zero in (False, True):
+            want = ops.f32_to_frames_u8(ops.sharpen_then_seeded_grain(ops.frames_u8_to_f32(x.clone()), 0.7, zero, 0.06, 0.3, 99, 4))
+            got = ops.sharpen_then_seeded_grain(x, 0.7, zero, 0.06, 0.3, 99, 4)
+            assert torch.equal(got, want), (shape, zero)
+    # guard bytes around the output stay untouched
+    x = torch.randint(0, 256, (3, 5, 7, 3), generator=g, dtype=torch.uint8).to(dev)
+    from comfyui_vrgamedevgirl_amd import _hip, rng
+    import ctypes as C
+    fe = 5 * 7 * 3
+    buf = torch.full((fe * 3 + 16,), 0xAB, dtype=torch.uint8, device=dev)
+    d = ops.NoisePlan(1, rng.per_frame_seeded(fe, 7, dev)).desc()
+    st = _hip.lib().vrg_sharpen_grain_u8(_hip.ptr(x), C.c_void_p(buf.data_ptr() + 5), 3, 5, 7, 0.5, 0, 0.04, 0.5, float(np.float32(0.5)), C.byref(d),
+                                         _hip.current_stream())
+    assert st == _hip.VRG_OK
+    assert bool((buf[:5] == 0xAB).all()) and bool((buf[5 + 3 * fe:] == 0xAB).all())
+    assert torch.equal(buf[5:5 + 3 * fe].view(3, 5, 7, 3), ops.sharpen_then_seeded_grain(x, 0.5, False, 0.04, 0.5, 7, 0))
 
 
 # ---------------------------------------------------------------------------------------- opening colour match (8f-4)

@@ -331,3 +331,47 @@ def test_product_sources_have_no_command_line_switches(pkg):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-D" + macro, "-fsyntax-only",
                             os.path.join(csrc, "vrg_api.hip")], capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "not build options of the product sources" in r.stderr, macro
+
+
+def test_lazy_frames_download_once_at_first_use(pkg, monkeypatch):
+    """_devices.LazyFrames without a GPU (the download replaced by a host copy): shape questions do not download; any torch / numpy use
+    downloads exactly once, on the calling thread, without re-entering itself (the cache's content stamp reads the tensor through torch);
+    afterwards the object is an ordinary tensor known to the device-copy cache; a result dropped unread leaves the registry at once."""
+    import gc
+    import weakref
+    from comfyui_vrgamedevgirl_amd import _devices as D
+    monkeypatch.setattr(D, "LAZY_SECONDS", 0.0)                   # no timer thread here
+    monkeypatch.setattr(D._DEVICE_COPIES, "_budget", lambda device: 1 << 30)
+    truth = torch.arange(2 * 3 * 4 * 3, dtype=torch.float32).reshape(2, 3, 4, 3)
+    calls = []
+
+    def make():
+        host = torch.zeros_like(truth)
+        p = D._Pending(host, torch.device("cpu"), [(0, 2, truth, None)], truth.numel() * 4)
+        monkeypatch.setattr(p, "_download", lambda p=p: (calls.append(1), p.host.copy_(p.pieces[0][2])))
+        res = D.LazyFrames(host, p)
+        p.owner = weakref.ref(res, lambda _r, pr=weakref.ref(p): D._LAZY.forget(pr()) if pr() is not None else None)
+        D._LAZY.add(p, 1 << 30)
+        return res, p
+
+    t, p = make()
+    assert isinstance(t, torch.Tensor) and t.shape == truth.shape and t.dtype == torch.float32 and t.device.type == "cpu" and len(t) == 2
+    assert t.numel() == truth.numel() and t.is_contiguous() and t.stride() == truth.stride() and not calls and D.pending_of(t) is p
+    assert torch.equal(t, truth) and len(calls) == 1 and D.pending_of(t) is None and p.done       # (first use: one download)
+    assert torch.equal(t + 1, truth + 1) and len(calls) == 1
+    assert id(t) in D._DEVICE_COPIES.entries and p not in D._LAZY.pending
+    t.mul_(2)                                                                                       # an ordinary tensor now: in-place ops, version counter
+    assert D._DEVICE_COPIES.lookup(t, torch.device("cpu")) is None
+    for use in (lambda x: x.numpy(), lambda x: x[1], lambda x: list(x), lambda x: x.clone(), lambda x: x.to(torch.float16), lambda x: x.data_ptr(),
+                lambda x: torch.cat([x, x]), lambda x: x.permute(0, 3, 1, 2), lambda x: repr(x), lambda x: x.sum().item(), lambda x: np.asarray(x)):
+        n = len(calls)
+        u, pu = make()
+        use(u)
+        assert len(calls) == n + 1 and pu.done and D.pending_of(u) is None
+    u, pu = make()
+    n_pending = len(D._LAZY.pending)
+    assert pu in D._LAZY.pending
+    del u
+    gc.collect()
+    assert pu not in D._LAZY.pending and len(D._LAZY.pending) == n_pending - 1 and not pu.done
+    D._DEVICE_COPIES.clear()
