@@ -191,10 +191,13 @@ def live_traffic(timeout_s=150):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
-    def summary(substrings):
+    def summary(substrings, runs=1):
+        # tools/prof_driver.py runs every workload ONCE: a kernel's figure per pixel is the SUM over its launches (pass 1 of the colour match
+        # alone is launched per group of frames), divided by the number of driver workloads that launch it (`runs`: the apply march and the
+        # reductions serve both the headline chain and the colour match alone)
         names = [k for k in per_px if any(s in k for s in substrings)]
         def avg(c, mult=1.0):
-            return sum(sum(per_px[k][c]) / len(per_px[k][c]) * mult for k in names if c in per_px[k])
+            return sum(sum(per_px[k][c]) * mult for k in names if c in per_px[k]) / runs
         rd, wr = avg("FETCH_SIZE", 2.0), avg("WRITE_SIZE")
         busy, wave = avg("SQ_ACTIVE_INST_VALU"), avg("SQ_WAVE_CYCLES")
         return {"kernels": sorted(n.split("(")[0][:80] for n in names), "read": round(rd, 2), "written": round(wr, 2), "total": round(rd + wr, 2),
@@ -203,7 +206,8 @@ def live_traffic(timeout_s=150):
                 "valu_busy_simd_cycles": round(busy, 3),                    # SIMD-cycles per pixel with a VALU instruction executing
                 "wave_cycles": round(wave, 3), "wait_issue_share": round(avg("SQ_WAIT_INST_ANY") / wave, 3) if wave else None,
                 "wait_memory_share": round(avg("SQ_WAIT_ANY") / wave, 3) if wave else None}
-    res = {key: summary(subs) for key, subs in PASS_KERNELS.items()}
+    shared = {("chain4_4k", "apply"), ("colormatch_4k", "apply"), ("chain4_4k", "tstats"), ("colormatch_4k", "tstats")}
+    res = {key: summary(subs, 2 if key in shared else 1) for key, subs in PASS_KERNELS.items()}
     res["calibration_k_lut3d"] = summary(("k_lut3d",))
     if not res["calibration_k_lut3d"]["total"]:
         raise RuntimeError("no counters collected")

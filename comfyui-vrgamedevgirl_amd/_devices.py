@@ -316,6 +316,8 @@ def release_device_copies() -> int:
 #     `data_ptr()`, `untyped_storage()`, pickling, `__array__`, DLPack, printing) -- goes through `__torch_function__`, which first
 #     downloads the frames (asynchronous copies on the download stream, then one wait) and then runs the call on the plain tensor.
 #     Shape / dtype / device / stride / numel questions do not download.
+#   * A call that uploads its frames copies finished pieces to the host buffer in the background while it is still uploading (the
+#     download direction is idle then): a host-side consumer of a single node pays max(upload, download) as before, not their sum.
 #   * A result nobody has touched for VRGDG_LAZY_SECONDS (default 2) is downloaded by a timer; so is the oldest one when the pending
 #     results outgrow the device-copy budget.  After its download a result is an ordinary entry of the device-copy cache above.
 #   * What this cannot see: native code that reads a tensor's memory WITHOUT going through a torch API (a pybind11 extension taking
@@ -331,8 +333,9 @@ LAZY_SECONDS = float(os.environ.get("VRGDG_LAZY_SECONDS", "2"))
 class _Pending:
     """The device pieces of a result whose host copy has not been made yet."""
 
-    def __init__(self, host: torch.Tensor, device: torch.device, pieces, nbytes: int):
+    def __init__(self, host: torch.Tensor, device: torch.device, pieces, nbytes: int, queued=None):
         self.host, self.device, self.pieces, self.nbytes = host, device, pieces, nbytes
+        self.queued = list(queued) if queued is not None else [None] * len(pieces)     # per piece: the event of a copy already queued, or None
         self.lock = threading.Lock()
         self.done = False
         self.born = time.monotonic()
@@ -344,12 +347,14 @@ class _Pending:
             with _STAGING.lock:
                 _h2d, d2h, _own = _STAGING.side_streams(self.device, 0)
             with torch.cuda.stream(d2h):
-                for s, e, gpu, ran in self.pieces:
+                for (s, e, gpu, ran), ev_q in zip(self.pieces, self.queued):
+                    if ev_q is not None:              # copied while the call was still uploading (see _stream_frames_on)
+                        continue
                     d2h.wait_event(ran)
                     self.host[s:e].copy_(gpu, non_blocking=True)
                     gpu.record_stream(d2h)
                 ev = torch.cuda.Event()
-                ev.record(d2h)
+                ev.record(d2h)                        # the stream is in order: behind every copy queued on it earlier as well
             ev.synchronize()
 
     def materialise(self):
@@ -649,7 +654,7 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                 release_device_copies()
         except Exception:
             pass
-    produced = []
+    produced, queued = [], []
     with _STAGING.lock:
         lanes = []
         seen = {}
@@ -716,7 +721,21 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
                     ran = _event()
                     ran.record(compute)
                 if lazy_out:
+                    # A call that has to UPLOAD its frames leaves the download direction of the link idle meanwhile: the pieces are copied
+                    # to the host buffer as they finish (queued, not waited for) -- a host-side consumer then finds all but the last
+                    # piece there, as with eager downloads (up and down in duplex), and the next node of this pack still takes the frames
+                    # from HBM without waiting.  A call whose frames were already in HBM has no such idle time: nothing is queued, the
+                    # download happens if and when somebody asks for the result on the host.
+                    done = None
+                    if cached is None:
+                        with torch.cuda.stream(d2h):
+                            d2h.wait_event(ran)
+                            out[s:e].copy_(gpu_out, non_blocking=True)
+                            gpu_out.record_stream(d2h)
+                            done = _event()
+                            done.record(d2h)
                     produced.append((s, e, gpu_out, ran))
+                    queued.append(done)
                     continue
                 dst = out[s:e] if ring is None else ring[k][:(e - s) * out_fb].view(out_dtype).view(gpu_out.shape)
                 with torch.cuda.stream(d2h):
@@ -738,7 +757,7 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
         # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
     if lazy_out:
         import weakref
-        p = _Pending(out, devices[0], produced, F * out_fb)
+        p = _Pending(out, devices[0], produced, F * out_fb, queued)
         res = LazyFrames(out, p)
         # a result dropped unread takes its device pieces with it at once (the registry's reference is the only other one)
         p.owner = weakref.ref(res, lambda _r, pr=weakref.ref(p): _LAZY.forget(pr()) if pr() is not None else None)
