@@ -142,12 +142,12 @@ def _profile_json(*names):
 PASS_KERNELS = {
     ("chain4_4k", "stats"): ("k_produce_lab<3",),
     ("chain4_4k", "apply"): ("k_apply_march<",),
-    ("chain4_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
+    ("chain4_4k", "tstats"): ("k_tstats_frame<false, 1>",),
     ("chain3_4k", "apply"): ("k_chain_march<3, true",),
     ("grain_lut_1080p", "apply"): ("k_chain_pointwise<3",),
     ("colormatch_4k", "stats"): ("k_lab_partials<0, true>",),
-    ("colormatch_4k", "apply"): ("k_apply_march<",),
-    ("colormatch_4k", "tstats"): ("k_tstats_frame", "k_tstats_rows<"),
+    ("colormatch_4k", "apply"): ("k_chain_pointwise4<20",),
+    ("colormatch_4k", "tstats"): ("k_tstats_frame<false, 1>",),
 }
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9          # 1,024 SIMDs at the 2.4 GHz the PMC runs report (GRBM_GUI_ACTIVE / time)
 
@@ -193,7 +193,7 @@ def live_traffic(timeout_s=150):
 
     def summary(substrings, runs=1):
         # tools/prof_driver.py runs every workload ONCE: a kernel's figure per pixel is the SUM over its launches (pass 1 of the colour match
-        # alone is launched per group of frames), divided by the number of driver workloads that launch it (`runs`: the apply march and the
+        # alone is launched per group of frames), divided by the number of driver workloads that launch it (`runs`: the whole-frame
         # reductions serve both the headline chain and the colour match alone)
         names = [k for k in per_px if any(s in k for s in substrings)]
         def avg(c, mult=1.0):
@@ -206,7 +206,7 @@ def live_traffic(timeout_s=150):
                 "valu_busy_simd_cycles": round(busy, 3),                    # SIMD-cycles per pixel with a VALU instruction executing
                 "wave_cycles": round(wave, 3), "wait_issue_share": round(avg("SQ_WAIT_INST_ANY") / wave, 3) if wave else None,
                 "wait_memory_share": round(avg("SQ_WAIT_ANY") / wave, 3) if wave else None}
-    shared = {("chain4_4k", "apply"), ("colormatch_4k", "apply"), ("chain4_4k", "tstats"), ("colormatch_4k", "tstats")}
+    shared = {("chain4_4k", "tstats"), ("colormatch_4k", "tstats")}
     res = {key: summary(subs, 2 if key in shared else 1) for key, subs in PASS_KERNELS.items()}
     res["calibration_k_lut3d"] = summary(("k_lut3d",))
     if not res["calibration_k_lut3d"]["total"]:

@@ -9,7 +9,7 @@ import os
 import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VRGDG_HIP_LIB") or os.path.join(PKG_DIR, "libvrgdg_hip.so")   # override: A/B builds (tools/ab_libs.sh)
+LIB_PATH = os.environ.get("VRGDG_HIP_LIB") or os.path.join(PKG_DIR, "libvrgdg_hip.so")   # override: A/B builds (tools/build_variant.py, tools/ab_interleaved.py)
 
 VRG_OK = 0
 VRG_ERR_BAD_ARG = 1

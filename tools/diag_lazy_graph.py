@@ -1,0 +1,35 @@
+"""Per-call timing of the four-node graph with the lazy download: where does an occasional slow repetition spend its time?
+    python tools/diag_lazy_graph.py [--frames 16] [--reps 14]"""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package
+load_package()
+from comfyui_vrgamedevgirl_amd import nodes, _devices, VRGDG_IV_Adjustments as iv
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--reps", type=int, default=14)
+a = ap.parse_args()
+g = torch.Generator().manual_seed(3)
+x = torch.rand((a.frames, 2160, 3840, 3), generator=g)
+ref = x[:1].clone()
+calls = [("grain", lambda t: nodes.FastFilmGrain().apply_grain(t, 0.04, 0.5, 4)[0]),
+         ("lut", lambda t: iv.VRGDG_LUTS().apply_lut(t, "AMD_TealOrange_33.cube", "auto", 10.0)[0]),
+         ("match", lambda t: nodes.ColorMatchToReference().match_color(t, ref, 1.0, 1)[0]),
+         ("unsharp", lambda t: nodes.FastUnsharpSharpen().apply_unsharp(t, 0.5, False)[0])]
+for rep in range(a.reps):
+    t = x
+    marks = []
+    t0 = time.perf_counter()
+    for name, fn in calls:
+        s = time.perf_counter()
+        t = fn(t)
+        marks.append((name, time.perf_counter() - s))
+    s = time.perf_counter()
+    _devices.materialise(t)
+    marks.append(("download", time.perf_counter() - s))
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    del t
+    print(f"[diag] rep {rep}: total {total * 1e3:7.1f} ms  " + "  ".join(f"{n} {d * 1e3:6.1f}" for n, d in marks), flush=True)
