@@ -590,9 +590,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? MARCH_MIN_WAVES : 1) void 
                 {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 0);
+                    // (aux 2 = nt on loads and stores: the two 25 GB frame streams bypass the L1 and do not displace the LUT's 1.6 MB from the XCD's L2:
+                    //  chain 3 -2.6 % uniform, -4.6 % video-like; stores alone -2.4 / -3.3 %; sc1 or sc1 nt stores +1.5...2.5 % -- profiles/r05_ab_march_store_policy.json)
+                    for (int m = 0; m < 4; ++m) xraw[m] = __builtin_amdgcn_raw_buffer_load_b96(rs_in, ld_voff[m], (rowbase + E) * 4, 2);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b96(resq[m], rs_out, st_voff[m], out_soff, 0);
+                    for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b96(resq[m], rs_out, st_voff[m], out_soff, 2);
                     // a 96-bit store reads its data registers over several cycles; the backend pads the next VALU write of those
                     // registers only for stores WITHOUT an SGPR offset (GCNHazardRecognizer::createsVALUHazard) -- with one, as here, the
                     // R channel of the upper lanes of a 16-lane row came out as the NEXT row's value in builds whose schedule put a VALU
