@@ -358,13 +358,17 @@ ALGO_BPP = {"stats": 12, "apply": 24, "tstats": 12}         # SURVEY.md section 
 
 
 def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_stats=None, verify=True, digest=False, fast_variant=False,
-                 time_reference_stats=False):
+                 time_reference_stats=False, cube_name=None):
     """One leg: `frames` synthetic frames of `workload` resident in HBM on every rank, `warmup` untimed + `steps` timed steps bracketed
     by barrier + synchronize, MAX over ranks.  Returns the measurements and frees its buffers."""
     ops, sharding, dist = C.ops, C.sharding, C.dist
     rank, world, dev = C.rank, C.world, C.dev
     H, W, stages = WORKLOADS[workload]
     chunk = 4
+    lut, lut_cpu = C.lut, C.lut_cpu
+    if cube_name is not None:             # a leg with another cube size (25^3: 8 of the reference's 12 cubes; 17^3: the table lives in LDS)
+        lut_cpu = C.cube.parse_cube_file(os.path.join(C.luts_dir, cube_name))
+        lut = ops.upload_lut(lut_cpu, dev)
     x = make_frames(frames, H, W, dev, 1234 + (0 if args.same_data else rank), pixel_dist, first_frame=rank * frames if args.same_data else None)
     out = torch.empty_like(x)
     lab_ws = torch.empty_like(x) if "colormatch" in stages else None      # Lab image between the two colour-match passes
@@ -401,7 +405,7 @@ def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_sta
         if geom_stream is not None:
             plans = (ops.NoisePlan(chunk, geom_stream, chunk0=rank * (frames // chunk)), None, frames // chunk)
         spec = ops.ChainSpec(grain=(0.04, 0.5, chunk) if "grain" in stages else None,
-                             lut=(C.lut, 10.0) if "lut" in stages else None,
+                             lut=(lut, 10.0) if "lut" in stages else None,
                              colormatch=(ref_ms, 1.0) if "colormatch" in stages else None,
                              sharpen=("unsharp", 0.5, False) if "sharpen" in stages else None, cm_math=cm_math, cm_chunk=CM_BATCH,
                              cm_ref_event=ref_ev, cm_stats=(cm_stats if cm_math is None else None))
@@ -433,13 +437,13 @@ def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_sta
         return el, per_rank, ev
 
     elapsed, per_rank_ms, events = timed()
-    R = {"workload": workload, "dist": pixel_dist, "frames": frames, "H": H, "W": W, "stages": stages, "chunk": chunk, "steps": steps, "warmup": warmup,
+    R = {"workload": workload, "dist": pixel_dist, "cube": cube_name, "frames": frames, "H": H, "W": W, "stages": stages, "chunk": chunk, "steps": steps, "warmup": warmup,
          "elapsed": elapsed, "per_rank_ms": per_rank_ms, "px_rank": frames * H * W, "cm_stats": cm_stats}
     # the timed steps' own output, checked and fingerprinted BEFORE anything else overwrites it (never inside the timed region)
     R["verify"] = None
     if rank == 0 and verify:
         try:
-            R["verify"] = verify_output(ops, x, out, ref, C.lut, C.lut_cpu, stages, geom_stream, rank, frames, chunk, dev, cm_stats)
+            R["verify"] = verify_output(ops, x, out, ref, lut, lut_cpu, stages, geom_stream, rank, frames, chunk, dev, cm_stats)
         except Exception as exc:              # a checker problem must not lose the measurement; it is reported as unverified
             R["verify"] = {"verified": False, "error": f"{type(exc).__name__}: {exc}"}
     R["digests"] = None
@@ -561,6 +565,7 @@ def main():
     C.dev = dev = torch.device("cuda", torch.cuda.current_device())
     C.lut_cpu = lut_cpu = cube.parse_cube_file(os.path.join(iv.LUTS_DIR, "AMD_TealOrange_33.cube"))
     C.lut = ops.upload_lut(lut_cpu, dev)
+    C.cube, C.luts_dir = cube, iv.LUTS_DIR
     H, W, stages = WORKLOADS[args.workload]
     default_frames = {"grain_lut_1080p": 128, "colormatch_4k": 512}
     frames = args.frames or default_frames.get(args.workload, 256)      # BASELINE.json configs[1..4]
@@ -698,19 +703,27 @@ def main():
         n1080 = 128 if args.frames is None else args.frames          # BASELINE's frame counts unless --frames shrinks the run
         legs = [("chain4_4k", "video", frames), ("chain3_4k", "uniform", frames), ("chain3_4k", "video", frames),
                 ("grain_lut_1080p", "uniform", n1080), ("grain_lut_1080p", "video", n1080), ("colormatch_4k", "uniform", 2 * frames)]
+        # chain 3 with the other cube sizes of the field: 25^3 (8 of the reference's 12 shipped cubes) and 17^3 (node table staged in LDS)
+        legs += [("chain3_4k", "uniform", frames, "AMD_WarmFilm_25.cube"), ("chain3_4k", "video", frames, "AMD_WarmFilm_25.cube"),
+                 ("chain3_4k", "uniform", frames, "AMD_Identity_17.cube")]
         cfgs = {"headline": leg_summary(M, world, pmc, pmc_src)}
-        for wl, pd, nf in legs:
+        for wl, pd, nf, *cb in legs:
+            key = f"{wl}.{pd}" + (f".{cb[0].split('_')[-1].split('.')[0]}cube" if cb else "")
             try:
                 # (a 1080p step is 3 ms: one host hiccup inside five of them shows -- those legs take four times the steps)
-                L = run_workload(C, args, wl, pd, nf, max(args.steps // 2, 3) * (4 if WORKLOADS[wl][0] <= 1080 else 1), 3, verify=not args.no_verify)
-                cfgs[f"{wl}.{pd}"] = leg_summary(L, world, pmc, pmc_src)
+                L = run_workload(C, args, wl, pd, nf, max(args.steps // 2, 3) * (4 if WORKLOADS[wl][0] <= 1080 else 1), 3, verify=not args.no_verify,
+                                 cube_name=cb[0] if cb else None)
+                cfgs[key] = leg_summary(L, world, pmc if not cb else {}, pmc_src)        # (the PMC passes ran the 33^3 cube)
+                if cb:
+                    cfgs[key]["cube"] = cb[0]
             except Exception as exc:
-                cfgs[f"{wl}.{pd}"] = {"error": f"{type(exc).__name__}: {exc}"}
+                cfgs[key] = {"error": f"{type(exc).__name__}: {exc}"}
         cfgs["note"] = ("BASELINE.json configs[1] = grain_lut_1080p (128 frames), configs[2] = chain3_4k (256 frames; the pass north_star's >= 60 % target "
                         "names), configs[3] = colormatch_4k (512 frames), configs[4] per-GPU shard = headline; `pixels` uniform = iid U[0,1) (worst case "
                         "for the LUT gathers), video = smooth field + N(0, 0.02) texture (SURVEY.md section 8d, D2 / D1).  hbm_frac = Mpix_s x "
                         "algorithmic_bytes_per_pixel / 8 TB/s; valu_busy_frac of the dominant kernel as in `roofline`; `verified` = first and last RNG "
-                        "chunk against the stand-alone operators and the oracle after the timed steps")
+                        "chunk against the stand-alone operators and the oracle after the timed steps; the `...25cube` / `...17cube` legs run chain 3 with this pack's "
+                        "25^3 and 17^3 cubes (the default legs: AMD_TealOrange_33.cube)")
         line["configs"] = cfgs
     if rank == 0:
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":

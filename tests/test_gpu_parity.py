@@ -2299,7 +2299,7 @@ def test_bench_verifies_its_own_output(dev):
     # the other single-GPU BASELINE configs ride along as legs of the same run, each checked against the oracle after its timed steps
     cfgs = line["configs"]
     for key in ("headline", "chain4_4k.video", "chain3_4k.uniform", "chain3_4k.video", "grain_lut_1080p.uniform", "grain_lut_1080p.video",
-                "colormatch_4k.uniform"):
+                "colormatch_4k.uniform", "chain3_4k.uniform.25cube", "chain3_4k.video.25cube", "chain3_4k.uniform.17cube"):
         leg = cfgs[key]
         assert "error" not in leg, (key, leg)
         assert leg["verified"] is True and leg["Mpix_s"] > 0 and leg["ms_per_step"] > 0 and 0 < leg["hbm_frac"] < 1, (key, leg)
