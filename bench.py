@@ -732,7 +732,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import host_fed
                 torch.cuda.empty_cache()
-                line["host_fed"] = host_fed.measure(frames=8, reps=5)
+                line["host_fed"] = host_fed.measure(frames=8, reps=5, warmup=4)       # (torch's host / device pools of this process settle after 3 calls per row)
             except Exception as exc:
                 line["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def measure(frames=16, H=2160, W=3840, reps=3):
+def measure(frames=16, H=2160, W=3840, reps=3, warmup=2):
     """Wall-clock seconds per call: two warm-up calls per case, then `reps` (>= 3) ROUNDS in which every case runs once -- the cases are
     interleaved so that a slow phase of the box hits all of them --, and the MEDIAN over the rounds with the spread (max - min) beside
     it.  (Round 3 reported the minimum of ONE repetition per case: page-locked input once came out slower than pageable.)"""
@@ -56,7 +56,7 @@ def measure(frames=16, H=2160, W=3840, reps=3):
                  lambda: chain(x)))
     runs.append(("grain -> LUT -> colour match -> unsharp, four node calls, every result downloaded at once (VRGDG_LAZY_DOWNLOAD=0: 1 upload + 4 downloads)",
                  "pageable input", lambda: chain_eager(x)))
-    for _ in range(2):             # warm-up, twice: the first call page-locks the result buffers, the second still grows torch's device pool
+    for _ in range(max(1, int(warmup))):             # warm-up, at least twice: the first call page-locks the result buffers, the second still grows torch's device pool
         for _, _, fn in runs:      # (tools/diag_lazy_graph.py: calls 1 and 2 of the graph take 880 / 210 ms, every later one 76.5-77.8)
             once(fn)
     times = [[] for _ in runs]
@@ -71,7 +71,7 @@ def measure(frames=16, H=2160, W=3840, reps=3):
         if not name.startswith("grain ->"):
             row["GB_s_each_way"] = round(nbytes / t / 1e9, 2)
         rows.append(row)
-    return {"frames": frames, "height": H, "width": W, "devices": os.environ.get("VRGDG_DEVICES", "") or "one", "timing": f"median of {reps} interleaved rounds",
+    return {"frames": frames, "height": H, "width": W, "devices": os.environ.get("VRGDG_DEVICES", "") or "one", "timing": f"median of {reps} interleaved rounds after {max(1, int(warmup))} warm-up rounds",
             "rows": rows}
 
 
