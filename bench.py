@@ -144,7 +144,7 @@ PASS_KERNELS = {
     ("chain4_4k", "apply"): ("k_apply_march<",),
     ("chain4_4k", "tstats"): ("k_tstats_frame<false, 1>",),
     ("chain3_4k", "apply"): ("k_chain_march<3, true",),
-    ("grain_lut_1080p", "apply"): ("k_chain_pointwise<3",),
+    ("grain_lut_1080p", "apply"): ("k_chain_march<3, false", "k_chain_pointwise<3"),      # (the march from ~10,000 strip jobs on: csrc/vrg_chain.hip)
     ("colormatch_4k", "stats"): ("k_lab_partials<0, true>",),
     ("colormatch_4k", "apply"): ("k_chain_pointwise4<20",),
     ("colormatch_4k", "tstats"): ("k_tstats_frame<false, 1>",),
@@ -351,6 +351,8 @@ def _kernel_name(stages, which):
         return "k_apply_march<COLORMATCH|FROM_LAB> (match -> Lab->RGB -> 3x3 sharpen, register-resident wave march)"
     if "sharpen" in stages and "grain" in stages:
         return "k_chain_march (fused grain -> LUT -> sharpen, register-resident wave march)"
+    if "grain" in stages and "lut" in stages:
+        return "k_chain_march without a stencil (large launches) / k_chain_pointwise (fused grain -> LUT)"
     return "k_chain_tile / k_chain_pointwise (fused apply pass)"
 
 

@@ -529,6 +529,18 @@ int vrg_fused_chain_f32(const float* in, float* out, int64_t frames, int32_t hei
         if ((desc->stages & VRG_STAGE_LUT) && !(desc->stages & VRG_STAGE_COLORMATCH) && desc->stages != VRG_STAGE_LUT &&
             lut_lds_applicable(desc->lut_size, frames * (int64_t)height * width) && frames * (int64_t)height * width >= 24000000ll)   // enough strips for 12-wave workgroups on every CU
             variant = 2;
+        // grain -> LUT over a global table (no stencil): since the march's pixel rows are non-temporal accesses (round 5) its steady-row body
+        // beats the point-wise kernel -- one Philox call per four elements instead of one per element, quad-cooperative gathers -- once the
+        // launch holds a few rounds of waves: 128 x 1080p 78 / 95 against 76 / 89 Gpix/s (uniform / video-like), 64 x 4K 83 / 100 against 76 /
+        // 89, with a 25^3 cube 82 / 111 against 77 / 91; below ~10,000 strip jobs (3 waves per slot of the chip) it loses: 96 x 720p 59
+        // against 75, 8 x 1080p 48 against 67 (profiles/r05_bench_flat_march.json, r05_bench_flat_march_sizes.json)
+        if (variant == 1 && desc->stages == (VRG_STAGE_GRAIN | VRG_STAGE_LUT) && desc->noise.chunk_frames > 0 && desc->noise.grid_threads > 0 &&
+            frames % desc->noise.chunk_frames == 0) {
+            const int64_t chunk_elems = (int64_t)desc->noise.chunk_frames * height * width * 3;
+            const int64_t four_g = 4ll * desc->noise.grid_threads;
+            const int64_t jobs = (frames / desc->noise.chunk_frames) * ((chunk_elems + four_g - 1) / four_g) * ((width + 62) / 63);
+            if (jobs >= 10000) variant = 2;
+        }
     }
     if (variant == 2) {
         // the march kernel has no colour-match stage and addresses a chunk with 32-bit element offsets (<= 0x60000000

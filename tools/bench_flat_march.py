@@ -10,15 +10,19 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--json", default="")
+ap.add_argument("--sizes", default="128x1080x1920,64x2160x3840,8x1080x1920", help="FxHxW,...")
+ap.add_argument("--cubes", default="33,25,17")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 luts = {n: ops.upload_lut(cube.parse_cube_file(os.path.join(iv.LUTS_DIR, f)), dev) for n, f in ((33, "AMD_TealOrange_33.cube"), (25, "AMD_WarmFilm_25.cube"), (17, "AMD_Identity_17.cube"))}
 rows = []
-for (F, H, W) in ((128, 1080, 1920), (64, 2160, 3840), (8, 1080, 1920)):
+for (F, H, W) in [tuple(int(v) for v in z.split("x")) for z in a.sizes.split(",")]:
     for dist in ("uniform", "video"):
         x = bench.make_frames(F, H, W, dev, 1234, dist)
         px = F * H * W
         for n, lut in luts.items():
+            if str(n) not in a.cubes.split(","):
+                continue
             for bs in (4,):
                 outs, ts = {}, {}
                 for rnd in range(a.rounds + 1):
