@@ -310,7 +310,8 @@ def release_device_copies() -> int:
 # ------------------------------------------------------------------------------------------------------------
 # Lazy download.  With the device copy kept (above) the upload of the next node is gone; its own DOWNLOAD is not: grain -> LUT ->
 # colour match -> unsharp still crosses PCIe four times for results nobody reads on the host.  So a node's result is handed to ComfyUI
-# as `LazyFrames`: a CPU torch.Tensor (subclass) over page-locked storage whose download has NOT been queued yet.
+# as `LazyFrames`: a CPU torch.Tensor (subclass) over page-locked storage whose download has not been waited for -- and, where the frames
+# were already in HBM, not even queued.
 #   * The next node of this pack takes the frames from HBM (the pending pieces) and never touches the host buffer.
 #   * ANY other use -- a torch function or Tensor method that can see data (`.numpy()`, `.cpu()`, `.to()`, indexing, iteration, `torch.cat`,
 #     `data_ptr()`, `untyped_storage()`, pickling, `__array__`, DLPack, printing) -- goes through `__torch_function__`, which first
@@ -495,6 +496,21 @@ def pending_of(t):
         if p is not None and not p.done:
             return p
     return None
+
+
+def on_device(t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    """`t` on `device` (fp32 frames): the pending device pieces of a LazyFrames of that device as they are (no download, no upload),
+    anything else through `.to()`."""
+    p = pending_of(t)
+    if p is not None and p.device == device and t.dtype == torch.float32:
+        cur = torch.cuda.current_stream(device)
+        parts = []
+        for _s, _e, gpu, ran in p.pieces:
+            cur.wait_event(ran)
+            parts.append(gpu)
+        _LAZY.downloads_skipped += 1
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    return t.to(device=device, dtype=torch.float32)
 
 
 def materialise(t):

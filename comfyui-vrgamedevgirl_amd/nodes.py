@@ -11,7 +11,7 @@ from typing import Tuple
 import torch
 
 from . import ops
-from ._devices import compute_device, frame_groups, intermediate_device, stream_frames
+from ._devices import compute_device, frame_groups, intermediate_device, on_device, stream_frames
 
 _IMAGE = ("IMAGE",)
 
@@ -111,7 +111,7 @@ class ColorMatchToReference:
 
     def match_color(self, images, reference_image, match_strength, batch_size):
         dev = compute_device()
-        ref = reference_image.to(device=dev, dtype=torch.float32)
+        ref = on_device(reference_image, dev)            # (a result of this pack that is still in HBM is used where it is)
         n_ref = int(ref.shape[0])
         frames = int(images.shape[0])
         expand = None

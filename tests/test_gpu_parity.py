@@ -1667,6 +1667,13 @@ def test_lazy_download_four_nodes_in_a_graph_cross_pcie_twice(pkg, ops, dev, mon
     got = graph(x)
     assert torch.equal(got[3][2:4], want[3][2:4]) and torch.equal(torch.cat([got[2], got[2]])[6:], want[2])
     assert torch.equal(got[1].to(dev).cpu(), want[1]) and torch.equal(got[0].permute(0, 3, 1, 2), want[0].permute(0, 3, 1, 2))
+    # a pending result as the REFERENCE image of a colour match: read where it is
+    lz = nodes.FastUnsharpSharpen().apply_unsharp(x[:1], 0.4, False)[0]
+    assert _devices.pending_of(lz) is not None
+    with_lazy_ref = nodes.ColorMatchToReference().match_color(x, lz, 0.7, 2)[0]
+    assert _devices.pending_of(lz) is not None
+    plain_ref = nodes.FastUnsharpSharpen().apply_unsharp(x[:1].clone(), 0.4, False)[0].clone()
+    assert torch.equal(with_lazy_ref, nodes.ColorMatchToReference().match_color(x, plain_ref, 0.7, 2)[0])
     # nobody reads it: the timer downloads it, after which it sits in the device-copy cache
     monkeypatch.setattr(_devices, "LAZY_SECONDS", 0.2)
     torch.manual_seed(11)
