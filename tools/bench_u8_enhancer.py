@@ -13,9 +13,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=8)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--json", default="")
+ap.add_argument("--size", default="2160x3840", help="HxW (round 5: any -- 768x1366, 480x854, 1080x1918 ... run k_sharpen_grain_u8_any)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-F, H, W = a.frames, 2160, 3840
+F = a.frames
+H, W = (int(v) for v in a.size.split("x"))
 px = F * H * W
 g = torch.Generator().manual_seed(11)
 host = torch.randint(0, 256, (F, H, W, 3), generator=g, dtype=torch.uint8)
@@ -73,7 +75,7 @@ a0 = np.stack(loop_old()); a1 = np.stack(loop_new())
 rows = []
 for (name, _, _), v in zip(cases, ts):
     med = statistics.median(v)
-    rows.append({"case": name, "frames": F, "ms_median": round(med, 4), "ms_min": round(min(v), 4), "ms_max": round(max(v), 4),
+    rows.append({"case": name, "frames": F, "size": a.size, "ms_median": round(med, 4), "ms_min": round(min(v), 4), "ms_max": round(max(v), 4),
                  "spread_pct": round(100 * (max(v) - min(v)) / med, 2), "Mpix_s": round(px / med / 1e3, 1)})
     print("[u8]", rows[-1], flush=True)
 res = {"rows": rows, "speedup_device": round(rows[0]["ms_median"] / rows[1]["ms_median"], 3), "speedup_host_fed": round(rows[2]["ms_median"] / rows[3]["ms_median"], 3),
