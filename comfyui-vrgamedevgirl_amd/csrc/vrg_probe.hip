@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void k_dbg_copy(const f32x4* __restrict__ in, 
 // nothing else in the loop but the counter.  The measured lane-instructions per second are the VALU roofline the fused
 // chains are priced against in DESIGN.md (they are issue bound, not HBM bound).
 #define VRG_REP8(X) X X X X X X X X
+#define VRG_REP4(X) X X X X
 template <int MODE>
 __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, int32_t iters) {
     float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1.0f, a2 = a0 + 2.0f, a3 = a0 + 3.0f, a4 = a0 + 4.0f, a5 = a0 + 5.0f, a6 = a0 + 6.0f,
@@ -410,10 +411,55 @@ __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, 
             VRG_REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cmp_lt_f32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %9, vcc\n"
                                   "v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %9, vcc\n v_cmp_lt_f32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %9, vcc"
                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c) : "vcc");)
-        } else {
+        } else if (MODE == 7) {
             VRG_REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
                                   "v_fma_f64 %0, %0, %4, %0\n v_fma_f64 %1, %1, %4, %1\n v_fma_f64 %2, %2, %4, %2\n v_fma_f64 %3, %3, %4, %3"
                                   : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "v"(w4));)
+        } else if (MODE == 8) {
+            VRG_REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 9) {
+            VRG_REP8(asm volatile("v_add_f32_dpp %0, %8, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %1, %8, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %2, %8, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %3, %8, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %4, %8, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %5, %8, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %6, %8, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %7, %8, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 10) {
+            VRG_REP8(asm volatile("v_add_f32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %1, %8, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %2, %8, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %3, %8, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %4, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %5, %8, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %6, %8, %6 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %7, %8, %7 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 11) {
+            VRG_REP8(asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 12) {
+            VRG_REP8(asm volatile("v_cndmask_b32 %0, %0, %9, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %9, vcc\n v_cndmask_b32 %3, %3, %9, vcc\n v_cndmask_b32 %4, %4, %9, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %9, vcc\n v_cndmask_b32 %7, %7, %9, vcc"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 13) {
+            VRG_REP8(asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 14) {
+            VRG_REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 15) {
+            VRG_REP8(asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3\n v_cvt_f32_u32 %4, %4\n v_cvt_f32_u32 %5, %5\n v_cvt_f32_u32 %6, %6\n v_cvt_f32_u32 %7, %7"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k) : "vcc");)
+        } else if (MODE == 16) {
+            VRG_REP8(asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k) : "vcc");)
+        } else if (MODE == 17) {
+            VRG_REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k) : "vcc");)
+        } else if (MODE == 18) {
+            VRG_REP8(asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n s_nop 1\n"
+                                  "v_add_f32_dpp %0, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %1, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+                                  "v_add_f32_dpp %2, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_f32_dpp %3, %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));)
+        } else if (MODE == 19) {
+            VRG_REP8(asm volatile("v_sin_f32 %0, %0\n v_sin_f32 %1, %1\n v_sin_f32 %2, %2\n v_sin_f32 %3, %3\n v_sin_f32 %4, %4\n v_sin_f32 %5, %5\n v_sin_f32 %6, %6\n v_sin_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 20) {
+            VRG_REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                                  "v_pk_add_f32 %4, %4, %9\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %9\n v_pk_add_f32 %7, %7, %9"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 21) {
+            VRG_REP4(asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n v_mul_f32 %1, %1, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %2, %2, %9\n v_mul_f32 %3, %3, %8\n v_add_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_add_f32 %4, %4, %9\n v_mul_f32 %5, %5, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %6, %6, %9\n v_mul_f32 %7, %7, %8\n v_add_f32 %7, %7, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) +
@@ -425,18 +471,15 @@ __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, 
 extern "C" {
 
 int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream) {
-    if (!out || blocks <= 0 || iters <= 0 || mode < 0 || mode > 7) return VRG_ERR_BAD_ARG;
+    if (!out || blocks <= 0 || iters <= 0 || mode < 0 || mode > 21) return VRG_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+#define VRG_VALU_CASE(M) case M: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<M>, dim3(blocks), dim3(256), 0, st, out, iters); break;
     switch (mode) {
-        case 0: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 1: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 2: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 3: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 4: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 5: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<5>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        case 6: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<6>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-        default: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<7>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+        VRG_VALU_CASE(0) VRG_VALU_CASE(1) VRG_VALU_CASE(2) VRG_VALU_CASE(3) VRG_VALU_CASE(4) VRG_VALU_CASE(5) VRG_VALU_CASE(6) VRG_VALU_CASE(7)
+        VRG_VALU_CASE(8) VRG_VALU_CASE(9) VRG_VALU_CASE(10) VRG_VALU_CASE(11) VRG_VALU_CASE(12) VRG_VALU_CASE(13) VRG_VALU_CASE(14)
+        VRG_VALU_CASE(15) VRG_VALU_CASE(16) VRG_VALU_CASE(17) VRG_VALU_CASE(18) VRG_VALU_CASE(19) VRG_VALU_CASE(20) VRG_VALU_CASE(21)
     }
+#undef VRG_VALU_CASE
     VRG_CHECK_LAUNCH();
     return VRG_OK;
 }

@@ -54,7 +54,10 @@ int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32
 int vrg_debug_lut_fetch(const float* in, float* out, int64_t pixels, const float* cells, int32_t lut_size, int32_t mode, void* stream);
 /* Issue-rate probe (tools/gpu_diag.py --valu): `blocks` x 256 threads each issue iters x 64 instructions of one kind
  * (mode 0 v_fma_f32, 1 v_mad_u64_u32, 2 v_log_f32, 3 v_pk_fma_f32, 4 v_xor_b32, 5 sqrt/sin/cos/rcp mix,
- * 6 v_cmp+v_cndmask pairs, 7 v_mul_f64/v_fma_f64); `out` = blocks*256 floats.  Measures the VALU roofline. */
+ * 6 v_cmp+v_cndmask pairs, 7 v_mul_f64/v_fma_f64; round 6, the instruction classes of the march's row step: 8 v_add_f32, 9 v_add_f32_dpp
+ * wave_shr:1, 10 v_add_f32_dpp row_shr:1, 11 v_mov_b32_dpp quad_perm, 12 v_cndmask_b32, 13 v_max_f32, 14 v_mul_f32, 15 v_cvt_f32_u32,
+ * 16 v_mul_hi_u32, 17 v_mul_lo_u32, 18 v_add_f32 -> s_nop 1 -> v_add_f32_dpp of its result (the padded hazard), 19 v_sin_f32,
+ * 20 v_pk_mul_f32 / v_pk_add_f32, 21 dependent v_mul_f32 -> v_add_f32 pairs in 8 chains); `out` = blocks*256 floats.  Measures the VALU roofline. */
 int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream);
 /* Streaming-copy ceiling: out[i] = in[i] over n_floats fp32 values (a multiple of 4; 16-byte aligned
  * pointers), 16 B per lane.  mode 0: plain loads / stores; 1: non-temporal; 2: non-temporal, four float4 per thread; 3: read only;
