@@ -1,6 +1,9 @@
 """ctypes binding of libvrgdg_hip.so (the C ABI declared in include/vrgdg_hip.h).
 
 There is NO CPU fallback: if the library is missing, or no HIP device is visible, every op raises.
+
+The self-tests and probes of include/vrgdg_hip_debug.h live in a second library, libvrgdg_hip_debug.so, that nothing of the product loads:
+it is opened the first time a test or a tool asks the handle for one of its names (`lib().vrg_debug_...`).
 """
 from __future__ import annotations
 
@@ -10,6 +13,7 @@ import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRGDG_HIP_LIB") or os.path.join(PKG_DIR, "libvrgdg_hip.so")   # override: A/B builds (tools/build_variant.py, tools/ab_interleaved.py)
+DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip_debug.so")
 
 VRG_OK = 0
 VRG_ERR_BAD_ARG = 1
@@ -19,7 +23,7 @@ STENCIL_UNSHARP, STENCIL_LAPLACIAN, STENCIL_SOBEL = 0, 1, 2
 STAGE_GRAIN, STAGE_LUT, STAGE_COLORMATCH, STAGE_SHARPEN, STAGE_FROM_LAB = 1, 2, 4, 8, 16
 CM_MATH_DEVICE, CM_MATH_FAST = 0, 1
 ADJUST_DIV_IEEE, ADJUST_DIV_DEVICE = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class NoiseDesc(C.Structure):
@@ -101,6 +105,8 @@ _SIGNATURES = {
     "vrg_chain_stats_f32": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
     "vrg_chain_stats_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc)]),
     "vrg_chain_stats_lab_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.POINTER(ChainDesc), _P, _P, _P]),
+    "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
+    "vrg_selfcheck_pow_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
 }
 
 # include/vrgdg_hip_debug.h: self-tests and probes -- for the test suite and the measurement tools, not part of the drop-in boundary
@@ -114,7 +120,6 @@ _DEBUG_SIGNATURES = {
     "vrg_debug_lut_fetch": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "vrg_debug_copy_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "vrg_debug_valu_rate": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
-    "vrg_noise_f32": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(NoiseDesc), _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -124,7 +129,39 @@ _lib = None
 _lock = threading.Lock()
 
 
-def load_library(path: str = LIB_PATH) -> C.CDLL:
+class Library:
+    """Handle of the loaded product library.  Attribute access resolves the names of include/vrgdg_hip.h in libvrgdg_hip.so; a name of
+    include/vrgdg_hip_debug.h -- and only such a name -- opens libvrgdg_hip_debug.so (once) and resolves there, so that tests and tools keep
+    writing `lib().vrg_debug_...` while no node ever touches the debug library."""
+
+    def __init__(self, cdll: C.CDLL, path: str, debug_path: str = DEBUG_LIB_PATH):
+        self.__dict__["_cdll"] = cdll
+        self.__dict__["_path"] = path
+        self.__dict__["_debug_path"] = debug_path
+        self.__dict__["_debug"] = None
+
+    def debug(self) -> C.CDLL:
+        if self._debug is None:
+            with _lock:
+                if self._debug is None:
+                    if not os.path.exists(self._debug_path):
+                        raise RuntimeError(f"libvrgdg_hip_debug.so not found at {self._debug_path} (self-tests / probes: build it with "
+                                           f"`python {os.path.join(PKG_DIR, 'build_ext.py')}`)")
+                    dbg = C.CDLL(self._debug_path)
+                    for name, (res, args) in _DEBUG_SIGNATURES.items():
+                        fn = getattr(dbg, name)   # AttributeError if the debug ABI drifted
+                        fn.restype = res
+                        fn.argtypes = args
+                    self.__dict__["_debug"] = dbg
+        return self._debug
+
+    def __getattr__(self, name):
+        if name in _DEBUG_SIGNATURES:
+            return getattr(self.debug(), name)
+        return getattr(self._cdll, name)
+
+
+def load_library(path: str = LIB_PATH) -> Library:
     """dlopen the library and attach the prototypes (no device needed)."""
     import torch  # noqa: F401  -- FIRST: the HIP runtime must be the one torch loaded (same soname, shared streams/pointers)
     if not os.path.exists(path):
@@ -132,16 +169,16 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
             f"libvrgdg_hip.so not found at {path}: build it with `python {os.path.join(PKG_DIR, 'build_ext.py')}` "
             "(hipcc, gfx950). This package has no CPU fallback.")
     lib = C.CDLL(path)
-    for name, (res, args) in list(_SIGNATURES.items()) + list(_DEBUG_SIGNATURES.items()):
+    for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
     if lib.vrg_abi_version() != ABI_VERSION:
         raise RuntimeError("libvrgdg_hip.so ABI version mismatch")
-    return lib
+    return Library(lib, path)
 
 
-def lib() -> C.CDLL:
+def lib() -> Library:
     """The loaded library, for launching kernels: also requires a visible HIP device."""
     global _lib
     if _lib is None:

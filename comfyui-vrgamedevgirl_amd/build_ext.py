@@ -1,10 +1,11 @@
-"""Build libvrgdg_hip.so (hipcc, gfx950 only) in-tree.
+"""Build libvrgdg_hip.so -- the product: the C ABI of include/vrgdg_hip.h -- and libvrgdg_hip_debug.so -- the self-tests and probes of
+include/vrgdg_hip_debug.h, for the test suite and the measurement tools only -- in-tree (hipcc, gfx950 only).
 
     python comfyui-vrgamedevgirl_amd/build_ext.py [--force]
 
-hipcc cross-compiles without a GPU.  The library has no torch dependency: it is a plain C-ABI shared
-object (include/vrgdg_hip.h) that links against the HIP runtime by soname, so inside a torch process it
-binds to the runtime torch already loaded.
+hipcc cross-compiles without a GPU.  The libraries have no torch dependency: plain C-ABI shared objects that link against the HIP runtime
+by soname, so inside a torch process they bind to the runtime torch already loaded.  Nothing the nodes call lives in the debug library
+(round 6: csrc/vrg_probe.hip left the product).
 """
 from __future__ import annotations
 
@@ -18,12 +19,14 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip.so")
+DEBUG_LIB_PATH = os.path.join(PKG_DIR, "libvrgdg_hip_debug.so")
 STAMP = LIB_PATH + ".stamp"
 
 SOURCES = ("vrg_pointwise.hip", "vrg_stencil.hip", "vrg_chain.hip", "vrg_march.hip", "vrg_produce.hip", "vrg_apply_march.hip", "vrg_adjust.hip",
-           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip", "vrg_probe.hip", "vrg_host.hip")
+           "vrg_collective.hip", "vrg_lut_tetra.hip", "vrg_torch_stats.hip", "vrg_api.hip", "vrg_host.hip")
+DEBUG_SOURCES = ("vrg_probe.hip",)
 HEADERS = ("vrg_common.hpp", "vrg_pixel_math.hpp", "vrg_chain_stages.hpp", "vrg_adjust_math.hpp", "vrg_pow_tables.inc",
-           "vrg_ziv_log_table.inc", "vrg_produce_body.hpp", "vrg_apply_body.hpp", "vrg_tstats_body.hpp")
+           "vrg_ziv_log_table.inc", "vrg_produce_body.hpp", "vrg_apply_body.hpp", "vrg_tstats_body.hpp", "vrg_lanes.hpp", "vrg_tstats_config.hpp")
 
 # -ffp-contract=off : the reference performs one rounding per op; FMAs are written explicitly where
 #                     torch's own device code has them (Box-Muller).
@@ -55,7 +58,7 @@ def _hipcc() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    for name in SOURCES + HEADERS:
+    for name in SOURCES + DEBUG_SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
     for name in ("vrgdg_hip.h", "vrgdg_hip_debug.h"):
@@ -79,9 +82,9 @@ def _object_digest(name: str) -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every translation unit to an object (in parallel, cached by content digest under csrc/.obj) and link."""
+    """Compile every translation unit to an object (in parallel, cached by content digest under csrc/.obj) and link the two libraries."""
     want = _digest()
-    if not force and os.path.exists(LIB_PATH) and os.path.exists(STAMP):
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(DEBUG_LIB_PATH) and os.path.exists(STAMP):
         with open(STAMP) as fh:
             if fh.read().strip() == want:
                 return LIB_PATH
@@ -107,12 +110,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             fh.write(dig)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs + ["-ldl", "-pthread"]      # vrg_collective.hip: dlopen / dlsym (RCCL at run time)
-    if verbose:
-        print("[vrgdg-amd] linking:", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES) + len(DEBUG_SOURCES), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES + DEBUG_SOURCES))
+    for lib, group in ((LIB_PATH, objs[:len(SOURCES)]), (DEBUG_LIB_PATH, objs[len(SOURCES):])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib] + group + ["-ldl", "-pthread"]      # vrg_collective.hip: dlopen / dlsym (RCCL at run time)
+        if verbose:
+            print("[vrgdg-amd] linking:", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     with open(STAMP, "w") as fh:
         fh.write(want)
     return LIB_PATH

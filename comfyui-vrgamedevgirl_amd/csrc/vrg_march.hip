@@ -20,6 +20,7 @@
 //
 // Without a grain stage the same kernel runs with a synthetic G = 48 rows (siblings = four row bands).
 #include "vrg_chain_stages.hpp"
+#include "vrg_lanes.hpp"
 
 // The variants this kernel was chosen from (round 3's general row step for every row, per-lane gathers, loads / stores at the head of the
 // row, rotated noise synthesis, timing ablations with wrong pixels, ...) are NOT compile-time switches of the product source: the
@@ -43,31 +44,8 @@ struct MarchK {
     int64_t elems_after;
 };
 
-__device__ __forceinline__ float lane_prev(float v) {   // value held by lane-1
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_next(float v) {   // value held by lane+1
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
-
-// the same shifts for operands of an add (steady rows): no `old` value and bound_ctrl, so that the backend can fold the shift into
-// the add's first operand (v_add_f32_dpp) -- the lane at the wave's end reads 0.0, and it is a halo lane whose result is dropped
-__device__ __forceinline__ float tap_prev(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float tap_next(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
-}
-
 __device__ __forceinline__ int64_t floor_div64(int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 __device__ __forceinline__ int floor_div32(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-
-// lane_prev/lane_next self-test: out[lane] = lane_prev(lane), out[64+lane] = lane_next(lane)
-__global__ void k_selftest_lanes(float* out) {
-    const float v = (float)threadIdx.x;
-    out[threadIdx.x] = lane_prev(v);
-    out[64 + threadIdx.x] = lane_next(v);
-}
 
 // WAVES = 4: one job per wave, nothing shared.  WAVES = 12 (LUT stage with a cube of at most 21^3): the workgroup first
 // stages the cube's node table in LDS (dynamic shared memory, one float4 per node) and the gathers of the LUT stage
@@ -717,10 +695,3 @@ int launch_march(const float* in, float* out, int64_t frames, int32_t H, int32_t
 }
 
 }  // namespace vrg
-
-extern "C" int vrg_selftest_lanes(float* out128, void* stream) {
-    if (!out128) return VRG_ERR_BAD_ARG;
-    hipLaunchKernelGGL(vrg::k_selftest_lanes, dim3(1), dim3(64), 0, (hipStream_t)stream, out128);
-    VRG_CHECK_LAUNCH();
-    return VRG_OK;
-}

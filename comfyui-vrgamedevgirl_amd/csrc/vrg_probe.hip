@@ -3,6 +3,8 @@
 // of the colour-match arithmetic one value at a time (compared with the torch op the reference executes), and the measurement probes
 // DESIGN.md / LABNOTES.md quote (LUT record fetch patterns, streaming-copy ceiling, VALU issue rates).  gfx950 only.
 #include "vrg_common.hpp"
+#include "vrg_lanes.hpp"
+#include "vrg_tstats_config.hpp"
 
 namespace vrg {
 
@@ -466,9 +468,61 @@ __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, 
                                           (float)(w0 ^ w1 ^ w2 ^ w3 ^ w4 ^ w5 ^ w6 ^ w7) + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 
+// lane_prev / lane_next self-test (csrc/vrg_lanes.hpp): out[lane] = lane_prev(lane), out[64 + lane] = lane_next(lane)
+__global__ void k_selftest_lanes(float* out) {
+    const float v = (float)threadIdx.x;
+    out[threadIdx.x] = lane_prev(v);
+    out[64 + threadIdx.x] = lane_next(v);
+}
+
+// Exhaustive check of the Welford update's division (vrg_tstats_body.hpp: q = delta * rn; e = fma(-n, q, delta); q' = fma(e, rn, q) with
+// rn = 1.0f / n) against the IEEE quotient: one thread per (count n, fp32 significand of delta).  The sequence commutes with scaling
+// delta by a power of two as long as nothing leaves the normal range -- which the kernels' range flag (2^-100 <= |delta| <= 2^100)
+// guarantees -- and with its sign, so 2^23 significands per count are ALL inputs: equality is established by enumeration for every
+// count the kernels can reach (the launcher falls back to the IEEE division beyond TS_MARKSTEIN_MAX_COUNT).
+__global__ void __launch_bounds__(256) k_selftest_welford_division(unsigned long long* mismatches, uint32_t n_first) {
+    const uint32_t n = n_first + blockIdx.y;
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;            // 0 .. 2^23 - 1
+    const float delta = f32_from_bits(0x3f800000u | m);
+    const float nf = (float)n;
+    const float rn = 1.0f / nf;
+    const float q0 = delta * rn;
+    const float e = __builtin_fmaf(-nf, q0, delta);
+    const float q = __builtin_fmaf(e, rn, q0);
+    if (!(q == delta / nf)) atomicAdd(mismatches, 1ull);
+}
 }  // namespace vrg
 
+extern "C" int vrg_selftest_welford_division(unsigned long long* mismatches1, uint32_t n_first, uint32_t n_count, void* stream) {
+    if (!mismatches1 || n_first == 0 || n_count == 0 || (uint64_t)n_first + n_count > (1ull << 24)) return VRG_ERR_BAD_ARG;
+    for (uint32_t done = 0; done < n_count; done += 32768u) {
+        const uint32_t now = n_count - done < 32768u ? n_count - done : 32768u;
+        hipLaunchKernelGGL(vrg::k_selftest_welford_division, dim3(1u << 15, now), dim3(256), 0, (hipStream_t)stream, mismatches1, n_first + done);
+        if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
+    }
+    return VRG_OK;
+}
+
+// Host-only: the geometry ts_config derives for (num_outputs, reduction length, vector width): cfg4 = {block_width, block_height,
+// split across warps, vectorised}; VRG_ERR_UNSUPPORTED where torch would split the reduction across workgroups.  No GPU needed
+// (tests/test_torch_reduce_oracle.py compares it with what rocprofv3 recorded for torch's own launches).
+extern "C" int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32_t vec, int32_t* cfg4) {
+    if (!cfg4 || num_outputs < 1 || reduce_len < 1 || (vec != 2 && vec != 4)) return VRG_ERR_BAD_ARG;
+    vrg::TsCfg c;
+    if (!vrg::ts_config(num_outputs, reduce_len, vec, c)) return VRG_ERR_UNSUPPORTED;
+    cfg4[0] = c.bw; cfg4[1] = c.bh; cfg4[2] = c.split; cfg4[3] = c.vectorize;
+    return VRG_OK;
+}
+
 extern "C" {
+
+int vrg_selftest_lanes(float* out128, void* stream) {
+    if (!out128) return VRG_ERR_BAD_ARG;
+    hipLaunchKernelGGL(vrg::k_selftest_lanes, dim3(1), dim3(64), 0, (hipStream_t)stream, out128);
+    VRG_CHECK_LAUNCH();
+    return VRG_OK;
+}
+
 
 int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream) {
     if (!out || blocks <= 0 || iters <= 0 || mode < 0 || mode > 21) return VRG_ERR_BAD_ARG;

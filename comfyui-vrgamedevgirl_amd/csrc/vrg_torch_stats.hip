@@ -26,49 +26,9 @@
 // (tests/golden/torch_reduce_truth.npz collected on the MI355X; tests/test_gpu_parity.py compares with torch directly).
 #include <atomic>
 #include "vrg_tstats_body.hpp"
+#include "vrg_tstats_config.hpp"
 
 namespace vrg {
-
-struct TsCfg { int bw, bh, split, vectorize; };
-
-static int ts_last_pow2(int n) {
-    n |= n >> 1; n |= n >> 2; n |= n >> 4; n |= n >> 8; n |= n >> 16;
-    const int r = n - (n >> 1);
-    return r > 1 ? r : 1;
-}
-static int64_t ts_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
-
-// setReduceConfig for iter.ndim() == 2, reduction over the contiguous fastest dimension, warp 64, 512 threads max.
-// false: a geometry with ctas_per_output > 1 (not reachable for >= 2 outputs; kept as a guard).  `num_mp` = the device's CU count
-// (256 on the MI355X): it enters only through target_grid_size = num_mp * (max_threads_per_mp / block threads), and ROCm's cap of
-// max_threads_per_mp = 256 for 2-dim iterators makes that 0 for the 512-thread blocks of every call with more than one output --
-// the geometry of the calls this file replays is therefore the same on any CU count (a compute-partitioned MI355X, another gfx950 SKU).
-static bool ts_config(int64_t num_outputs, int64_t n, int vec, TsCfg& c, int num_mp = 256) {
-    int64_t dim0 = n;
-    c.vectorize = dim0 >= 128;
-    if (c.vectorize) dim0 /= vec;
-    const int d0 = dim0 < 512 ? ts_last_pow2((int)dim0) : 512;
-    const int d1 = num_outputs < 512 ? ts_last_pow2((int)num_outputs) : 512;
-    int bw = d0 < 64 ? d0 : 64;
-    const int bh = d1 < 512 / bw ? d1 : 512 / bw;
-    bw = d0 < 512 / bh ? d0 : 512 / bh;
-    int64_t vpt = ts_div_up(n, bw);
-    const int thr = bh * 16 < 256 ? bh * 16 : 256;
-    c.split = vpt >= thr;
-    c.bw = bw; c.bh = bh;
-    const int64_t step_in = (int64_t)bw * (c.split ? bh : 1), step_out = c.split ? 1 : bh;
-    const int64_t grid_x = ts_div_up(num_outputs, step_out);
-    const int max_tpm = grid_x == 1 ? 2048 : 256;          // `grid.x == grid.y == grid.z == 1` as C evaluates it
-    const int64_t target = (int64_t)num_mp * (int64_t)(max_tpm / (bw * bh));
-    vpt = ts_div_up(n, step_in);
-    if (c.split && vpt >= 256 && grid_x <= target) {
-        const int64_t c1 = ts_div_up(target, grid_x), c2 = ts_div_up(vpt, 16), c3 = ts_div_up(vpt, 256);
-        int64_t ctas = (c1 < c2 ? c1 : c2) > c3 ? (c1 < c2 ? c1 : c2) : c3;
-        if (ctas > 256) ctas = 256; else if (ctas > 128) ctas = 128; else if (ctas < 16) ctas = 1;
-        if (ctas != 1) return false;
-    }
-    return true;
-}
 
 // One thread's share of one output: `X(p)` = element p of the output's reduction range, `shift` = elements by which that range
 // starts past a VEC-aligned address in the reference's planar tensor.
@@ -468,11 +428,21 @@ static int ts_launch_calls(const float* lab, int64_t n, int64_t count, int b, fl
             return VRG_OK;
         }
         const bool split = frames <= TS_SPLIT_MAX_FRAMES;
-        const int depth = split ? 2 : 1;
-        const dim3 grid(split ? (unsigned)(32 * ((frames + 7) / 8)) : (unsigned)frames);
-#define TS_LAUNCH(S, D) hipLaunchKernelGGL((k_tstats_frame<S, D>), grid, dim3(512), 0, st, lab, n, frames, cm.bw, cm.bh, factor, eps, out)
-        if (depth == 2) TS_LAUNCH(true, VRG_TS_SPLIT_DEPTH); else TS_LAUNCH(false, VRG_TS_WHOLE_DEPTH);
-#undef TS_LAUNCH
+        if (split) {
+            hipLaunchKernelGGL((k_tstats_frame<true, VRG_TS_SPLIT_DEPTH>), dim3((unsigned)(32 * ((frames + 7) / 8))), dim3(512), 0, st, lab, n, frames, cm.bw,
+                               cm.bh, factor, eps, out);
+        } else {
+            // One workgroup streams one frame.  Round 6 (profiles/r06_tstats_sizes.json): 256 4K frames in one launch -- one workgroup per CU --
+            // read at 5.5 TB/s, 512 frames in one launch (two resident per CU: 512 concurrent 100 MB streams) at 4.0, 384 at 3.6, but 512 as
+            // two launches of 256 at 5.5 again; address translation is not involved (TCP_UTCL1 misses: 75 of 9.5e8 requests), the L2's read
+            // latency rises 838 -> 1003 cycles with the second resident stream per CU.  So: at most one workgroup per CU per launch.
+            const int64_t per = num_mp > 0 ? num_mp : 256;
+            for (int64_t f0 = 0; f0 < frames; f0 += per) {
+                const int64_t nf = frames - f0 < per ? frames - f0 : per;
+                hipLaunchKernelGGL((k_tstats_frame<false, VRG_TS_WHOLE_DEPTH>), dim3((unsigned)nf), dim3(512), 0, st, lab + (size_t)f0 * (size_t)n * 3, n, nf,
+                                   cm.bw, cm.bh, factor, eps, out + (size_t)f0 * 6);
+            }
+        }
     } else {
         // all planes of all calls in one launch: plane -> (frame, channel), position in its call from frame % b
         hipLaunchKernelGGL((k_tstats_plane<MeanOp, 0>), dim3((unsigned)(frames * 3)), dim3(512), 0, st, lab, n, (int64_t)0, b, cm, factor, eps, out);
@@ -530,44 +500,4 @@ static int lab_stats_torch_any(const float* lab, int64_t frames, int32_t height,
     if (rc != VRG_OK) return rc;
     if (tail) rc = ts_launch_calls(lab + (size_t)full * chunk_frames * n * 3, n, 1, tail, eps, mean_std + (size_t)full * chunk_frames * 6, cus, scratch, scratch_bytes, st, prefer_lanes);
     return rc;
-}
-
-namespace vrg {
-// Exhaustive check of the Welford update's division (vrg_tstats_body.hpp: q = delta * rn; e = fma(-n, q, delta); q' = fma(e, rn, q) with
-// rn = 1.0f / n) against the IEEE quotient: one thread per (count n, fp32 significand of delta).  The sequence commutes with scaling
-// delta by a power of two as long as nothing leaves the normal range -- which the kernels' range flag (2^-100 <= |delta| <= 2^100)
-// guarantees -- and with its sign, so 2^23 significands per count are ALL inputs: equality is established by enumeration for every
-// count the kernels can reach (the launcher falls back to the IEEE division beyond TS_MARKSTEIN_MAX_COUNT).
-__global__ void __launch_bounds__(256) k_selftest_welford_division(unsigned long long* mismatches, uint32_t n_first) {
-    const uint32_t n = n_first + blockIdx.y;
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;            // 0 .. 2^23 - 1
-    const float delta = f32_from_bits(0x3f800000u | m);
-    const float nf = (float)n;
-    const float rn = 1.0f / nf;
-    const float q0 = delta * rn;
-    const float e = __builtin_fmaf(-nf, q0, delta);
-    const float q = __builtin_fmaf(e, rn, q0);
-    if (!(q == delta / nf)) atomicAdd(mismatches, 1ull);
-}
-}  // namespace vrg
-
-extern "C" int vrg_selftest_welford_division(unsigned long long* mismatches1, uint32_t n_first, uint32_t n_count, void* stream) {
-    if (!mismatches1 || n_first == 0 || n_count == 0 || (uint64_t)n_first + n_count > (1ull << 24)) return VRG_ERR_BAD_ARG;
-    for (uint32_t done = 0; done < n_count; done += 32768u) {
-        const uint32_t now = n_count - done < 32768u ? n_count - done : 32768u;
-        hipLaunchKernelGGL(vrg::k_selftest_welford_division, dim3(1u << 15, now), dim3(256), 0, (hipStream_t)stream, mismatches1, n_first + done);
-        if (hipGetLastError() != hipSuccess) return VRG_ERR_LAUNCH;
-    }
-    return VRG_OK;
-}
-
-// Host-only: the geometry ts_config derives for (num_outputs, reduction length, vector width): cfg4 = {block_width, block_height,
-// split across warps, vectorised}; VRG_ERR_UNSUPPORTED where torch would split the reduction across workgroups.  No GPU needed
-// (tests/test_torch_reduce_oracle.py compares it with what rocprofv3 recorded for torch's own launches).
-extern "C" int vrg_debug_torch_reduce_config(int64_t num_outputs, int64_t reduce_len, int32_t vec, int32_t* cfg4) {
-    if (!cfg4 || num_outputs < 1 || reduce_len < 1 || (vec != 2 && vec != 4)) return VRG_ERR_BAD_ARG;
-    vrg::TsCfg c;
-    if (!vrg::ts_config(num_outputs, reduce_len, vec, c)) return VRG_ERR_UNSUPPORTED;
-    cfg4[0] = c.bw; cfg4[1] = c.bh; cfg4[2] = c.split; cfg4[3] = c.vectorize;
-    return VRG_OK;
 }

@@ -131,6 +131,18 @@ def _check_side(t: torch.Tensor, name: str, like: torch.Tensor, shape_tail=None,
     return t
 
 
+def _out_like(x: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """The destination of an operator: a fresh tensor, or the caller's (contiguous, shaped and typed like the frames, same device, not
+    the frames themselves -- the stencils read neighbours of what they write)."""
+    if out is None:
+        return torch.empty_like(x)
+    if out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous tensor shaped and typed like the frames on the same device")
+    if out.data_ptr() == x.data_ptr() and x.numel():
+        raise ValueError("out must not alias the input frames")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # noise descriptors
 # ------------------------------------------------------------------------------------------------
@@ -167,6 +179,31 @@ def plan_noise(frames: int, frame_numel: int, chunk_frames: int, device, generat
     if tail:
         tail_plan = NoisePlan(tail, rng.reserve(tail * frame_numel, 1, device, generator))
     return main, tail_plan, n_full
+
+
+def slice_plans(plans, first_frame: int, frames: int):
+    """The part of a whole-batch reservation (`plan_noise`) that covers frames [first_frame, first_frame + frames): what `plan_noise` would
+    have returned for that piece had the pieces been reserved one after the other -- a batch's chunks are consecutive generator ranges, so
+    reserving it at once (when the node is called) and slicing (when a piece runs) consumes the generator exactly as the reference's
+    chunk loop does.  `first_frame` must be a multiple of the chunk size."""
+    main, tail, n_full = plans
+    step = main.chunk_frames if main is not None else (tail.chunk_frames if tail is not None else 1)
+    full_end = n_full * step if main is not None else 0
+    if first_frame % step and first_frame < full_end:
+        raise ValueError("a piece of a grain batch must start on a noise chunk")
+    end = first_frame + frames
+    sub_main, sub_n = None, 0
+    if main is not None and first_frame < full_end:
+        sub_n = (min(end, full_end) - first_frame) // step
+        if sub_n:
+            sub_main = NoisePlan(step, main.stream, main.chunk0 + first_frame // step)
+    covered = first_frame + sub_n * step if first_frame < full_end else first_frame
+    sub_tail = None
+    if covered < end:
+        if tail is None or covered != full_end or end - covered != tail.chunk_frames:
+            raise ValueError("a piece of a grain batch must be made of whole noise chunks")
+        sub_tail = tail
+    return sub_main, sub_tail, sub_n
 
 
 # ------------------------------------------------------------------------------------------------
@@ -222,12 +259,12 @@ def _film_grain_oversize(x, out, grain_intensity, saturation_mix, chunk_frames, 
 
 @_on_device
 def film_grain(images: torch.Tensor, grain_intensity: float, saturation_mix: float, chunk_frames: int = 0,
-               generator: Optional[torch.Generator] = None, plans=None) -> torch.Tensor:
+               generator: Optional[torch.Generator] = None, plans=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Film grain with in-register Philox noise, bit-identical to the reference run on this GPU with the same
     generator state: chunks of `chunk_frames` frames each draw one ``torch.randn`` (0 = one draw for all)."""
     x = _check_frames(images, channels=3)
     F, H, W, _ = x.shape
-    out = torch.empty_like(x)
+    out = _out_like(x, out)
     if F == 0:
         return out
     fe = H * W * 3
@@ -407,15 +444,18 @@ def blend_terms(strength: float):
 
 
 @_on_device
-def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0) -> torch.Tensor:
+def lut3d(image: torch.Tensor, lut: DeviceLut, strength: float = 10.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if image.ndim != 4 or image.shape[-1] < 3:
         raise ValueError("VRGDG_LUTS expects IMAGE input shaped like [batch, height, width, channels].")
     x = _check_frames(image, "image")
     mode, B, omB = blend_terms(strength)
     if mode == 0:
+        if out is not None:
+            _out_like(x, out).copy_(x)
+            return out
         return x
     _check_side(lut.table, "LUT record table", x)
-    out = torch.empty_like(x)
+    out = _out_like(x, out)
     px = x.numel() // x.shape[-1]
     if px == 0:
         return out
@@ -457,11 +497,11 @@ _STENCIL = {"unsharp": _hip.STENCIL_UNSHARP, "laplacian": _hip.STENCIL_LAPLACIAN
 
 
 @_on_device
-def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool = False) -> torch.Tensor:
+def stencil3x3(images: torch.Tensor, op: str, strength: float, zero_border: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """unsharp / laplacian / sobel.  zero_border=False is the reference's default numpy path (edge replicate);
     True is its ``use_gpu`` path (zero padding, and for laplacian/sobel the conv2d sign/epsilon conventions)."""
     x = _check_frames(images)
-    out = torch.empty_like(x)
+    out = _out_like(x, out)
     F, H, W, Cn = x.shape
     if x.numel() == 0:
         return out
@@ -711,7 +751,7 @@ def _device_stats_selfcheck(device) -> None:
 # `toolchain_status()` -- the powers then differ from the reference's by an ulp in rare lanes.
 # ------------------------------------------------------------------------------------------------
 _TOOLCHAIN = {}              # device index -> {"pow": bool, "march": bool}
-_POW_SITES = ((12, 2.4, 0.0625, 2.0), (13, 1.0 / 2.4, 0.0031308, 4.0), (14, 1.0 / 3.0, 0.008856, 4.0))
+_POW_SITES = ((12, 2.4, 0.0625, 2.0), (13, 1.0 / 2.4, 0.0031308, 4.0), (14, 1.0 / 3.0, 0.008856, 4.0))     # (vrg_debug_cm_math op, y, domain) per call site
 
 
 def _pow_probe_arguments(lo: float, hi: float, device) -> torch.Tensor:
@@ -722,6 +762,9 @@ def _pow_probe_arguments(lo: float, hi: float, device) -> torch.Tensor:
     return torch.from_numpy(np.concatenate([bits, near1]).view(np.float32)).to(device)
 
 
+_TOOLCHAIN_RUNNING = set()   # device indices whose probes are running right now (on whatever thread)
+
+
 def toolchain_selfcheck(device, force: bool = False) -> dict:
     key = torch.device(device).index
     if key is None:
@@ -729,39 +772,53 @@ def toolchain_selfcheck(device, force: bool = False) -> dict:
     with _STATE_LOCK:
         if key in _TOOLCHAIN and not force:
             return _TOOLCHAIN[key]
-        _TOOLCHAIN[key] = {"pow": True, "march": True}         # re-entrancy: the probes below run fused_chain themselves
+        if key in _TOOLCHAIN_RUNNING:
+            # the probes below run fused_chain themselves (re-entrancy), and another host thread may arrive while they run: both get the
+            # SAFE answer for this one call -- the tile kernels, same bits -- and nothing is recorded before the probes have finished
+            return {"pow": True, "march": False}
+        if torch.cuda.is_current_stream_capturing():
+            return {"pow": True, "march": False}          # the probes synchronise: not inside a graph capture; checked at the next plain call
+        _TOOLCHAIN_RUNNING.add(key)
     dev = torch.device("cuda", key)
     res = {"pow": True, "march": True}
-    with torch.cuda.device(key):
-        lib = _hip.lib()
-        for op, y, lo, hi in _POW_SITES:
-            x = _pow_probe_arguments(lo, hi, dev)
-            got = torch.empty_like(x)
-            _hip.check(lib.vrg_debug_cm_math(_hip.ptr(x), _hip.ptr(got), x.numel(), op, _f32(y), _hip.current_stream()), "vrg_debug_cm_math")
-            res["pow"] = res["pow"] and bool(torch.equal(got, torch.pow(x, y)))
-        g = torch.Generator(device=dev).manual_seed(20260926)
-        frames = torch.rand((2, 512, 512, 3), generator=g, device=dev)       # one RNG chunk of 2 frames: full-grid Philox geometry, steady rows
-        axis = np.linspace(0.0, 1.0, 33, dtype=np.float32)
-        bb, gg, rr = np.meshgrid(axis, axis, axis, indexing="ij")             # [b][g][r] -> (r, g, b): a smooth non-identity grade
-        table = np.stack([rr ** 1.25, 0.9 * gg + 0.1 * bb, bb * bb], axis=-1).astype(np.float32)
-        lut = upload_lut({"lut": torch.from_numpy(table), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}, dev)
-        outs = []
-        for variant in (2, 1):
-            gen = torch.Generator(device=dev).manual_seed(7)
-            spec = ChainSpec(grain=(0.04, 0.5, 2), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False), variant=variant)
-            outs.append(fused_chain(frames, spec, generator=gen))
-        res["march"] = bool(torch.equal(outs[0], outs[1]))
-    with _STATE_LOCK:
-        _TOOLCHAIN[key] = res
+    try:
+        with torch.cuda.device(key):
+            lib = _hip.lib()
+            for site, (op, y, lo, hi) in enumerate(_POW_SITES):
+                x = _pow_probe_arguments(lo, hi, dev)
+                got = torch.empty_like(x)
+                _hip.check(lib.vrg_selfcheck_pow_f32(_hip.ptr(x), _hip.ptr(got), x.numel(), site, _hip.current_stream()), "vrg_selfcheck_pow_f32")
+                res["pow"] = res["pow"] and bool(torch.equal(got, torch.pow(x, y)))
+            g = torch.Generator(device=dev).manual_seed(20260926)
+            frames = torch.rand((2, 512, 512, 3), generator=g, device=dev)       # one RNG chunk of 2 frames: full-grid Philox geometry, steady rows
+            axis = np.linspace(0.0, 1.0, 33, dtype=np.float32)
+            bb, gg, rr = np.meshgrid(axis, axis, axis, indexing="ij")             # [b][g][r] -> (r, g, b): a smooth non-identity grade
+            table = np.stack([rr ** 1.25, 0.9 * gg + 0.1 * bb, bb * bb], axis=-1).astype(np.float32)
+            lut = upload_lut({"lut": torch.from_numpy(table), "domain_min": torch.zeros(3), "domain_max": torch.ones(3)}, dev)
+            outs = []
+            for variant in (2, 1):
+                gen = torch.Generator(device=dev).manual_seed(7)
+                spec = ChainSpec(grain=(0.04, 0.5, 2), lut=(lut, 10.0), sharpen=("unsharp", 0.5, False), variant=variant)
+                outs.append(fused_chain(frames, spec, generator=gen))
+            res["march"] = bool(torch.equal(outs[0], outs[1]))
+    except Exception as exc:             # a probe that cannot run (out of memory, a launch error) proves nothing: take the safe kernels, say so
+        res = {"pow": False, "march": False, "error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        with _STATE_LOCK:
+            _TOOLCHAIN_RUNNING.discard(key)
+            _TOOLCHAIN[key] = res
     if not (res["pow"] and res["march"]):
         import warnings
         what = []
-        if not res["march"]:
-            what.append("the wave-march kernel disagrees with the tile kernels (hand-counted waits of its LDS-DMA gathers): fused chains take the "
-                        "tile kernels in this process")
-        if not res["pow"]:
-            what.append("dev_pow_ziv disagrees with this ROCm's powf (its rounding test is calibrated against ROCm 7.0's ocml): colour match may "
-                        "differ from the reference by an ulp in rare pixels")
+        if "error" in res:
+            what.append(f"the first-use self-check could not run ({res['error']}): fused chains take the tile kernels in this process")
+        else:
+            if not res["march"]:
+                what.append("the wave-march kernel disagrees with the tile kernels (hand-counted waits of its LDS-DMA gathers): fused chains take the "
+                            "tile kernels in this process")
+            if not res["pow"]:
+                what.append("dev_pow_ziv disagrees with this ROCm's powf (its rounding test is calibrated against ROCm 7.0's ocml): colour match may "
+                            "differ from the reference by an ulp in rare pixels")
         warnings.warn("comfyui-vrgamedevgirl_amd: built or run with another toolchain than the one its fast forms were measured on -- "
                       + "; ".join(what) + " (ops.toolchain_status())", RuntimeWarning)
     return res
@@ -770,7 +827,8 @@ def toolchain_selfcheck(device, force: bool = False) -> dict:
 def toolchain_status(device=None) -> dict:
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     res = toolchain_selfcheck(device)
-    return {"pow_equals_ocml": res["pow"], "march_equals_tile_kernels": res["march"], "hip": torch.version.hip, "torch": torch.__version__}
+    return {"pow_equals_ocml": res["pow"], "march_equals_tile_kernels": res["march"], "error": res.get("error"), "hip": torch.version.hip,
+            "torch": torch.__version__}
 
 
 def _auto_variant(device) -> int:
@@ -902,7 +960,7 @@ def colormatch_apply(images: torch.Tensor, img_ms: torch.Tensor, ref_ms: torch.T
 @_on_device
 def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_strength: float,
                 ref_ms: Optional[torch.Tensor] = None, cache_lab: bool = True, cm_math=None, cm_chunk=1, cm_stats=None,
-                ref_event=None) -> torch.Tensor:
+                ref_event=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per-frame Lab mean/std transfer to the reference frame(s) (nodes.py:91-124).  Two passes over HBM:
     statistics (which also stores the Lab image when cache_lab) and apply; see fused_chain.  `cm_chunk`: frames per statistics
     call of the reference (the node's batch_size, or the list of call sizes) -- it shapes the device statistics like it shapes
@@ -913,11 +971,15 @@ def color_match(images: torch.Tensor, reference_image: torch.Tensor, match_stren
         ref_ms = reference_stats(reference_image.to(x.device), cm_math, stats)
     if cache_lab or stats == "device":
         return fused_chain(x, ChainSpec(colormatch=(ref_ms, match_strength), cm_math=cm_math, cm_chunk=cm_chunk, cm_stats=stats,
-                                        cm_ref_event=ref_event))
+                                        cm_ref_event=ref_event), out=out)
     if ref_event is not None:
         torch.cuda.current_stream().wait_event(ref_event)
     img_ms = finalize_stats(lab_stats(x, cm_math))
-    return colormatch_apply(x, img_ms, ref_ms, match_strength, cm_math)
+    res = colormatch_apply(x, img_ms, ref_ms, match_strength, cm_math)
+    if out is not None:
+        _out_like(x, out).copy_(res)
+        return out
+    return res
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1159,6 +1221,26 @@ def fused_chain(images: torch.Tensor, spec: ChainSpec, generator: Optional[torch
             e1.record()
             kernel_events.append(("apply", e0, e1, nf))
     return out
+
+
+def fused_stages(frames: torch.Tensor, first_frame: int, stages: dict, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """What `_devices` runs when consecutive nodes of this pack were called on one another's results (deferred graph fusion): the
+    recorded nodes -- ``stages[kind]`` for kind in grain / lut / colormatch / sharpen, each the parameters its node was called with -- as
+    ONE fused chain over frames [first_frame, first_frame + n) of the ORIGINAL input.  Bit-identical to the nodes run one after the
+    other (tests/test_gpu_parity.py): grain draws from the generator range its node reserved when it was called (``plans``, sliced per
+    piece), the colour statistics are reduced over the node's batch_size calls (``calls_of``), the reference statistics come from the
+    side stream they were queued on at call time (``ref_event``).  Reference call order: nodes.py:41-66 -> VRGDG_IV_Adjustments.py:345-361
+    -> nodes.py:91-124 -> nodes.py:156-209."""
+    n = int(frames.shape[0])
+    g, l, c, sh = (stages.get(k) for k in ("grain", "lut", "colormatch", "sharpen"))
+    spec = ChainSpec(grain=(g["I"], g["s"], g["step"]) if g else None,
+                     lut=(l["lut"], l["strength"]) if l else None,
+                     colormatch=(c["ref_ms"], c["k"]) if c else None,
+                     sharpen=(sh["op"], sh["strength"], sh["zero"]) if sh else None,
+                     cm_chunk=c["calls_of"](first_frame, n) if c else 1,
+                     cm_ref_event=c["ref_event"] if c else None)
+    plans = slice_plans(g["plans"], first_frame, n) if g else None
+    return fused_chain(frames, spec, plans=plans, out=out)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VRG_ABI_VERSION 7
+#define VRG_ABI_VERSION 8
 
 enum vrg_status {
     VRG_OK = 0,
@@ -326,6 +326,19 @@ int vrg_event_create(void** ev);
 int vrg_event_record(void* ev, void* stream);
 int vrg_event_elapsed_ms(void* start, void* stop, float* ms);
 int vrg_event_destroy(void* ev);
+
+/* Raw N(0,1) stream of the given chunks, bit-identical to torch.randn on this device; `frame_elems` = H*W*3.  The node layer materialises the
+ * noise of an RNG chunk of more than 2^29 elements with it, leaf by leaf as ATen splits such a randn (reference: nodes.py:51 with batch_size 0
+ * or >= 22 4K frames), and the tests compare the stream itself against torch. */
+int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
+                  const vrg_noise_desc* noise, void* stream);
+
+/* First-use self-check of the one toolchain-calibrated arithmetic form of the colour match (csrc/vrg_pixel_math.hpp dev_pow_ziv: table
+ * logarithm + rounding test whose half-widths were measured against ROCm 7.0's ocml): out[i] = the power of in[i] exactly as call site
+ * `site` of the Lab transforms evaluates it -- 0: sRGB -> linear (x^2.4 on [0.0625, 2]), 1: linear -> sRGB (x^(1/2.4) on [0.0031308, 4]),
+ * 2: the Lab cube root (x^(1/3) on [0.008856, 4]).  The host compares with this ROCm's powf (torch.pow, which the reference's kornia calls:
+ * nodes.py:98, 115) and reports a mismatch (ops.toolchain_status). */
+int vrg_selfcheck_pow_f32(const float* in, float* out, int64_t n, int32_t site, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -1,9 +1,9 @@
-/* vrgdg_hip_debug.h -- self-tests, element-wise probes and timing probes of libvrgdg_hip.so.
+/* vrgdg_hip_debug.h -- self-tests, element-wise probes and timing probes: the C ABI of libvrgdg_hip_debug.so, a library of its own (round 6).
  *
  * NOT part of the drop-in boundary (include/vrgdg_hip.h): nothing a host of the node pack calls.  These entry points exist for the
  * test suite (exhaustive device sweeps that PROVE an arithmetic substitution, element-wise pieces of the colour-match arithmetic to
  * compare with the torch op the reference executes, the launch geometry of the replayed reductions) and for the measurement tools
- * (tools/probe_gather.py, tools/copy_ceiling.py, tools/probe_valu.py).  They live in their own translation unit (csrc/vrg_probe.hip)
+ * (tools/probe_gather.py, tools/copy_ceiling.py, tools/probe_valu.py).  They live in their own translation unit (csrc/vrg_probe.hip), linked into libvrgdg_hip_debug.so and into nothing the nodes load,
  * and are bound separately by _hip.py (`_DEBUG_SIGNATURES`); tests/test_abi.py holds both headers to the library's exports. */
 #ifndef VRGDG_HIP_DEBUG_H_
 #define VRGDG_HIP_DEBUG_H_
@@ -11,11 +11,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-/* Raw N(0,1) stream of the given chunks, bit-identical to torch.randn on this device (debug /
- * test entry: lets the tests compare the stream itself against torch). `frame_elems` = H*W*3. */
-int vrg_noise_f32(float* out, int64_t frames, int64_t frame_elems,
-                  const vrg_noise_desc* noise, void* stream);
 
 /* Device self-test: sweeps all 2^32 fp32 inputs through the FMA-based constant divisions of the kernels
  * (csrc/vrg_pixel_math.hpp div_const / div9) and counts disagreements with the IEEE quotient.

@@ -24,14 +24,28 @@ def _declared(name):
     return set(re.findall(r"\b(vrg_[a-z0-9_]+)\s*\(", header))
 
 
+def _exports(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("vrg_")}
+
+
 def test_header_symbols_are_exported(hip):
-    """The drop-in boundary (vrgdg_hip.h) and the separate self-test / probe header (vrgdg_hip_debug.h): every prototype is exported
-    and bound, and the boundary carries no debug entry point."""
+    """Two headers, two libraries: the drop-in boundary (vrgdg_hip.h <-> libvrgdg_hip.so) and the self-tests / probes of the test suite and
+    the tools (vrgdg_hip_debug.h <-> libvrgdg_hip_debug.so).  Every prototype is exported by ITS library and bound; the product library
+    exports nothing but the boundary -- no probe or self-test is linked into what the nodes load."""
     declared, debug = _declared("vrgdg_hip.h"), _declared("vrgdg_hip_debug.h")
     assert declared and debug, "no prototypes found"
+    assert _exports(hip.LIB_PATH) == declared, "libvrgdg_hip.so exports differ from vrgdg_hip.h"
+    assert _exports(hip.DEBUG_LIB_PATH) == debug, "libvrgdg_hip_debug.so exports differ from vrgdg_hip_debug.h"
     lib = hip.load_library()
-    for sym in sorted(declared | debug):
-        assert hasattr(lib, sym), f"{sym} declared but not exported"
+    assert lib._debug is None                                   # loading the product does not open the debug library
+    for sym in sorted(declared):
+        assert hasattr(lib._cdll, sym), f"{sym} declared but not exported"
+    assert lib._debug is None
+    for sym in sorted(debug):
+        assert hasattr(lib, sym), f"{sym} declared but not exported by the debug library"
+    assert lib._debug is not None
     assert declared == set(hip.EXPORTED_SYMBOLS), "ctypes prototypes out of sync with vrgdg_hip.h"
     assert debug == set(hip.DEBUG_SYMBOLS), "ctypes prototypes out of sync with vrgdg_hip_debug.h"
     assert not [s for s in declared if s.startswith(("vrg_debug_", "vrg_selftest_"))]
@@ -47,7 +61,7 @@ def test_struct_layouts_match_the_header(hip):
 
 def test_versions_and_error_strings(hip):
     lib = hip.load_library()
-    assert lib.vrg_abi_version() == 7 == hip.ABI_VERSION
+    assert lib.vrg_abi_version() == 8 == hip.ABI_VERSION
     assert lib.vrg_error_string(0) == b"ok"
     assert b"argument" in lib.vrg_error_string(1)
     assert lib.vrg_lab_stats_scratch_bytes(3) == 3 * 128 * 6 * 8

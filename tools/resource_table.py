@@ -14,7 +14,7 @@ def field(block, key):
     return m.group(1) if m else "?"
 
 rows = []
-for src in be.SOURCES:
+for src in be.SOURCES + be.DEBUG_SOURCES:
     cflags = [f for f in be.HIPCC_FLAGS if f != "-shared"]
     r = subprocess.run([be._hipcc(), *cflags, *be.EXTRA_FLAGS.get(src, ()), "-I", be.INCLUDE, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", "/dev/null"],
                        capture_output=True, text=True)
