@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import cube, ops
-from ._devices import compute_device, stream_frames
+from ._devices import Stage, compute_device, defer, stream_frames
 
 LUTS_DIR = os.path.join(os.path.dirname(__file__), "LUTS")
 SUPPORTED_LUT_EXTENSIONS = cube.SUPPORTED_LUT_EXTENSIONS
@@ -38,12 +38,21 @@ def _graded(image, lut_data, requested_device, strength):
         return _graded(image.to(torch.float32), lut_data, requested_device, strength).to(image.dtype)
     target = VRGDG_LUTS._resolve_device(requested_device, image)
     dev_lut = ops.upload_lut(lut_data, target)
+
+    def on(device):             # several GPUs (VRGDG_DEVICES): every device gets its own copy of the record table
+        lut_d = dev_lut if torch.device(device) == torch.device(target) else ops.upload_lut(lut_data, device)
+        return lambda frames, _first, out=None: ops.lut3d(frames, lut_d, strength, out=out)
+
+    fusable = image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0 and image.shape[-1] == 3
+    stage = Stage("lut", on(target), 1, {"lut": dev_lut, "strength": strength}) if fusable else None
     if image.device.type == "cpu" and image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0:
-        # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames)
-        def on(device):             # several GPUs (VRGDG_DEVICES): every device gets its own copy of the record table
-            lut_d = dev_lut if torch.device(device) == torch.device(target) else ops.upload_lut(lut_data, device)
-            return lambda frames, _first: ops.lut3d(frames, lut_d, strength)
-        return stream_frames(image, on(target), fn_for_device=on)
+        # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames); recorded and fused with
+        # the neighbouring nodes of this pack where the graph allows it (_devices.defer)
+        return stream_frames(image, on(target), fn_for_device=on, stage=stage)
+    if stage is not None and image.is_cuda and image.device == torch.device(target):
+        res = defer(image, torch.device(target), stage, image.device)      # device frames in a device-resident graph: same deferral
+        if res is not None:
+            return res
     working = image.to(device=target)
     return ops.lut3d(working, dev_lut, strength).to(device=image.device)
 

@@ -304,6 +304,9 @@ def release_device_copies() -> int:
     e.g. before loading a model; the copies also expire by themselves after VRGDG_DEVICE_CACHE_SECONDS."""
     n = _DEVICE_COPIES.held_bytes()
     _DEVICE_COPIES.clear()
+    if "_LAZY" in globals():
+        n += _LAZY.flush()               # results that exist only in HBM so far are downloaded; the copies made of them are dropped as well
+        _DEVICE_COPIES.clear()
     return n
 
 
@@ -330,15 +333,108 @@ def release_device_copies() -> int:
 LAZY_DOWNLOAD = os.environ.get("VRGDG_LAZY_DOWNLOAD", "1") != "0"
 LAZY_SECONDS = float(os.environ.get("VRGDG_LAZY_SECONDS", "2"))
 
+# ------------------------------------------------------------------------------------------------------------
+# Deferred graph fusion (round 6).  The kernels bench.py measures -- grain -> LUT -> (colour match) -> sharpen as ONE pass (two with a
+# colour match) -- were reachable only from ops.fused_chain: in a graph every node launched its own kernel.  Now a node that is handed
+# CPU frames does not run at all when it is called: it validates its arguments, reserves what the reference's call would have consumed
+# at that moment (the generator range of the grain node: ops.plan_noise; the reference frame's statistics of the colour match, queued
+# on the side stream) and returns a `LazyFrames` whose pending record holds a RECIPE: (source frames, [stage, ...]).
+#   * The next node of this pack that receives it APPENDS its stage when the order is one ops.fused_chain runs (grain < LUT < colour
+#     match < sharpen, each once) and returns a new LazyFrames over the SAME source; any other order starts a new recipe on top.
+#   * First host use of a result (or the timer, LAZY_SECONDS) runs its recipe: upload, ONE fused launch per piece (ops.fused_stages),
+#     download -- the three in duplex, straight into the page-locked buffer the LazyFrames was made over.  grain -> LUT -> colour match ->
+#     unsharp as four node calls: one upload, one k_produce_lab + statistics + k_apply_march per piece, one download.
+#   * A consumer inside this pack that cannot append (or wants the frames as a colour-match reference) runs the recipe INTO HBM and
+#     reads the pieces there, as before.
+# Same bits and same generator state as the four nodes run eagerly (tests/test_gpu_parity.py::test_deferred_graph_*): the fused chain
+# is bit-identical to its stages run one after the other, and the noise plan is reserved in call order.  What it adds to the lazy
+# download's one blind spot: the SOURCE tensor is read when the recipe runs, not when the first node was called -- ComfyUI's rule that
+# node inputs (cached outputs of other nodes) are never written is what makes that the same frames; a source whose version counter or
+# content stamp changed in between is reported with a RuntimeWarning.  VRGDG_DEFER_GRAPH=0 restores node-by-node execution.
+# ------------------------------------------------------------------------------------------------------------
+DEFER_GRAPH = os.environ.get("VRGDG_DEFER_GRAPH", "1") != "0"
+_STAGE_ORDER = {"grain": 0, "lut": 1, "colormatch": 2, "sharpen": 3}
+
+
+class Stage:
+    """One node's operator: `fn(gpu_frames, first_frame, out=None) -> gpu_frames` (the stand-alone kernels, noise / statistics already
+    reserved), the frame multiple its pieces must keep, and -- where ops.fused_chain can run it as a stage of one launch -- `kind` and
+    the parameters (`fuse`) ops.fused_stages takes."""
+    __slots__ = ("kind", "fn", "multiple_of", "fuse")
+
+    def __init__(self, kind, fn, multiple_of=1, fuse=None):
+        self.kind, self.fn, self.multiple_of, self.fuse = kind, fn, max(int(multiple_of), 1), fuse
+
+
+class _Recipe:
+    __slots__ = ("source", "stages", "source_pieces", "version", "stamp")
+
+    def __init__(self, source, stages, source_pieces=None):
+        self.source, self.stages, self.source_pieces = source, list(stages), source_pieces
+        plain_cpu = isinstance(source, torch.Tensor) and not isinstance(source, LazyFrames) and source.device.type == "cpu"
+        self.version = _version_of(source) if plain_cpu else None
+        self.stamp = _content_stamp(source) if plain_cpu and source.is_contiguous() and source.numel() else None
+
+    def multiple_of(self) -> int:
+        import math
+        m = 1
+        for st in self.stages:
+            m = m * st.multiple_of // math.gcd(m, st.multiple_of)
+        return m
+
+    def compiled(self):
+        """(fn(gpu_frames, first_frame, out=None), frames multiple): one stage as its node runs it, several as ONE fused chain."""
+        if len(self.stages) == 1:
+            return self.stages[0].fn, self.stages[0].multiple_of
+        from . import ops
+        fuse = {st.kind: st.fuse for st in self.stages}
+        return (lambda gpu, first, out=None: ops.fused_stages(gpu, first, fuse, out=out)), self.multiple_of()
+
+    def can_append(self, stage: "Stage", frame_bytes: int) -> bool:
+        if stage.fuse is None or any(st.fuse is None for st in self.stages):
+            return False
+        if _STAGE_ORDER[stage.kind] <= _STAGE_ORDER[self.stages[-1].kind]:
+            return False
+        import math
+        m = self.multiple_of()
+        lcm = m * stage.multiple_of // math.gcd(m, stage.multiple_of)
+        return lcm == max(m, stage.multiple_of) or lcm * frame_bytes <= STAGE_BYTES      # pieces stay pieces
+
+    def check_source(self):
+        if self.stamp is None:
+            return
+        changed = self.version != _version_of(self.source)
+        if not changed:
+            try:
+                changed = self.stamp != _content_stamp(self.source)
+            except Exception:
+                changed = False
+        if changed:
+            import warnings
+            warnings.warn("comfyui-vrgamedevgirl_amd: the input frames of a deferred node were written between the node's call and the "
+                          "moment its result was first used; the result is computed from their CURRENT content (node inputs are shared "
+                          "cached outputs and must not be written; VRGDG_DEFER_GRAPH=0 runs every node when it is called)", RuntimeWarning)
+
+
+def _inference_of(t: torch.Tensor) -> bool:
+    try:
+        return bool(t.is_inference())
+    except Exception:
+        return False
+
 
 class _Pending:
-    """The device pieces of a result whose host copy has not been made yet."""
+    """What stands behind a LazyFrames whose frames are not in its buffer yet: a recipe that has not run, or -- once it has run into HBM, or
+    for a result the pipeline left there -- the device pieces that have not been copied to the host."""
 
-    def __init__(self, host: torch.Tensor, device: torch.device, pieces, nbytes: int, queued=None):
+    def __init__(self, host: torch.Tensor, device: torch.device, pieces=None, nbytes: int = 0, queued=None, recipe=None):
         self.host, self.device, self.pieces, self.nbytes = host, device, pieces, nbytes
-        self.queued = list(queued) if queued is not None else [None] * len(pieces)     # per piece: the event of a copy already queued, or None
+        self.queued = list(queued) if queued is not None else [None] * len(pieces or ())     # per piece: the event of a copy already queued, or None
+        self.recipe = recipe
         self.lock = threading.Lock()
         self.done = False
+        self._on_host = False        # the eager pipeline already wrote every piece to self.host
+        self.tries = 0               # failed timer downloads (re-queued a few times, then reported)
         self.born = time.monotonic()
         self.owner = None            # weak reference to the LazyFrames handed out
 
@@ -349,7 +445,7 @@ class _Pending:
                 _h2d, d2h, _own = _STAGING.side_streams(self.device, 0)
             with torch.cuda.stream(d2h):
                 for (s, e, gpu, ran), ev_q in zip(self.pieces, self.queued):
-                    if ev_q is not None:              # copied while the call was still uploading (see _stream_frames_on)
+                    if ev_q is not None:              # copied while the call was still uploading (see _pipeline)
                         continue
                     d2h.wait_event(ran)
                     self.host[s:e].copy_(gpu, non_blocking=True)
@@ -358,17 +454,77 @@ class _Pending:
                 ev.record(d2h)                        # the stream is in order: behind every copy queued on it earlier as well
             ev.synchronize()
 
-    def materialise(self):
-        with self.lock:                  # (self.host is the plain tensor under the LazyFrames: nothing in here re-enters __torch_function__)
+    def _run_recipe(self, to_host: bool) -> bool:
+        """Run the recipe: `to_host` -- the frames are wanted in self.host (duplex pipeline, eager downloads); else in HBM (pieces).
+        Returns False when the frames were wanted in HBM but do not fit the budget (the caller downloads instead)."""
+        r = self.recipe
+        r.check_source()
+        fn, mult = r.compiled()
+        F = int(self.host.shape[0])
+        with torch.cuda.device(self.device):
+            if self.host.is_cuda:                                     # device-resident graph: the result buffer IS the destination
+                src = r.source if not isinstance(r.source, LazyFrames) else materialise(r.source)
+                fn(src.to(self.device), 0, out=self.host)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.pieces, self.queued, self.nbytes = [(0, F, self.host, ev)], [ev], 0
+                self.recipe = None
+                return True
+            src = r.source
+            if isinstance(src, torch.Tensor) and src.is_cuda and not isinstance(src, LazyFrames):     # device frames in, host frames out
+                gpu = fn(src.to(self.device), 0)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.pieces, self.queued = [(0, F, gpu, ev)], [None]
+                self.nbytes = int(gpu.numel()) * gpu.element_size()
+                self.recipe = None
+                return True
+            lazy = not to_host
+            if lazy and F * self.host[0].numel() * self.host.element_size() > _DEVICE_COPIES._budget(self.device):
+                return False
+            _out, produced, queued, was_lazy, _n = _pipeline([self.device], [fn], src, mult, self.host.dtype, out=self.host, lazy=lazy,
+                                                             cached=r.source_pieces)
+            self.pieces = produced
+            self.queued = queued if was_lazy else [True] * len(produced)       # eager pipeline: every piece is on the host already
+            self.nbytes = sum(int(g.numel()) * g.element_size() for _, _, g, _ in produced)
+            self.recipe = None
+            if not was_lazy:
+                self._on_host = True
+            return True
+
+    def device_pieces(self):
+        """The frames as device pieces [(s, e, gpu, ran_event)] without touching the host buffer; None if they cannot be held in HBM."""
+        with _STAGING.lock, self.lock:            # (lock order: the staging lock first, everywhere)
+            if self.done and self.host.is_cuda:
+                return self.pieces
             if self.done:
+                return None
+            with torch.inference_mode(_inference_of(self.host)):
+                if self.recipe is not None and not self._run_recipe(to_host=False):
+                    return None
+            if self.host.is_cuda:
+                self.done = True
+            return self.pieces
+
+    def materialise(self):
+        with _STAGING.lock, self.lock:   # (self.host is the plain tensor under the LazyFrames: nothing in here re-enters __torch_function__)
+            if self.done:
+                _LAZY.forget(self)
                 return
-            self._download()
+            # the buffer was created where the node ran -- under ComfyUI inside torch.inference_mode() -- and is written here, possibly from
+            # the timer's or a consumer's thread: in-place writes to an inference tensor need inference mode (ADVICE round 5)
+            with torch.inference_mode(_inference_of(self.host)):
+                if self.recipe is not None:
+                    self._run_recipe(to_host=True)
+                if not self.host.is_cuda and not self._on_host:
+                    self._download()
             self.done = True
         _LAZY.forget(self)
         owner = self.owner() if self.owner is not None else None
         if owner is not None:
             owner._vrg_pending = None    # an ordinary tensor from here on -- BEFORE the cache looks at it (its stamp reads the data through torch)
-            _DEVICE_COPIES.remember(owner, self.device, self.pieces)       # ... and an ordinary, validated device copy
+            if not self.host.is_cuda and self.pieces:
+                _DEVICE_COPIES.remember(owner, self.device, self.pieces)       # ... and an ordinary, validated device copy
 
 
 class _LazyRegistry:
@@ -376,15 +532,20 @@ class _LazyRegistry:
         self.lock = threading.RLock()
         self.pending = []            # oldest first
         self._timer = None
+        self._timer_due = 0.0
         self.downloads_skipped = 0   # results consumed on the device and never downloaded (statistics for tests / tools)
+        self.fused = 0               # nodes appended to the recipe of their input instead of run on their own (deferred graph fusion)
 
     def add(self, p: "_Pending", budget: int):
         over = []
         with self.lock:
             self.pending.append(p)
             total = sum(q.nbytes for q in self.pending)
-            while len(self.pending) > 1 and total > budget:
-                q = self.pending.pop(0)
+            while total > budget:        # the oldest results that HOLD device memory go to the host (a recipe that has not run holds none)
+                q = next((q for q in self.pending if q.nbytes > 0 and q is not p), None)
+                if q is None:
+                    break
+                self.pending.remove(q)
                 total -= q.nbytes
                 over.append(q)
             self._arm()
@@ -396,25 +557,58 @@ class _LazyRegistry:
             if p in self.pending:
                 self.pending.remove(p)
 
+    def held_bytes(self) -> int:
+        with self.lock:
+            return sum(q.nbytes for q in self.pending)
+
+    def flush(self) -> int:
+        """Send every pending result that holds device memory to the host now (release_device_copies, a call short of memory)."""
+        with self.lock:
+            held = [q for q in self.pending if q.nbytes > 0 and (q.owner is None or q.owner() is not None)]
+        n = 0
+        for q in held:
+            try:
+                n += q.nbytes
+                q.materialise()
+            except Exception:
+                pass
+        return n
+
     def _arm(self):
-        if LAZY_SECONDS <= 0 or self._timer is not None or not self.pending:
+        if LAZY_SECONDS <= 0 or not self.pending:
             return
+        due = time.monotonic() + LAZY_SECONDS
+        if self._timer is not None:
+            if self._timer_due <= due + 1e-3:
+                return
+            self._timer.cancel()         # armed for a later moment than the current setting asks for
         t = threading.Timer(LAZY_SECONDS, self._sweep)
         t.daemon = True
-        self._timer = t
+        self._timer, self._timer_due = t, due
         t.start()
 
     def _sweep(self):
         with self.lock:
-            self._timer = None
+            if self._timer is not None and threading.current_thread() is not self._timer and self._timer_due > time.monotonic() + 1e-3:
+                pass                     # (a direct call -- tests, flush paths -- leaves the armed timer alone)
+            else:
+                self._timer = None
             now = time.monotonic()
-            due = [p for p in self.pending if now - p.born >= LAZY_SECONDS and (p.owner is None or p.owner() is not None)]
-            self.pending = [p for p in self.pending if p not in due and (p.owner is None or p.owner() is not None)]
+            self.pending = [p for p in self.pending if p.owner is None or p.owner() is not None]
+            due = [p for p in self.pending if now - p.born >= LAZY_SECONDS]
         for p in due:
             try:
-                p.materialise()
-            except Exception:
-                pass
+                p.materialise()              # (removes itself from the registry when it succeeds)
+            except Exception as exc:
+                # ADVICE round 5: a failed timer download used to be swallowed AND forgotten -- its device memory stayed held and uncounted.
+                # It stays registered (and counted), is retried by the next sweeps, and is reported once it has failed three times; the
+                # owner's first host use raises the real error.
+                p.tries += 1
+                p.born = now
+                if p.tries == 3:
+                    import warnings
+                    warnings.warn(f"comfyui-vrgamedevgirl_amd: a deferred result could not be brought to the host by the timer "
+                                  f"({type(exc).__name__}: {exc}); it is kept pending", RuntimeWarning)
         with self.lock:
             self._arm()
 
@@ -499,17 +693,19 @@ def pending_of(t):
 
 
 def on_device(t: torch.Tensor, device: torch.device) -> torch.Tensor:
-    """`t` on `device` (fp32 frames): the pending device pieces of a LazyFrames of that device as they are (no download, no upload),
-    anything else through `.to()`."""
+    """`t` on `device` (fp32 frames): the pending device pieces of a LazyFrames of that device as they are (no download, no upload; a
+    recipe that has not run runs into HBM), anything else through `.to()`."""
     p = pending_of(t)
     if p is not None and p.device == device and t.dtype == torch.float32:
-        cur = torch.cuda.current_stream(device)
-        parts = []
-        for _s, _e, gpu, ran in p.pieces:
-            cur.wait_event(ran)
-            parts.append(gpu)
-        _LAZY.downloads_skipped += 1
-        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        pieces = p.device_pieces()
+        if pieces:
+            cur = torch.cuda.current_stream(device)
+            parts = []
+            for _s, _e, gpu, ran in pieces:
+                cur.wait_event(ran)
+                parts.append(gpu)
+            _LAZY.downloads_skipped += 1
+            return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
     return t.to(device=device, dtype=torch.float32)
 
 
@@ -538,10 +734,100 @@ def piece_frames(n_frames: int, frame_bytes: int, multiple_of: int = 1) -> int:
     return min(per, max(n_frames, 1))
 
 
-def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None, fn_for_device=None) -> torch.Tensor:
+#: floats between two NaNs inside a poisoned frame (256 KiB) -- see _poison
+_POISON_STRIDE = 1 << 16
+
+
+def _poison(buf: torch.Tensor):
+    """A result buffer nobody has filled yet must not look like an image: torch's caching host allocator hands back page-locked blocks with the
+    frames of an EARLIER result in them, and native code that reads a LazyFrames' memory without any torch call would take them for this
+    one.  fp32 buffers get quiet NaNs: the first cache line (16 floats) of every frame, one float every 256 KiB
+    inside it, and the buffer's first and last 4 KiB -- any whole-frame read sees NaNs until the download has overwritten them.  Sparse
+    on purpose (round 6, tools/diag_lazy_graph.py --inside): one NaN per 4 KiB page -- 390,000 scattered stores for 16 4K frames -- cost up
+    to 60 ms, and the download that followed ran at half speed (89 instead of 42 ms): every one of those lines is dirty in a CPU cache
+    when the GPU's DMA writes arrive.  A few thousand lines cost nothing measurable."""
+    if buf.dtype != torch.float32 or buf.device.type != "cpu" or buf.numel() == 0:
+        return
+    nan = float("nan")
+    flat = buf.view(-1)
+    frames = buf.view(int(buf.shape[0]), -1) if buf.ndim >= 2 else flat.view(1, -1)
+    frames[:, :16] = nan
+    if frames.shape[1] > _POISON_STRIDE:
+        frames[:, ::_POISON_STRIDE] = nan
+    flat[:1024] = nan
+    flat[-1024:] = nan
+
+
+def _result_buffer(shape, dtype, nbytes: int):
+    """(page-locked?, buffer) for a host result of `nbytes`: page-locked when it fits PIN_LIMIT_BYTES and the host grants it."""
+    if nbytes <= PIN_LIMIT_BYTES:
+        try:
+            return True, torch.empty(shape, dtype=dtype, pin_memory=True)
+        except RuntimeError:                  # the host refused to page-lock that much: pageable result + ring
+            pass
+    return False, torch.empty(shape, dtype=dtype)
+
+
+def _wrap_lazy(out: torch.Tensor, p: "_Pending", budget: int) -> "LazyFrames":
+    import weakref
+    res = LazyFrames(out, p)
+    # a result dropped unread takes its device pieces with it at once (the registry's reference is the only other one)
+    p.owner = weakref.ref(res, lambda _r, pr=weakref.ref(p): _LAZY.forget(pr()) if pr() is not None else None)
+    _LAZY.add(p, budget)
+    return res
+
+
+def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device: torch.device):
+    """The deferred form of one node call (see "Deferred graph fusion" above): a LazyFrames over a fresh result buffer whose recipe is the
+    input's recipe + `stage` where that is one fused chain, else [`stage`] on top of the input.  None: this call is not deferred (switch
+    off, several devices, frames that are not [F,H,W,C] fp32, a result too large to page-lock) -- the caller runs it now."""
+    if not (DEFER_GRAPH and LAZY_DOWNLOAD and DEVICE_CACHE_BYTES > 0):
+        return None
+    if images.ndim != 4 or images.dtype != torch.float32 or int(images.shape[0]) == 0 or not images.is_contiguous():
+        return None
+    src_cuda = images.is_cuda
+    if src_cuda and images.device != device:
+        return None
+    if not src_cuda and images.device.type != "cpu":
+        return None
+    if out_device.type == "cuda":
+        if not src_cuda or torch.device(out_device.type, out_device.index if out_device.index is not None else device.index) != device:
+            return None                       # host frames in, device frames out: uploaded and run now
+    frame_bytes = 4
+    for d in images.shape[1:]:
+        frame_bytes *= int(d)
+    nbytes = int(images.shape[0]) * frame_bytes
+    p_in = pending_of(images)
+    recipe = None
+    if p_in is not None and p_in.device == device and p_in.recipe is not None and p_in.host.device.type == out_device.type:
+        with p_in.lock:
+            r = p_in.recipe                    # (may have run meanwhile on the timer's thread)
+            if r is not None and r.can_append(stage, frame_bytes):
+                recipe = _Recipe(r.source, r.stages + [stage], r.source_pieces)
+                _LAZY.fused += 1
+    if p_in is not None and p_in.device == device:
+        _LAZY.downloads_skipped += 1           # this node takes its frames on the device: its input is not downloaded for it
+    if recipe is None:
+        pieces = None
+        if p_in is None and not src_cuda:
+            pieces = _DEVICE_COPIES.lookup(images, device)      # an unchanged, already downloaded result of this pack: still in HBM
+        recipe = _Recipe(images, [stage], pieces)
+    if out_device.type == "cuda":
+        out = torch.empty(tuple(images.shape), dtype=torch.float32, device=device)
+    else:
+        pinned, out = _result_buffer(tuple(images.shape), torch.float32, nbytes)
+        if not pinned:
+            return None
+        _poison(out)
+    p = _Pending(out, device, recipe=recipe)
+    return _wrap_lazy(out, p, _DEVICE_COPIES._budget(device))
+
+
+def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None, fn_for_device=None, stage: "Stage" = None) -> torch.Tensor:
     """Run ``fn(gpu_frames, first_frame) -> gpu_frames`` over a CPU-resident batch with copies and kernels overlapped.
     Returns a CPU tensor shaped like `images` (dtype `out_dtype`, default the input's), page-locked when it fits
-    PIN_LIMIT_BYTES.
+    PIN_LIMIT_BYTES.  With `stage` (a node that says what it is: deferred graph fusion) and one compute device the call is recorded and
+    runs at the result's first use -- see `defer`.
 
     Several GPUs (``compute_devices()``, VRGDG_DEVICES): the pieces -- whole multiples of `multiple_of` frames -- go round-robin to
     the devices, each with its own upload / compute / download streams, and are SUBMITTED in frame order from this host thread, so
@@ -551,6 +837,10 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
     devices = compute_devices() if fn_for_device is not None else [compute_device()]
     if len(devices) == 1:
         dev = devices[0]
+        if stage is not None and out_dtype in (None, torch.float32):
+            res = defer(images, dev, stage, torch.device("cpu"))
+            if res is not None:
+                return res
         with torch.cuda.device(dev):          # kernels, side streams and events all on the compute device
             return _stream_frames_on([dev], [fn if fn_for_device is None else fn_for_device(dev)], images, multiple_of, out_dtype)
     fns, made = [], {}
@@ -628,8 +918,27 @@ def _event():
 
 
 def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
-    pend_in = pending_of(images) if len(devices) == 1 else None      # a result of a previous node that is still on the GPU only
-    if pend_in is not None and (pend_in.device != devices[0] or not images.is_contiguous()):
+    """The pipeline run NOW (a node that was not deferred): the result as a LazyFrames whose download is pending where that applies."""
+    out, produced, queued, lazy_out, n_lanes = _pipeline(devices, fns, images, multiple_of, out_dtype)
+    if lazy_out:
+        F = int(out.shape[0])
+        p = _Pending(out, devices[0], produced, F * out[0].numel() * out.element_size(), queued)
+        return _wrap_lazy(out, p, _DEVICE_COPIES._budget(devices[0]))
+    if n_lanes == 1 and produced:
+        _DEVICE_COPIES.remember(out, devices[0], produced)       # the next node of this pack may be handed `out`: its frames are still in HBM
+    return out
+
+
+def _pipeline(devices, fns, images, multiple_of, out_dtype, out=None, lazy=None, cached=None):
+    """Upload / run / download `images` in pieces.  `out`: the caller's result buffer (else one is allocated); `lazy`: True / False forces
+    the result to stay in HBM (pieces, downloads not queued unless the call uploads) / to be downloaded as the pieces finish, None decides
+    as a node call does; `cached`: device pieces of `images` the caller already holds.  Returns (out, device pieces [(s, e, gpu, ran)],
+    per-piece download events or None, lazy?, lanes)."""
+    pend_in = pending_of(images) if len(devices) == 1 and cached is None else None      # a result of a previous node that is still on the GPU only
+    if pend_in is not None and (pend_in.device != devices[0] or not images.is_contiguous() or images.is_cuda):
+        pend_in = None
+    in_pieces = pend_in.device_pieces() if pend_in is not None else None                 # (a recipe that has not run runs into HBM here)
+    if pend_in is not None and not in_pieces:
         pend_in = None
     if pend_in is None:
         images = materialise(images).contiguous()
@@ -639,35 +948,36 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
     for d in images.shape[1:]:
         frame_numel *= int(d)
     if F == 0 or frame_numel == 0:
-        return torch.empty(tuple(images.shape), dtype=out_dtype)
+        return (out if out is not None else torch.empty(tuple(images.shape), dtype=out_dtype)), [], [], False, 1
     out_fb = frame_numel * torch.empty((), dtype=out_dtype).element_size()
     in_fb = frame_numel * images.element_size()
-    pin_out = F * out_fb <= PIN_LIMIT_BYTES
-    try:
-        out = torch.empty(tuple(images.shape), dtype=out_dtype, pin_memory=pin_out)
-    except RuntimeError:                      # the host refused to page-lock that much: pageable result + ring
-        if not pin_out:
-            raise
-        pin_out = False
-        out = torch.empty(tuple(images.shape), dtype=out_dtype)
+    if out is not None:
+        pin_out = out.is_pinned()
+    else:
+        pin_out, out = _result_buffer(tuple(images.shape), out_dtype, F * out_fb)
     per = piece_frames(F, max(in_fb, out_fb), multiple_of)
     pieces = [(s, min(F, s + per)) for s in range(0, F, per)]
     n_lanes = min(len(devices), len(pieces))
     if pend_in is not None:
-        cached = pend_in.pieces                # never downloaded, so nobody can have changed it: the frames are read where they are
+        cached = in_pieces                     # never downloaded, so nobody can have changed it: the frames are read where they are
         _LAZY.downloads_skipped += 1
-    else:
+    elif cached is None:
         cached = _DEVICE_COPIES.lookup(images, devices[0]) if n_lanes == 1 else None      # an unchanged result of a previous node: already in HBM
     # the result stays on the GPU until somebody asks for it on the host (LazyFrames): one lane, page-locked result, inside the budget
-    lazy_out = (LAZY_DOWNLOAD and n_lanes == 1 and pin_out and DEVICE_CACHE_BYTES > 0 and F * out_fb <= _DEVICE_COPIES._budget(devices[0]))
-    if _DEVICE_COPIES.held_bytes():
+    lazy_out = (n_lanes == 1 and pin_out and F * out_fb <= _DEVICE_COPIES._budget(devices[0]) and
+                (lazy if lazy is not None else (LAZY_DOWNLOAD and DEVICE_CACHE_BYTES > 0)))
+    if lazy_out and lazy is None:
+        _poison(out)
+    if _DEVICE_COPIES.held_bytes() or _LAZY.held_bytes():
         # device copies kept for adjacent nodes never stand in the way of a call's own pipeline (pieces in flight: input + output +
         # the kernels' workspaces): short of memory, they go first
         try:
             free, _total = torch.cuda.mem_get_info(devices[0])
             free += torch.cuda.memory_reserved(devices[0]) - torch.cuda.memory_allocated(devices[0])
             if free < 4 * PIPE_DEPTH * per * (in_fb + out_fb):
-                release_device_copies()
+                _DEVICE_COPIES.clear()
+                if pend_in is None and cached is None:         # (not while this very call reads such pieces)
+                    _LAZY.flush()
         except Exception:
             pass
     produced, queued = [], []
@@ -771,14 +1081,4 @@ def _stream_frames_on(devices, fns, images, multiple_of, out_dtype):
             for r in in_rings:
                 r.drain()
         # whatever follows on the caller's stream sees the other lanes' kernels finished (their results are already on the host)
-    if lazy_out:
-        import weakref
-        p = _Pending(out, devices[0], produced, F * out_fb, queued)
-        res = LazyFrames(out, p)
-        # a result dropped unread takes its device pieces with it at once (the registry's reference is the only other one)
-        p.owner = weakref.ref(res, lambda _r, pr=weakref.ref(p): _LAZY.forget(pr()) if pr() is not None else None)
-        _LAZY.add(p, _DEVICE_COPIES._budget(devices[0]))
-        return res
-    if n_lanes == 1 and produced:
-        _DEVICE_COPIES.remember(out, devices[0], produced)       # the next node of this pack may be handed `out`: its frames are still in HBM
-    return out
+    return out, produced, queued, lazy_out, n_lanes

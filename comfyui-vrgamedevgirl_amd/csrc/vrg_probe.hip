@@ -381,7 +381,9 @@ __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, 
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
     const f2 pb = {b, b}, pc = {c, c};
-    const uint32_t k = 0xD2511F53u;
+    const uint32_t k = 0xD2511F53u, k3 = 0x9E3779B9u;
+    const float sk = __builtin_amdgcn_readfirstlane((int)iters) > 2 ? 0.9997f : 1.0f;
+    const uint64_t mask = __builtin_amdgcn_readfirstlane((int)iters) > 3 ? 0x5555aaaa0f0ff0f0ull : 0x1ull;
     for (int32_t i = 0; i < iters; ++i) {
         if (MODE == 0) {
             VRG_REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -462,6 +464,131 @@ __global__ __launch_bounds__(256) void k_dbg_valu_rate(float* __restrict__ out, 
         } else if (MODE == 21) {
             VRG_REP4(asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %0, %0, %9\n v_mul_f32 %1, %1, %8\n v_add_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_add_f32 %2, %2, %9\n v_mul_f32 %3, %3, %8\n v_add_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_add_f32 %4, %4, %9\n v_mul_f32 %5, %5, %8\n v_add_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_add_f32 %6, %6, %9\n v_mul_f32 %7, %7, %8\n v_add_f32 %7, %7, %9"
                                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 30) {
+            VRG_REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 31) {
+            VRG_REP8(asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 32) {
+            VRG_REP8(asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 33) {
+            VRG_REP8(asm volatile("v_med3_f32 %0, %0, %8, %9\n v_med3_f32 %1, %1, %8, %9\n v_med3_f32 %2, %2, %8, %9\n v_med3_f32 %3, %3, %8, %9\n v_med3_f32 %4, %4, %8, %9\n v_med3_f32 %5, %5, %8, %9\n v_med3_f32 %6, %6, %8, %9\n v_med3_f32 %7, %7, %8, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 34) {
+            VRG_REP8(asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %9\n v_fmamk_f32 %1, %1, 0x3f7fbe77, %9\n v_fmamk_f32 %2, %2, 0x3f7fbe77, %9\n v_fmamk_f32 %3, %3, 0x3f7fbe77, %9\n v_fmamk_f32 %4, %4, 0x3f7fbe77, %9\n v_fmamk_f32 %5, %5, 0x3f7fbe77, %9\n v_fmamk_f32 %6, %6, 0x3f7fbe77, %9\n v_fmamk_f32 %7, %7, 0x3f7fbe77, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 35) {
+            VRG_REP8(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 36) {
+            VRG_REP8(asm volatile("v_add_f32_e64 %0, %0, %9 clamp\n v_add_f32_e64 %1, %1, %9 clamp\n v_add_f32_e64 %2, %2, %9 clamp\n v_add_f32_e64 %3, %3, %9 clamp\n v_add_f32_e64 %4, %4, %9 clamp\n v_add_f32_e64 %5, %5, %9 clamp\n v_add_f32_e64 %6, %6, %9 clamp\n v_add_f32_e64 %7, %7, %9 clamp"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 37) {
+            VRG_REP8(asm volatile("v_cmp_u_f32 vcc, %0, %8\n v_cmp_u_f32 vcc, %1, %8\n v_cmp_u_f32 vcc, %2, %8\n v_cmp_u_f32 vcc, %3, %8\n v_cmp_u_f32 vcc, %4, %8\n v_cmp_u_f32 vcc, %5, %8\n v_cmp_u_f32 vcc, %6, %8\n v_cmp_u_f32 vcc, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 38) {
+            VRG_REP8(asm volatile("v_cmp_class_f32 vcc, %0, %8\n v_cmp_class_f32 vcc, %1, %8\n v_cmp_class_f32 vcc, %2, %8\n v_cmp_class_f32 vcc, %3, %8\n v_cmp_class_f32 vcc, %4, %8\n v_cmp_class_f32 vcc, %5, %8\n v_cmp_class_f32 vcc, %6, %8\n v_cmp_class_f32 vcc, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 40) {
+            VRG_REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %9, %10\n v_cndmask_b32_e64 %1, %1, %9, %10\n v_cndmask_b32_e64 %2, %2, %9, %10\n v_cndmask_b32_e64 %3, %3, %9, %10\n v_cndmask_b32_e64 %4, %4, %9, %10\n v_cndmask_b32_e64 %5, %5, %9, %10\n v_cndmask_b32_e64 %6, %6, %9, %10\n v_cndmask_b32_e64 %7, %7, %9, %10"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 41) {
+            VRG_REP8(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 42) {
+            VRG_REP8(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 43) {
+            VRG_REP8(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 44) {
+            VRG_REP8(asm volatile("v_cos_f32 %0, %0\n v_cos_f32 %1, %1\n v_cos_f32 %2, %2\n v_cos_f32 %3, %3\n v_cos_f32 %4, %4\n v_cos_f32 %5, %5\n v_cos_f32 %6, %6\n v_cos_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 45) {
+            VRG_REP8(asm volatile("v_rndne_f32 %0, %0\n v_rndne_f32 %1, %1\n v_rndne_f32 %2, %2\n v_rndne_f32 %3, %3\n v_rndne_f32 %4, %4\n v_rndne_f32 %5, %5\n v_rndne_f32 %6, %6\n v_rndne_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 46) {
+            VRG_REP8(asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3\n v_floor_f32 %4, %4\n v_floor_f32 %5, %5\n v_floor_f32 %6, %6\n v_floor_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 47) {
+            VRG_REP8(asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3\n v_fract_f32 %4, %4\n v_fract_f32 %5, %5\n v_fract_f32 %6, %6\n v_fract_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 48) {
+            VRG_REP8(asm volatile("v_ldexp_f32 %0, %0, %8\n v_ldexp_f32 %1, %1, %8\n v_ldexp_f32 %2, %2, %8\n v_ldexp_f32 %3, %3, %8\n v_ldexp_f32 %4, %4, %8\n v_ldexp_f32 %5, %5, %8\n v_ldexp_f32 %6, %6, %8\n v_ldexp_f32 %7, %7, %8"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 49) {
+            VRG_REP8(asm volatile("v_frexp_mant_f32 %0, %0\n v_frexp_mant_f32 %1, %1\n v_frexp_mant_f32 %2, %2\n v_frexp_mant_f32 %3, %3\n v_frexp_mant_f32 %4, %4\n v_frexp_mant_f32 %5, %5\n v_frexp_mant_f32 %6, %6\n v_frexp_mant_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 50) {
+            VRG_REP8(asm volatile("v_cvt_i32_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_cvt_i32_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n v_cvt_i32_f32 %4, %4\n v_cvt_i32_f32 %5, %5\n v_cvt_i32_f32 %6, %6\n v_cvt_i32_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 51) {
+            VRG_REP8(asm volatile("v_cvt_u32_f32 %0, %0\n v_cvt_u32_f32 %1, %1\n v_cvt_u32_f32 %2, %2\n v_cvt_u32_f32 %3, %3\n v_cvt_u32_f32 %4, %4\n v_cvt_u32_f32 %5, %5\n v_cvt_u32_f32 %6, %6\n v_cvt_u32_f32 %7, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 52) {
+            VRG_REP8(asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 53) {
+            VRG_REP8(asm volatile("v_add_f32 %0, %0, %8\n s_nop 1\n v_add_f32 %1, %1, %8\n s_nop 1\n v_add_f32 %2, %2, %8\n s_nop 1\n v_add_f32 %3, %3, %8\n s_nop 1\n v_add_f32 %4, %4, %8\n s_nop 1\n v_add_f32 %5, %5, %8\n s_nop 1\n v_add_f32 %6, %6, %8\n s_nop 1\n v_add_f32 %7, %7, %8\n s_nop 1"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c), "s"(mask) : "vcc");)
+        } else if (MODE == 60) {
+            VRG_REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 61) {
+            VRG_REP8(asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 62) {
+            VRG_REP8(asm volatile("v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 3, %3\n v_lshlrev_b32 %4, 3, %4\n v_lshlrev_b32 %5, 3, %5\n v_lshlrev_b32 %6, 3, %6\n v_lshlrev_b32 %7, 3, %7"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 63) {
+            VRG_REP8(asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n v_lshrrev_b32 %4, 3, %4\n v_lshrrev_b32 %5, 3, %5\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 3, %7"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 64) {
+            VRG_REP8(asm volatile("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 65) {
+            VRG_REP8(asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 66) {
+            VRG_REP8(asm volatile("v_lshl_add_u32 %0, %0, 2, %8\n v_lshl_add_u32 %1, %1, 2, %8\n v_lshl_add_u32 %2, %2, 2, %8\n v_lshl_add_u32 %3, %3, 2, %8\n v_lshl_add_u32 %4, %4, 2, %8\n v_lshl_add_u32 %5, %5, 2, %8\n v_lshl_add_u32 %6, %6, 2, %8\n v_lshl_add_u32 %7, %7, 2, %8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 67) {
+            VRG_REP8(asm volatile("v_bfe_u32 %0, %0, 3, 8\n v_bfe_u32 %1, %1, 3, 8\n v_bfe_u32 %2, %2, 3, 8\n v_bfe_u32 %3, %3, 3, 8\n v_bfe_u32 %4, %4, 3, 8\n v_bfe_u32 %5, %5, 3, 8\n v_bfe_u32 %6, %6, 3, 8\n v_bfe_u32 %7, %7, 3, 8"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 68) {
+            VRG_REP8(asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 69) {
+            VRG_REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %8, vcc\n v_addc_co_u32 %1, vcc, %1, %8, vcc\n v_addc_co_u32 %2, vcc, %2, %8, vcc\n v_addc_co_u32 %3, vcc, %3, %8, vcc\n v_addc_co_u32 %4, vcc, %4, %8, vcc\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_addc_co_u32 %6, vcc, %6, %8, vcc\n v_addc_co_u32 %7, vcc, %7, %8, vcc"
+                                  : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(k), "v"(k3), "s"(mask) : "vcc");)
+        } else if (MODE == 72) {
+            VRG_REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 73) {
+            VRG_REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 55) {
+            VRG_REP8(asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                                  "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sk));)
+        } else if (MODE == 56) {
+            VRG_REP8(asm volatile("v_mul_f32 %0, 0x3f7fbe77, %0\n v_mul_f32 %1, 0x3f7fbe77, %1\n v_mul_f32 %2, 0x3f7fbe77, %2\n v_mul_f32 %3, 0x3f7fbe77, %3\n"
+                                  "v_mul_f32 %4, 0x3f7fbe77, %4\n v_mul_f32 %5, 0x3f7fbe77, %5\n v_mul_f32 %6, 0x3f7fbe77, %6\n v_mul_f32 %7, 0x3f7fbe77, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 57) {
+            VRG_REP8(asm volatile("v_mul_f32 %0, 0.5, %0\n v_mul_f32 %1, 0.5, %1\n v_mul_f32 %2, 0.5, %2\n v_mul_f32 %3, 0.5, %3\n"
+                                  "v_mul_f32 %4, 0.5, %4\n v_mul_f32 %5, 0.5, %5\n v_mul_f32 %6, 0.5, %6\n v_mul_f32 %7, 0.5, %7"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 39) {
+            VRG_REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %9, vcc\n v_cndmask_b32 %1, %1, %9, vcc\n v_cndmask_b32 %2, %2, %9, vcc\n"
+                                  "v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %9, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %9, vcc"
+                                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");)
+        } else if (MODE == 54) {
+            VRG_REP8(asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9\n"
+                                  "v_readlane_b32 s20, %4, 3\n v_readlane_b32 s21, %5, 5\n v_readlane_b32 s22, %6, 7\n v_readlane_b32 s23, %7, 9"
+                                  : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7) : "s20", "s21", "s22", "s23");)
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) +
@@ -525,13 +652,12 @@ int vrg_selftest_lanes(float* out128, void* stream) {
 
 
 int vrg_debug_valu_rate(float* out, int32_t blocks, int32_t iters, int32_t mode, void* stream) {
-    if (!out || blocks <= 0 || iters <= 0 || mode < 0 || mode > 21) return VRG_ERR_BAD_ARG;
+    if (!out || blocks <= 0 || iters <= 0 || mode < 0) return VRG_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
 #define VRG_VALU_CASE(M) case M: hipLaunchKernelGGL(vrg::k_dbg_valu_rate<M>, dim3(blocks), dim3(256), 0, st, out, iters); break;
     switch (mode) {
-        VRG_VALU_CASE(0) VRG_VALU_CASE(1) VRG_VALU_CASE(2) VRG_VALU_CASE(3) VRG_VALU_CASE(4) VRG_VALU_CASE(5) VRG_VALU_CASE(6) VRG_VALU_CASE(7)
-        VRG_VALU_CASE(8) VRG_VALU_CASE(9) VRG_VALU_CASE(10) VRG_VALU_CASE(11) VRG_VALU_CASE(12) VRG_VALU_CASE(13) VRG_VALU_CASE(14)
-        VRG_VALU_CASE(15) VRG_VALU_CASE(16) VRG_VALU_CASE(17) VRG_VALU_CASE(18) VRG_VALU_CASE(19) VRG_VALU_CASE(20) VRG_VALU_CASE(21)
+        VRG_VALU_CASE(0) VRG_VALU_CASE(1) VRG_VALU_CASE(2) VRG_VALU_CASE(3) VRG_VALU_CASE(4) VRG_VALU_CASE(5) VRG_VALU_CASE(6) VRG_VALU_CASE(7) VRG_VALU_CASE(8) VRG_VALU_CASE(9) VRG_VALU_CASE(10) VRG_VALU_CASE(11) VRG_VALU_CASE(12) VRG_VALU_CASE(13) VRG_VALU_CASE(14) VRG_VALU_CASE(15) VRG_VALU_CASE(16) VRG_VALU_CASE(17) VRG_VALU_CASE(18) VRG_VALU_CASE(19) VRG_VALU_CASE(20) VRG_VALU_CASE(21) VRG_VALU_CASE(30) VRG_VALU_CASE(31) VRG_VALU_CASE(32) VRG_VALU_CASE(33) VRG_VALU_CASE(34) VRG_VALU_CASE(35) VRG_VALU_CASE(36) VRG_VALU_CASE(37) VRG_VALU_CASE(38) VRG_VALU_CASE(39) VRG_VALU_CASE(40) VRG_VALU_CASE(41) VRG_VALU_CASE(42) VRG_VALU_CASE(43) VRG_VALU_CASE(44) VRG_VALU_CASE(45) VRG_VALU_CASE(46) VRG_VALU_CASE(47) VRG_VALU_CASE(48) VRG_VALU_CASE(49) VRG_VALU_CASE(50) VRG_VALU_CASE(51) VRG_VALU_CASE(52) VRG_VALU_CASE(53) VRG_VALU_CASE(54) VRG_VALU_CASE(55) VRG_VALU_CASE(56) VRG_VALU_CASE(57) VRG_VALU_CASE(60) VRG_VALU_CASE(61) VRG_VALU_CASE(62) VRG_VALU_CASE(63) VRG_VALU_CASE(64) VRG_VALU_CASE(65) VRG_VALU_CASE(66) VRG_VALU_CASE(67) VRG_VALU_CASE(68) VRG_VALU_CASE(69) VRG_VALU_CASE(72) VRG_VALU_CASE(73)
+        default: return VRG_ERR_BAD_ARG;
     }
 #undef VRG_VALU_CASE
     VRG_CHECK_LAUNCH();

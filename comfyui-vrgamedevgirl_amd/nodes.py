@@ -11,7 +11,7 @@ from typing import Tuple
 import torch
 
 from . import ops
-from ._devices import compute_device, frame_groups, intermediate_device, on_device, stream_frames
+from ._devices import Stage, compute_device, defer, frame_groups, intermediate_device, on_device, stream_frames
 
 _IMAGE = ("IMAGE",)
 
@@ -36,18 +36,25 @@ def _frames_bytes(images: torch.Tensor) -> int:
 PIPELINED = True
 
 
-def _run_grouped(images, fn, multiple_of=1, fn_for_device=None):
-    """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame)` returns GPU frames.  `fn_for_device(device)`
-    builds that callable for one of several GPUs (VRGDG_DEVICES, _devices.stream_frames); `fn` is the compute device's."""
+def _run_grouped(images, fn, multiple_of=1, fn_for_device=None, kind=None, fuse=None):
+    """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame, out=None)` returns GPU frames.  `fn_for_device(device)`
+    builds that callable for one of several GPUs (VRGDG_DEVICES, _devices.stream_frames); `fn` is the compute device's.  `kind` / `fuse`:
+    what this node is to ops.fused_chain (grain / lut / colormatch / sharpen and its parameters) -- with them the call may be DEFERRED and
+    fused with the nodes of this pack that follow it in the graph (_devices.defer)."""
     dev = compute_device()
     out_dev = intermediate_device()
+    stage = Stage(kind, fn, multiple_of, fuse) if kind is not None else None
     if images.is_cuda:
+        if stage is not None:
+            res = defer(images, dev, stage, out_dev)
+            if res is not None:
+                return res
         return fn(images.to(dev), 0).to(out_dev)
     if images.dtype != torch.float32:
         images = images.float()
     if PIPELINED and out_dev.type == "cpu" and images.shape[0] > 0:
         # CPU in, CPU out (ComfyUI's default): H2D, kernels and D2H overlapped on three streams
-        return stream_frames(images, fn, multiple_of, fn_for_device=fn_for_device)
+        return stream_frames(images, fn, multiple_of, fn_for_device=fn_for_device, stage=stage)
     pieces = []
     for s, e in frame_groups(images.shape[0], _frames_bytes(images), multiple_of):
         pieces.append(fn(images[s:e].to(dev), s).to(out_dev))
@@ -74,24 +81,28 @@ class FastFilmGrain:
     def apply_grain(self, images, grain_intensity, saturation_mix, batch_size):
         # `batch_size` frames share one torch.randn draw from the device's global generator, exactly like
         # the reference's chunk loop; 0 means one draw for the whole batch.
-        step = batch_size if batch_size > 0 else max(int(images.shape[0]), 1)
-
-        def run(gpu_frames, _first):
-            return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step)
-
+        frames = int(images.shape[0])
+        step = batch_size if batch_size > 0 else max(frames, 1)
         primary = compute_device()
+        many = images.ndim == 4 and frames > 0 and images.shape[-1] == 3 and not ops.oversize_chunks(frames, _frame_numel(images), step)
+        if not many:
+            # RNG chunks torch itself splits (> 2^29 elements), an empty batch, frames the kernels refuse: the generator is consumed inside
+            # ops.film_grain, piece by piece, in submission order
+            def run_now(gpu_frames, _first, out=None):
+                return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step, out=out)
+            return (_run_grouped(images, run_now, multiple_of=step),)
+        # The noise of the WHOLE batch is reserved here, when the node is called -- on the host, from the PRIMARY device's generator, the one
+        # the reference's torch.randn calls would consume, chunk after chunk (nodes.py:46-51) -- and sliced per piece when the piece runs:
+        # the generator moves exactly as the reference's loop moves it whether the pieces run now, later (deferred graph fusion) or on
+        # another GPU (VRGDG_DEVICES).
+        plans = ops.plan_noise(frames, _frame_numel(images), step, primary)
 
-        def run_on(dev):
-            # several GPUs: the noise of every piece is reserved -- in submission order, on the host -- from the PRIMARY device's
-            # generator, the one the reference's torch.randn calls would consume; the piece itself may run on any of the GPUs
-            def run_d(gpu_frames, _first):
-                n = int(gpu_frames.shape[0])
-                plans = ops.plan_noise(n, int(gpu_frames[0].numel()), step, primary)
-                return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step, plans=plans)
-            return run_d
+        def run(gpu_frames, first, out=None):
+            return ops.film_grain(gpu_frames, grain_intensity, saturation_mix, chunk_frames=step,
+                                  plans=ops.slice_plans(plans, first, int(gpu_frames.shape[0])), out=out)
 
-        many = images.ndim == 4 and images.shape[0] > 0 and not ops.oversize_chunks(int(images.shape[0]), _frame_numel(images), step)
-        return (_run_grouped(images, run, multiple_of=step, fn_for_device=run_on if many else None),)
+        fuse = {"I": grain_intensity, "s": saturation_mix, "step": step, "plans": plans}
+        return (_run_grouped(images, run, multiple_of=step, fn_for_device=lambda _device: run, kind="grain", fuse=fuse),)
 
 
 class ColorMatchToReference:
@@ -153,9 +164,9 @@ class ColorMatchToReference:
                 return out
             group = n_ref
 
-        def run(gpu_frames, first):
+        def run(gpu_frames, first, out=None):
             return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
-                                   ref_event=ref_ready)
+                                   ref_event=ref_ready, out=out)
 
         def run_on(device):
             if device == dev:
@@ -167,9 +178,12 @@ class ColorMatchToReference:
                                        ref_event=ready_d)
             return run_d
 
+        fuse = None
         if expand is not None:
             images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]
-        return (_run_grouped(images, run, multiple_of=group, fn_for_device=run_on),)
+        elif images.ndim == 4 and images.shape[-1] == 3:
+            fuse = {"ref_ms": ref_ms, "k": match_strength, "calls_of": calls_of, "ref_event": ref_ready}
+        return (_run_grouped(images, run, multiple_of=group, fn_for_device=run_on, kind="colormatch" if fuse else None, fuse=fuse),)
 
 
 class _Sharpen:
@@ -194,10 +208,11 @@ class _Sharpen:
         if use_gpu and self._RGB_ONLY_ON_GPU_FLAG and images.shape[-1] != 3:
             raise RuntimeError(f"Given groups=3, expected input to have 3 channels, but got {images.shape[-1]} channels instead")
 
-        def run(gpu_frames, _first):
-            return ops.stencil3x3(gpu_frames, self._OP, strength, zero_border=bool(use_gpu))
+        def run(gpu_frames, _first, out=None):
+            return ops.stencil3x3(gpu_frames, self._OP, strength, zero_border=bool(use_gpu), out=out)
 
-        return (_run_grouped(images, run, fn_for_device=lambda _device: run),)
+        fuse = {"op": self._OP, "strength": strength, "zero": bool(use_gpu)} if images.ndim == 4 and images.shape[-1] == 3 else None
+        return (_run_grouped(images, run, fn_for_device=lambda _device: run, kind="sharpen" if fuse else None, fuse=fuse),)
 
 
 class FastUnsharpSharpen(_Sharpen):

@@ -62,7 +62,7 @@ def assert_bit_equal(got, want, what=""):
 def test_native_library_is_loaded(pkg):
     from comfyui_vrgamedevgirl_amd import _hip
     lib = _hip.lib()
-    assert lib.vrg_abi_version() == _hip.ABI_VERSION == 7
+    assert lib.vrg_abi_version() == _hip.ABI_VERSION == 8
     with open("/proc/self/maps") as fh:
         assert any("libvrgdg_hip.so" in line for line in fh), "HIP extension not mapped into the process"
     import ctypes as C
@@ -1689,6 +1689,8 @@ def test_lazy_download_four_nodes_in_a_graph_cross_pcie_twice(pkg, ops, dev, mon
     torch.manual_seed(11)
     unread = nodes.FastFilmGrain().apply_grain(x, 0.05, 0.4, 2)[0]
     p = _devices.pending_of(unread)
+    assert p.recipe is not None and p.nbytes == 0                              # (round 6: deferred -- nothing has run, no HBM is held yet)
+    assert p.device_pieces() and p.recipe is None and p.nbytes > 0             # a consumer of this pack asked for the frames in HBM
     before = torch.cuda.memory_allocated(dev)
     del unread
     gc.collect()

@@ -45,17 +45,23 @@ def measure(frames=16, H=2160, W=3840, reps=3, warmup=2):
     for name, fn in cases:
         for label, src in (("pageable input", x), ("page-locked input", xp)):
             runs.append((name, label, (lambda f=fn, s_=src: f(s_))))
-    def chain_eager(t):
-        old = _devices.LAZY_DOWNLOAD
-        _devices.LAZY_DOWNLOAD = False
+    def chain_with(t, **flags):
+        old = {k: getattr(_devices, k) for k in flags}
+        for k, v in flags.items():
+            setattr(_devices, k, v)
         try:
-            return chain(t)
+            r = chain(t)
+            _devices.materialise(r)
+            return r
         finally:
-            _devices.LAZY_DOWNLOAD = old
-    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls in a graph (intermediates stay in HBM: 1 upload + 1 download)", "pageable input",
-                 lambda: chain(x)))
+            for k, v in old.items():
+                setattr(_devices, k, v)
+    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls in a graph, deferred and fused (round 6: one upload, ONE fused chain per piece, "
+                 "one download, all three in duplex)", "pageable input", lambda: chain(x)))
+    runs.append(("grain -> LUT -> colour match -> unsharp, four node calls, each runs when called, intermediates stay in HBM (VRGDG_DEFER_GRAPH=0: round 5's "
+                 "1 upload + 4 kernels + 1 download in sequence)", "pageable input", lambda: chain_with(x, DEFER_GRAPH=False)))
     runs.append(("grain -> LUT -> colour match -> unsharp, four node calls, every result downloaded at once (VRGDG_LAZY_DOWNLOAD=0: 1 upload + 4 downloads)",
-                 "pageable input", lambda: chain_eager(x)))
+                 "pageable input", lambda: chain_with(x, LAZY_DOWNLOAD=False)))
     for _ in range(max(1, int(warmup))):             # warm-up, at least twice: the first call page-locks the result buffers, the second still grows torch's device pool
         for _, _, fn in runs:      # (tools/diag_lazy_graph.py: calls 1 and 2 of the graph take 880 / 210 ms, every later one 76.5-77.8)
             once(fn)
