@@ -1015,6 +1015,43 @@ def test_fused_chain_across_several_philox_groups(ops, dev, variant, bs, shape):
     assert_bit_equal(fused, R.apply_lut_with_strength(o, data, 6.0), f"point-wise variant {variant}")
 
 
+@pytest.mark.parametrize("sharpen", [True, False])
+def test_march_rows_with_nan_and_inf_take_the_pass_through_forms(ops, dev, sharpen):
+    """Round 6: the steady rows of grain -> (unsharp) run a body WITHOUT the NaN / Inf pass-through selects when the wave's twelve input values
+    of the row hold no NaN, and the full forms for a row that does -- and for the two steps whose stencil windows still see it.  Frames
+    with NaN, +Inf and -Inf sprinkled over steady rows, priming rows and frame borders: the march (variant 2), the tile kernels (variant 1)
+    and the stand-alone operators give the same BITS, NaN payloads included; clean frames next to them are untouched by the slow rows."""
+    g = torch.Generator().manual_seed(91)
+    x = torch.rand((4, 720, 1280, 3), generator=g)
+    nan, inf = float("nan"), float("inf")
+    marks = [(0, 5, 7, 0, nan), (0, 300, 64, 1, inf), (0, 300, 65, 2, -inf), (1, 400, 640, 0, nan), (1, 401, 640, 1, nan), (1, 719, 1279, 2, nan),
+             (2, 0, 0, 0, -inf), (2, 360, 100, 1, inf), (2, 360, 101, 1, -inf), (2, 500, 1279, 0, nan), (3, 100, 0, 2, nan), (3, 100, 61, 0, inf)]
+    for f, y, xx, c, v in marks:
+        x[f, y, xx, c] = v
+    # a whole clean frame region far from every mark exists in each frame: rows 150..250
+    xd = x.to(dev)
+    outs = {}
+    for variant in (2, 1):
+        spec = ops.ChainSpec(grain=(0.05, 0.4, 2), sharpen=("unsharp", 0.7, False) if sharpen else None, variant=variant)
+        outs[variant] = ops.fused_chain(xd, spec, generator=torch.Generator(device=dev).manual_seed(17))
+    y = ops.film_grain(xd, 0.05, 0.4, chunk_frames=2, generator=torch.Generator(device=dev).manual_seed(17))
+    if sharpen:
+        y = ops.stencil3x3(y, "unsharp", 0.7, False)
+    bits = lambda t: t.view(torch.int32)
+    assert torch.equal(bits(outs[2]), bits(outs[1])) and torch.equal(bits(outs[2]), bits(y))
+    assert bool(torch.isnan(outs[2][0, 5, 7, 0])) and float(outs[2][0, 300, 64, 1]) == 1.0 and float(outs[2][0, 300, 65, 2]) == 0.0 or sharpen
+    assert int(torch.isnan(outs[2]).sum()) >= 5
+    # the CPU restatement agrees on a crop that holds a NaN, an Inf pair and clean rows (same noise: torch.randn on the device)
+    torch.manual_seed(23)
+    fused = ops.fused_chain(xd[:2], ops.ChainSpec(grain=(0.05, 0.4, 2), sharpen=("unsharp", 0.7, False) if sharpen else None))
+    torch.manual_seed(23)
+    o = R.fast_film_grain(x[:2], 0.05, 0.4, 2, noise_fn=lambda i, shp: torch.randn(shp, device=dev).cpu())
+    if sharpen:
+        o = R.unsharp(o, 0.7, False)
+    got, want = fused.cpu(), o
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 def test_fused_chain_with_colour_match(ops, dev, variant):
     data, dlut = _lut_pair(ops, dev, "AMD_WarmFilm_25.cube")

@@ -87,13 +87,13 @@ costs = json.load(open(a.costs)) if os.path.exists(a.costs) else {"classes": {},
 def price(op):
     """(class name, cycles) of one opcode"""
     oc = costs.get("opcodes", {})
-    base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
+    if op.endswith("_dpp"):                        # any DPP form issues at the half rate, whatever the base opcode
+        return "dpp", costs["classes"].get("dpp", 4.0)
+    base = re.sub(r"_(e32|e64|sdwa)$", "", op)
     for key in (op, base):
         if key in oc:
             c = oc[key]
             return c, costs["classes"][c]
-    if op.endswith("_dpp"):
-        return "dpp", costs["classes"].get("dpp", 4.0)
     for pat, c in costs.get("patterns", []):
         if re.match(pat, base):
             return c, costs["classes"][c]
