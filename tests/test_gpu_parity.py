@@ -366,8 +366,19 @@ def test_stencils_match_reference_fixtures(ops, dev):
             assert_bit_equal(ops.stencil3x3(xd, name, 0.8, False), _t(z[f"{tag}.{name}.0.8.0"]), f"{name} {tag} replicate")
             got = ops.stencil3x3(xd, name, 0.8, True)
             assert_bit_equal(got, raster(x, 0.8), f"{name} {tag} zero/raster")
-            if x.shape[-1] == 3:   # the reference's conv2d picks its own summation order: a few ulp
-                assert (got.cpu() - _t(z[f"{tag}.{name}.0.8.1"])).abs().max() <= 5e-7
+            if x.shape[-1] == 3:   # the reference's own CPU conv2d output: laplacian bit-equal, sobel within one unit of the last place
+                d = _unit_ulps(got, _t(z[f"{tag}.{name}.0.8.1"]))
+                assert d <= (0.0 if name == "laplacian" else 1.0), (tag, name, d)
+    # a video-sized frame: twelve rows of the reference's use_gpu=True outputs at 1080p (tests/golden/stencil_1080p_rows.npz)
+    z = _npz("stencil_1080p_rows.npz")
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    x = torch.rand(tuple(int(v) for v in z["shape"]), generator=g) * float(z["affine"][0]) + float(z["affine"][1])
+    xd, rows = x.to(dev), z["rows"]
+    assert np.array_equal(ops.stencil3x3(xd, "unsharp", 0.5, True).cpu().numpy()[0, rows], z["unsharp.0.5.1"])
+    assert np.array_equal(ops.stencil3x3(xd, "laplacian", 0.8, True).cpu().numpy()[0, rows], z["laplacian.0.8.1"])
+    sob = ops.stencil3x3(xd, "sobel", 0.8, True).cpu().numpy()[0, rows]
+    d = np.abs(sob.astype(np.float64) - z["sobel.0.8.1"].astype(np.float64)) / 2.0 ** -23
+    assert float(d.max()) <= 1.0 and int((d != 0).sum()) <= 69           # 45 of 69,120 elements, by one ulp(1.0)
 
 
 def test_sharpen_nodes(pkg, dev):
@@ -396,10 +407,13 @@ def test_sharpen_nodes(pkg, dev):
 #   "fast": table-driven powers; compared with both references in units of ulp(1.0) = 2^-23 of the [0,1] output.
 # Budgets below are 2x the maxima measured on MI355X (profiles/r02_cm_parity.json); they replace round 1's 2e-5 (168 ulp).
 ULP1 = 2.0 ** -23
-CM_E2E_DEVICE_ULP = 48      # device policy vs device oracle, end to end: statistics differences only (measured max 19.25)
+CM_E2E_DEVICE_ULP = 32      # fp64-statistics variant vs the device oracle, end to end: statistics differences only (measured max 16.6; the chain: 21.1 against 2x this)
 CM_FAST_VS_CPU_ULP = 64     # fast policy vs the reference on the CPU (Sleef powf, IEEE division) (measured max 26 on large frames)
-CM_CROSS_REF_ULP = 192      # a policy against the OTHER reference on small frames (the two references themselves differ by up to 31
-                            # ulp on 540p frames and more on thumbnails, where a statistics ulp moves every pixel)
+CM_CROSS_REF_ULP = 64       # a policy against the OTHER reference (round 6: 192 -> 64 = 2x the measured maxima, profiles/r04_cm_test_measured.json:
+                            # device policy vs the reference's CPU fixture 27.5, fast policy vs it 14.25, fast vs the device oracle 30.75, fast apply
+                            # with CPU statistics 32.3, random sweep 48.4 per unit of stencil gain; the two references THEMSELVES differ by 30.75
+                            # on a 270p frame -- north_star's "within 1 ulp" of "the reference" is met against the reference run on this GPU
+                            # (0 ulp), not against its CPU run, by either policy)
 MEASURED = {}
 
 
