@@ -567,6 +567,71 @@ def run_workload(C, args, workload, pixel_dist, frames, steps, warmup, *, cm_sta
     return R
 
 
+def graph_leg(C, args, frames, steps, warmup):
+    """The headline workload driven through NODE_CLASS_MAPPINGS: FastFilmGrain -> VRGDG_LUTS -> ColorMatchToReference -> FastUnsharpSharpen called one
+    after the other on device-resident 4K frames, ComfyUI's intermediate device on the GPU (`--gpu-only`; a stub of comfy.model_management says so
+    for the duration of the leg).  The nodes defer and fuse (_devices.defer): the four calls record a recipe, the first use of the last result runs
+    ONE fused chain into that result's tensor.  Timed like every leg (barrier + synchronize around `steps` graph executions); verified bit for bit
+    against ops.fused_chain on the same generator state."""
+    import types
+    pack = sys.modules["comfyui_vrgamedevgirl_amd"]
+    from comfyui_vrgamedevgirl_amd import _devices
+    ops, dev = C.ops, C.dev
+    H, W, _st = WORKLOADS["chain4_4k"]
+    mm = types.ModuleType("comfy.model_management")
+    mm.get_torch_device = lambda: dev
+    mm.intermediate_device = lambda: dev
+    comfy = types.ModuleType("comfy")
+    comfy.model_management = mm
+    saved = {k: sys.modules.get(k) for k in ("comfy", "comfy.model_management")}
+    sys.modules["comfy"], sys.modules["comfy.model_management"] = comfy, mm
+    try:
+        x = make_frames(frames, H, W, dev, 1234, "uniform")
+        ref = make_frames(1, H, W, dev, 4321, "uniform")
+        N = pack.NODE_CLASS_MAPPINGS
+        call = lambda key, *a: getattr(N[key](), N[key].FUNCTION)(*a)[0]
+
+        def graph():
+            t = call("FastFilmGrain", x, 0.04, 0.5, 4)
+            t = call("VRGDG_LUTS", t, "AMD_TealOrange_33.cube", "auto", 10.0)
+            t = call("ColorMatchToReference", t, ref, 1.0, CM_BATCH)
+            t = call("FastUnsharpSharpen", t, 0.5, False)
+            return _devices.materialise(t)             # the first use of the result (what the consumer of the graph's output does)
+
+        fused0 = _devices._LAZY.fused
+        for _ in range(warmup):
+            graph()
+        torch.cuda.synchronize()
+        with ClockSampler() as cs:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = graph()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        fused = (_devices._LAZY.fused - fused0) // max(steps + warmup, 1)
+        torch.manual_seed(20260930)
+        got = graph()
+        torch.manual_seed(20260930)
+        ref_ms = ops.reference_stats(ref, step_frames=frames)
+        want = ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(C.lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), cm_chunk=CM_BATCH))
+        same = bool(torch.equal(got, want)) and bool(got.is_cuda)
+        ms = el / steps * 1e3
+        res = {"what": "FastFilmGrain -> VRGDG_LUTS -> ColorMatchToReference -> FastUnsharpSharpen through NODE_CLASS_MAPPINGS, device-resident frames, intermediate "
+                       "device = the GPU; the four calls are deferred and run as one fused chain at the first use of the last result (_devices.defer)",
+               "frames": frames, "height": H, "width": W, "steps": steps, "warmup": warmup, "ms_per_graph": round(ms, 3),
+               "Mpix_s": round(frames * H * W / ms / 1e3, 1), "nodes_fused_per_graph": int(fused), "bit_identical_to_ops_fused_chain": same,
+               "clock_during_timed_steps": cs.summary()}
+        del x, ref, out, got, want
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 VALU_PEAK_T = 66.47       # T lane-instr/s: v_fma_f32 at 8 waves/SIMD over >= 17 ms launches on this chip (profiles/r02_valu_issue_rate_long.json; 78.6 by the clock)
 
 
@@ -814,6 +879,12 @@ def main():
                         "chunk against the stand-alone operators and the oracle after the timed steps; the `...25cube` / `...17cube` legs run chain 3 with this pack's "
                         "25^3 and 17^3 cubes (the default legs: AMD_TealOrange_33.cube); `chain3_4k....512frames` = the same pass at north_star's own size, 4K x 512 "
                         "frames (102 GB of frames resident); `clock_during_timed_steps` = the shader clock and socket power sampled while the leg's timed steps ran")
+        try:
+            g = graph_leg(C, args, frames, max(args.steps // 2, 3), 2)
+            g["vs_headline"] = round(g["Mpix_s"] / max(value, 1e-9), 3)
+            cfgs["graph_four_nodes_device_resident"] = g
+        except Exception as exc:
+            cfgs["graph_four_nodes_device_resident"] = {"error": f"{type(exc).__name__}: {exc}"}
         line["configs"] = cfgs
     if rank == 0:
         if world == 1 and not args.no_host_fed and args.workload == "chain4_4k":
@@ -822,7 +893,7 @@ def main():
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import host_fed
                 torch.cuda.empty_cache()
-                line["host_fed"] = host_fed.measure(frames=8, reps=5, warmup=4)       # (torch's host / device pools of this process settle after 3 calls per row)
+                line["host_fed"] = host_fed.measure(frames=16, reps=5, warmup=4)       # (torch's host / device pools of this process settle after 3 calls per row)
             except Exception as exc:
                 line["host_fed"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
