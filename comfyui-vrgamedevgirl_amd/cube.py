@@ -8,6 +8,7 @@ path is the HIP trilinear kernel, not this file.
 from __future__ import annotations
 
 import os
+import re
 
 import numpy as np
 import torch
@@ -85,60 +86,65 @@ def write_cube_file(lut_tensor, lut_path: str):
         handle.writelines("%.6f %.6f %.6f\n" % (r, g, b) for r, g, b in table)
 
 
+_NOT_ALNUM = re.compile(r"[\W_]+")            # runs of anything str.isalnum() rejects (\w is isalnum() or "_")
+_HEX6 = re.compile(r"[0-9a-f]{6}")
+_LUMA = (0.2126, 0.7152, 0.0722)               # the palette generator's luma weights (VRGDG_IV_Adjustments.py:98, 101)
+
+
 def sanitize_filename_part(value) -> str:
-    cleaned = "".join(ch if ch.isalnum() else "_" for ch in str(value or "").strip().lower())
-    cleaned = "_".join(part for part in cleaned.split("_") if part)
-    return cleaned or "custom"
+    """Lower-case, every run of non-alphanumerics one underscore, none at the ends; "custom" for nothing (the slug rule of the files
+    VRGDG_MakeLUT writes: VRGDG_IV_Adjustments.py:38-41, 395-402 -- a contract: existing graphs find their cubes by these names)."""
+    words = [w for w in _NOT_ALNUM.split(str(value or "").strip().lower()) if w]
+    return "_".join(words) if words else "custom"
 
 
 def parse_hex_color(token) -> np.ndarray:
-    token = str(token or "").strip().lower()
-    token = NAMED_COLORS.get(token, token)
-    if token.startswith("#"):
-        token = token[1:]
-    if len(token) == 3:
-        token = "".join(ch * 2 for ch in token)
-    if len(token) != 6 or any(ch not in "0123456789abcdef" for ch in token):
-        raise ValueError(f"Invalid color '{token}'. Use hex like #ff8800 or a basic color name.")
-    return np.array([int(token[i:i + 2], 16) / 255.0 for i in (0, 2, 4)], dtype=np.float32)
+    """"#rgb", "#rrggbb" (the "#" optional) or one of NAMED_COLORS -> fp32 RGB in [0, 1] (VRGDG_IV_Adjustments.py:44-64; the error text is
+    the reference's)."""
+    text = str(token or "").strip().lower()
+    text = NAMED_COLORS.get(text, text).removeprefix("#")
+    if len(text) == 3:
+        text = text[0] * 2 + text[1] * 2 + text[2] * 2
+    if not _HEX6.fullmatch(text):
+        raise ValueError(f"Invalid color '{text}'. Use hex like #ff8800 or a basic color name.")
+    rgb24 = int(text, 16)
+    return np.array([(rgb24 >> shift & 0xFF) / 255.0 for shift in (16, 8, 0)], dtype=np.float32)
 
 
 def parse_color_list(colors_text) -> np.ndarray:
-    parts = [p.strip() for p in str(colors_text or "").split(",") if p.strip()]
-    if not parts:
+    tokens = [t for t in (piece.strip() for piece in str(colors_text or "").split(",")) if t]
+    if not tokens:
         raise ValueError("Provide one or more colors separated by commas.")
-    return np.stack([parse_hex_color(p) for p in parts], axis=0)
+    return np.stack([parse_hex_color(t) for t in tokens], axis=0)
+
+
+def _luma(rgb: np.ndarray) -> np.ndarray:
+    # three products, two sums, in this order and in the arrays' own precision: the generator's table must come out bit for bit
+    return (_LUMA[0] * rgb[..., 0]) + (_LUMA[1] * rgb[..., 1]) + (_LUMA[2] * rgb[..., 2])
 
 
 def build_palette_lut(colors_text, lut_size) -> torch.Tensor:
-    """Luma-indexed palette LUT (VRGDG_IV_Adjustments.py:75-123): host-side, one-off."""
+    """The cube VRGDG_MakeLUT generates from a palette (VRGDG_IV_Adjustments.py:67-123): every grid colour keeps its luma and 18 % of its
+    chroma and takes the rest from the palette entry its luma points at.  Host-side, one-off, numpy in the reference's operation order --
+    tests/test_oracle_golden.py::test_palette_lut_matches_reference_generator holds the table to the reference's bit for bit."""
     palette = parse_color_list(colors_text)
-    axis = np.linspace(0.0, 1.0, int(lut_size), dtype=np.float32)
-    blue, green, red = np.meshgrid(axis, axis, axis, indexing="ij")
-    source = np.stack([red, green, blue], axis=-1)
-    w = (0.2126, 0.7152, 0.0722)
-    luma = (w[0] * source[..., 0]) + (w[1] * source[..., 1]) + (w[2] * source[..., 2])
-    if palette.shape[0] == 1:
-        target = np.empty(luma.shape + (3,), dtype=np.float32)
-        target[...] = palette[0]
+    ramp = np.linspace(0.0, 1.0, int(lut_size), dtype=np.float32)
+    b, g, r = np.meshgrid(ramp, ramp, ramp, indexing="ij")                 # table index order [b][g][r]
+    grid = np.stack([r, g, b], axis=-1)
+    y = _luma(grid)
+    if len(palette) == 1:
+        tint = np.broadcast_to(palette[0], y.shape + (3,)).astype(np.float32)
     else:
-        stops = np.linspace(0.0, 1.0, palette.shape[0], dtype=np.float32)
-        flat = luma.reshape(-1)
-        target = np.stack([np.interp(flat, stops, palette[:, c]) for c in range(3)], axis=-1)
-        target = target.reshape(luma.shape + (3,)).astype(np.float32)
-    target_luma = (w[0] * target[..., 0]) + (w[1] * target[..., 1]) + (w[2] * target[..., 2])
-    scale = luma / np.maximum(target_luma, 1e-6)
-    target = np.clip(target * scale[..., None], 0.0, 1.0)
-    chroma = source - luma[..., None]
-    mixed = np.clip((target * 0.82) + ((target + chroma) * 0.18), 0.0, 1.0)
-    return torch.from_numpy(mixed.astype(np.float32))
+        knots = np.linspace(0.0, 1.0, len(palette), dtype=np.float32)
+        tint = np.stack([np.interp(y.ravel(), knots, palette[:, ch]) for ch in range(3)], axis=-1).reshape(y.shape + (3,)).astype(np.float32)
+    tint = np.clip(tint * (y / np.maximum(_luma(tint), 1e-6))[..., None], 0.0, 1.0)      # the palette colour at the grid colour's luma
+    table = np.clip((tint * 0.82) + ((tint + (grid - y[..., None])) * 0.18), 0.0, 1.0)
+    return torch.from_numpy(table.astype(np.float32))
 
 
 def next_available_lut_path(luts_dir: str, base_name: str) -> str:
+    """<base>.cube, else <base>_2.cube, <base>_3.cube, ... -- the first that does not exist (VRGDG_IV_Adjustments.py:126-137)."""
+    import itertools
     os.makedirs(luts_dir, exist_ok=True)
-    candidate = os.path.join(luts_dir, f"{base_name}.cube")
-    index = 2
-    while os.path.exists(candidate):
-        candidate = os.path.join(luts_dir, f"{base_name}_{index}.cube")
-        index += 1
-    return candidate
+    names = itertools.chain([f"{base_name}.cube"], (f"{base_name}_{n}.cube" for n in itertools.count(2)))
+    return next(path for path in (os.path.join(luts_dir, name) for name in names) if not os.path.exists(path))
