@@ -654,6 +654,35 @@ def valu_fractions(c, rate_px_s):
     return round(w * rate_px_s / 1e12 / VALU_PEAK_T, 4), (round(busy * rate_px_s / SIMD_CYCLES_PER_S, 4) if busy else None)
 
 
+#: (workload, pass) -> the committed ISA price of that kernel's hot loop (tools/isa_cost.py over profiles/r06_valu_instruction_costs.json)
+ISA_COST_PROFILES = {("chain4_4k", "stats"): "r06_isa_cost_produce_lab.json", ("chain4_4k", "apply"): "r06_isa_cost_apply_march.json",
+                     ("chain3_4k", "apply"): "r06_isa_cost_march_chain3.json"}
+
+
+def issue_cost_roofline(workload, which, c, rate_px_s):
+    """The VALU roofline of THIS kernel's instruction mix (round 6).  gfx950 issues only part of its VALU at the 2-cycle rate (fp32 add / sub /
+    mul / fma, xor / and / or / mov, add_u32); every DPP form, min / max / med3, conversion, compare and select takes 4.4 cycles, packed fp32
+    4.6-5.1, v_mad_u64_u32 4.8, transcendentals 8.4 (tools/probe_valu_classes.py -> profiles/r06_valu_instruction_costs.json, cycles at the
+    2.4 GHz the probe launches ran at).  The kernel's hot loop, priced opcode by opcode (tools/isa_cost.py), gives its mean issue units per
+    VALU instruction; x the lane-instructions per pixel the PMC pass counted = issue units per pixel-lane; 1,024 SIMDs x 64 lanes x 2.4e9 units
+    per second / that = the pixel rate at which the VALU issue ports are full.  `frac` = measured rate / that rate (it can pass 1.0 by the
+    model's error: the probe's clock against the kernel's, hot loop against whole kernel)."""
+    name = ISA_COST_PROFILES.get((workload, which))
+    ipp = c.get("valu_lane_instr") if c else None
+    if not name or not ipp or not rate_px_s:
+        return None
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        isa = json.load(fh)
+    units = isa["issue_cycles"] / max(isa["valu"], 1)
+    bound = 1024 * 64 * 2.4e9 / (ipp * units)
+    return {"units_per_valu_instruction": round(units, 3), "lane_instr_per_px": round(ipp, 1), "issue_bound_Mpix_s": round(bound / 1e6, 1),
+            "achieved_Mpix_s": round(rate_px_s / 1e6, 1), "frac": round(rate_px_s / bound, 4), "isa_profile": f"profiles/{name}",
+            "by_class_share": {k: round(v / isa["issue_cycles"], 3) for k, v in sorted(isa["by_class"].items(), key=lambda kv: -kv[1]) if v}}
+
+
 def leg_summary(R, world, pmc, pmc_src):
     """The compact record of a leg for the line's `configs` object: whole-leg rate, the dominant pass and its two roofline fractions --
     algorithmic bytes against 8 TB/s (`hbm_frac`) and class-weighted VALU issue against the measured peak (`valu_busy_frac`, see
@@ -674,6 +703,7 @@ def leg_summary(R, world, pmc, pmc_src):
            "dominant_kernel": _kernel_name(stages, dom), "dominant_kernel_ms": round(dms, 3),
            "dominant_kernel_hbm_frac": round(ALGO_BPP[dom] * rate / 1e9 / HBM_PEAK_GBS, 4),
            "valu_busy_frac": vfrac, "sq_active_inst_valu_x4_frac": x4, "valu_lane_instr_per_px": c.get("valu_lane_instr") or None,
+           "issue_cost_roofline": issue_cost_roofline(R["workload"], dom, c, rate),
            "wait_issue_share_of_wave_cycles": c.get("wait_issue_share"), "wait_memory_share_of_wave_cycles": c.get("wait_memory_share"),
            "hbm_bytes_per_px_measured": c.get("total") or None, "pmc_source": pmc_src if c else None,
            "clock_during_timed_steps": R.get("clock"),
@@ -838,6 +868,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_avg_ms, 4),
                          "passes_ms": {k: round(v, 4) for k, v in pass_ms.items()}, "launches_per_step": M["launches_per_step"],
                          "issue": issue,
+                         "issue_cost_roofline": issue_cost_roofline(args.workload, dom, c, rate),
                          "clock_during_timed_steps": M.get("clock"),
                          "path": kernel_path(ops, dev, stages)},
         }
