@@ -11,8 +11,12 @@ import torch
 
 #: upper bound of one host->device staging transfer (bytes of fp32 frames) -- sequential fallback path
 STAGE_BYTES = 1 << 30
-#: target size of one pipelined piece (bytes of frames) and the number of pieces in flight
-PIPE_BYTES = 256 << 20
+#: target size of one pipelined piece (bytes of frames; a piece is never smaller than the node's frame multiple -- one grain chunk, one
+#: statistics call) and the number of pieces in flight.  Round 6 (tools/sweep_piece_size.py, profiles/r06_host_fed_piece_size_sweep.json; the
+#: four-node graph, deferred and fused, ms at 32 / 64 / 128 / 256 / 512 MB): 32 x 1080p 22.2 / 22.1 / 22.3 / 24.0 / 28.7, 48 x 720p 15.4 / 15.3 /
+#: 16.6 / 18.8 / 23.4, 16 x 4K with grain batch_size 1 41.5 / 41.4 / 40.9 / 42.3 / 47.3 (batch_size 4: the chunk is 400 MB, 45.5-45.9 whatever the
+#: target) -- the pipeline's fill and drain cost one piece each, so 256 MB (rounds 2-5) gave away 6-19 % on the batch sizes ComfyUI graphs carry.
+PIPE_BYTES = 64 << 20
 PIPE_DEPTH = 3
 
 
