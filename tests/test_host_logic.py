@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: generator bookkeeping, .cube I/O, blend terms, staging groups,
 statistics merging."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -8,7 +9,7 @@ import torch
 
 from oracle import philox as PH
 from oracle import restated as R
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 
 class FakeGen:
@@ -375,3 +376,29 @@ def test_lazy_frames_download_once_at_first_use(pkg, monkeypatch):
     gc.collect()
     assert pu not in D._LAZY.pending and len(D._LAZY.pending) == n_pending - 1 and not pu.done
     D._DEVICE_COPIES.clear()
+
+
+def test_bench_issue_cost_roofline_and_clock_sampler_without_a_gpu(pkg):
+    """bench.py's round-6 additions are host logic: the VALU roofline of a kernel's own instruction mix from the committed ISA price
+    (profiles/r06_isa_cost_*.json) and a PMC record, and the clock sampler on a box without amdgpu hwmon files."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    rec = {"valu_lane_instr": 687.3}
+    r = bench.issue_cost_roofline("chain4_4k", "stats", rec, 70.0e9)
+    assert r is not None and r["isa_profile"].endswith("r06_isa_cost_produce_lab.json")
+    units = r["units_per_valu_instruction"]
+    assert 3.0 < units < 3.7                                                      # pass 1: 44 % full-rate arithmetic, the rest 4.4 ... 8.4 cycles
+    assert abs(r["issue_bound_Mpix_s"] - 1024 * 64 * 2.4e9 / (687.3 * units) / 1e6) < 20.0        # (units is printed rounded to 3 places)
+    assert abs(r["frac"] - 70.0e9 / (r["issue_bound_Mpix_s"] * 1e6)) < 1e-3 and 0.9 < r["frac"] < 1.15
+    assert abs(sum(r["by_class_share"].values()) - 1.0) < 0.02
+    assert bench.issue_cost_roofline("grain_lut_1080p", "apply", rec, 1e9) is None      # no ISA price committed for that kernel
+    assert bench.issue_cost_roofline("chain4_4k", "stats", {}, 1e9) is None
+    with bench.ClockSampler() as cs:
+        pass
+    assert cs.summary() is None or "sclk_mhz_median" in cs.summary()
