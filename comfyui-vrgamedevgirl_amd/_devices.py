@@ -477,15 +477,18 @@ class _Pending:
         fn, mult = r.compiled()
         F = int(self.host.shape[0])
         with torch.cuda.device(self.device):
+            src = r.source
+            if isinstance(src, LazyFrames) and src.is_cuda:           # a device-resident result of this pack as the source: run it, take its tensor
+                src = materialise(src)._vrg_plain()
             if self.host.is_cuda:                                     # device-resident graph: the result buffer IS the destination
-                src = r.source if not isinstance(r.source, LazyFrames) else materialise(r.source)
+                if isinstance(src, LazyFrames):
+                    src = materialise(src)._vrg_plain()
                 fn(src.to(self.device), 0, out=self.host)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self.pieces, self.queued, self.nbytes = [(0, F, self.host, ev)], [ev], 0
                 self.recipe = None
                 return True
-            src = r.source
             if isinstance(src, torch.Tensor) and src.is_cuda and not isinstance(src, LazyFrames):     # device frames in, host frames out
                 gpu = fn(src.to(self.device), 0)
                 ev = torch.cuda.Event()
@@ -509,17 +512,23 @@ class _Pending:
 
     def device_pieces(self):
         """The frames as device pieces [(s, e, gpu, ran_event)] without touching the host buffer; None if they cannot be held in HBM."""
+        ran = False
         with _STAGING.lock, self.lock:            # (lock order: the staging lock first, everywhere)
             if self.done and self.host.is_cuda:
                 return self.pieces
             if self.done:
                 return None
             with torch.inference_mode(_inference_of(self.host)):
-                if self.recipe is not None and not self._run_recipe(to_host=False):
-                    return None
+                if self.recipe is not None:
+                    if not self._run_recipe(to_host=False):
+                        return None
+                    ran = True
             if self.host.is_cuda:
                 self.done = True
-            return self.pieces
+            pieces = self.pieces
+        if ran and self.nbytes:
+            _LAZY.enforce(self)                   # this result holds HBM now: older ones may have to go to the host (outside the locks)
+        return pieces
 
     def materialise(self):
         with _STAGING.lock, self.lock:   # (self.host is the plain tensor under the LazyFrames: nothing in here re-enters __torch_function__)
@@ -571,6 +580,26 @@ class _LazyRegistry:
         with self.lock:
             if p in self.pending:
                 self.pending.remove(p)
+
+    def enforce(self, keep: "_Pending"):
+        """A registered result started to hold device memory after it was added (its recipe ran into HBM): apply the budget again."""
+        over = []
+        with self.lock:
+            budget = _DEVICE_COPIES._budget(keep.device)
+            total = sum(q.nbytes for q in self.pending)
+            while total > budget:
+                q = next((q for q in self.pending if q.nbytes > 0 and q is not keep), None)
+                if q is None:
+                    break
+                self.pending.remove(q)
+                total -= q.nbytes
+                over.append(q)
+        for q in over:
+            try:
+                q.materialise()
+            except Exception:
+                with self.lock:
+                    self.pending.append(q)         # stays counted; the timer retries it
 
     def held_bytes(self) -> int:
         with self.lock:
