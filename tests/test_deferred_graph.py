@@ -451,3 +451,74 @@ def test_nodes_that_cannot_join_a_chain_still_read_their_input_in_hbm(pkg, monke
     assert D.pending_of(got[0]) is not None and D.pending_of(got[2]) is not None  # consumed in HBM, never downloaded
     assert all(torch.equal(g, w) for g, w in zip(got, want))
     D._DEVICE_COPIES.clear()
+
+
+@gpu
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_graphs_deferred_equal_eager(pkg, monkeypatch, seed):
+    """Random graphs over the pack's nodes -- chains, fan-out, results reused as colour-match references, intermediates read on the host at random
+    moments, nodes in orders that fuse and orders that do not, several frame multiples -- built twice with the same calls in the same order:
+    every node run when it is called (VRGDG_DEFER_GRAPH=0, eager downloads) against the deferred / fused default.  Same bits for EVERY tensor of
+    the graph, same generator state at the end."""
+    import random
+    from comfyui_vrgamedevgirl_amd import nodes, _devices as D, VRGDG_IV_Adjustments as iv
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rnd = random.Random(1000 + seed)
+    F = rnd.choice([4, 6, 8])
+    H, W = rnd.choice([(48, 80), (72, 128), (61, 97)])
+    x = _rand((F, H, W, 3), 500 + seed)
+    ref_img = _rand((1, 24, 32, 3), 600 + seed)
+    cubes = ["AMD_WarmFilm_25.cube", "AMD_TealOrange_33.cube", "AMD_Identity_17.cube"]
+    plan = []
+    for _ in range(rnd.randint(3, 7)):
+        kind = rnd.choice(["grain", "lut", "cm", "unsharp", "laplacian", "sobel", "read"])
+        src = rnd.random()                                   # which earlier tensor feeds it (resolved against the list at run time)
+        if kind == "grain":
+            plan.append((kind, src, (round(rnd.uniform(0.01, 0.2), 3), round(rnd.uniform(0, 1), 2), rnd.choice([0, 1, 2, F]))))
+        elif kind == "lut":
+            plan.append((kind, src, (rnd.choice(cubes), rnd.choice([10.0, 10.0, 6.5, 0.0]))))
+        elif kind == "cm":
+            plan.append((kind, src, (rnd.random() < 0.3, round(rnd.uniform(0.1, 1.0), 2), rnd.choice([1, 2, F]))))      # (reference = an earlier result?, k, batch_size)
+        elif kind == "read":
+            plan.append((kind, src, None))
+        else:
+            plan.append((kind, src, (round(rnd.uniform(0.1, 2.0), 2), rnd.random() < 0.4)))
+
+    def build():
+        ts = [x]
+        for kind, src, par in plan:
+            t = ts[min(int(src * len(ts)), len(ts) - 1)]
+            if kind == "grain":
+                ts.append(nodes.FastFilmGrain().apply_grain(t, *par)[0])
+            elif kind == "lut":
+                ts.append(iv.VRGDG_LUTS().apply_lut(t, par[0], "auto", par[1])[0])
+            elif kind == "cm":
+                r = ts[-1][:1] if (par[0] and len(ts) > 1) else ref_img
+                ts.append(nodes.ColorMatchToReference().match_color(t, r, par[1], par[2])[0])
+            elif kind == "read":
+                float(t.sum())                                # a host-side consumer in the middle of the graph
+            else:
+                cls = {"unsharp": nodes.FastUnsharpSharpen, "laplacian": nodes.FastLaplacianSharpen, "sobel": nodes.FastSobelSharpen}[kind]
+                meth = {"unsharp": "apply_unsharp", "laplacian": "apply_laplacian", "sobel": "apply_sobel"}[kind]
+                ts.append(getattr(cls(), meth)(t, par[0], par[1])[0])
+        return ts
+
+    monkeypatch.setattr(D, "LAZY_SECONDS", 60.0)
+    monkeypatch.setattr(D, "PIPE_BYTES", rnd.choice([1, 2, 64]) * x[0].numel() * 4)
+    monkeypatch.setattr(D, "DEFER_GRAPH", False)
+    monkeypatch.setattr(D, "LAZY_DOWNLOAD", False)
+    D._DEVICE_COPIES.clear()
+    torch.manual_seed(77 + seed)
+    want = [w.clone() for w in build()]
+    state = torch.cuda.get_rng_state(dev)
+    monkeypatch.setattr(D, "DEFER_GRAPH", True)
+    monkeypatch.setattr(D, "LAZY_DOWNLOAD", True)
+    D._DEVICE_COPIES.clear()
+    torch.manual_seed(77 + seed)
+    got = build()
+    assert torch.equal(torch.cuda.get_rng_state(dev), state), plan
+    order = list(range(len(got)))
+    rnd.shuffle(order)                                       # the results are read in an arbitrary order
+    for i in order:
+        assert got[i].shape == want[i].shape and torch.equal(got[i], want[i]), (i, plan)
+    D._DEVICE_COPIES.clear()
