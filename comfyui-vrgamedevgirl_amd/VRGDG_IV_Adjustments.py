@@ -39,12 +39,21 @@ def _graded(image, lut_data, requested_device, strength):
     target = VRGDG_LUTS._resolve_device(requested_device, image)
     dev_lut = ops.upload_lut(lut_data, target)
 
-    def on(device):             # several GPUs (VRGDG_DEVICES): every device gets its own copy of the record table
-        lut_d = dev_lut if torch.device(device) == torch.device(target) else ops.upload_lut(lut_data, device)
+    tables = {torch.device(target): dev_lut}
+
+    def table_on(device):       # several GPUs (VRGDG_DEVICES): every device gets its own copy of the record table
+        device = torch.device(device)
+        if device not in tables:
+            tables[device] = ops.upload_lut(lut_data, device)
+        return tables[device]
+
+    def on(device):
+        lut_d = table_on(device)
         return lambda frames, _first, out=None: ops.lut3d(frames, lut_d, strength, out=out)
 
     fusable = image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0 and image.shape[-1] == 3
-    stage = Stage("lut", on(target), 1, {"lut": dev_lut, "strength": strength}) if fusable else None
+    stage = Stage("lut", on(target), 1, {"lut": dev_lut, "strength": strength},
+                  for_device=lambda d: (on(d), {"lut": table_on(d), "strength": strength})) if fusable else None
     if image.device.type == "cpu" and image.dtype == torch.float32 and image.ndim == 4 and image.shape[0] > 0:
         # CPU tensor in, CPU tensor out: uploads, kernels and downloads overlapped (see _devices.stream_frames); recorded and fused with
         # the neighbouring nodes of this pack where the graph allows it (_devices.defer)

@@ -375,17 +375,31 @@ class Stage:
     """One node's operator: `fn(gpu_frames, first_frame, out=None) -> gpu_frames` (the stand-alone kernels, noise / statistics already
     reserved), the frame multiple its pieces must keep, and -- where ops.fused_chain can run it as a stage of one launch -- `kind` and
     the parameters (`fuse`) ops.fused_stages takes."""
-    __slots__ = ("kind", "fn", "multiple_of", "fuse")
+    __slots__ = ("kind", "fn", "multiple_of", "fuse", "for_device", "_made")
 
-    def __init__(self, kind, fn, multiple_of=1, fuse=None):
+    def __init__(self, kind, fn, multiple_of=1, fuse=None, for_device=None):
         self.kind, self.fn, self.multiple_of, self.fuse = kind, fn, max(int(multiple_of), 1), fuse
+        # several GPUs (VRGDG_DEVICES): `for_device(device) -> (fn, fuse)` builds the stage for another GPU -- its own copy of the LUT
+        # table, its own reference statistics; None: `fn` / `fuse` hold nothing that lives on a device
+        self.for_device, self._made = for_device, {}
+
+    def on(self, device, primary):
+        """(fn, fuse) of this stage on `device` (`primary` = the compute device `fn` / `fuse` were built for)."""
+        if self.for_device is None or device == primary:
+            return self.fn, self.fuse
+        key = device.index
+        if key not in self._made:
+            with torch.cuda.device(device):
+                self._made[key] = self.for_device(device)
+        return self._made[key]
 
 
 class _Recipe:
-    __slots__ = ("source", "stages", "source_pieces", "version", "stamp")
+    __slots__ = ("source", "stages", "source_pieces", "version", "stamp", "devices")
 
-    def __init__(self, source, stages, source_pieces=None):
+    def __init__(self, source, stages, source_pieces=None, devices=None):
         self.source, self.stages, self.source_pieces = source, list(stages), source_pieces
+        self.devices = list(devices) if devices else None        # several GPUs (VRGDG_DEVICES): the lanes the pieces go round-robin over
         plain_cpu = isinstance(source, torch.Tensor) and not isinstance(source, LazyFrames) and source.device.type == "cpu"
         self.version = _version_of(source) if plain_cpu else None
         self.stamp = _content_stamp(source) if plain_cpu and source.is_contiguous() and source.numel() else None
@@ -397,12 +411,14 @@ class _Recipe:
             m = m * st.multiple_of // math.gcd(m, st.multiple_of)
         return m
 
-    def compiled(self):
-        """(fn(gpu_frames, first_frame, out=None), frames multiple): one stage as its node runs it, several as ONE fused chain."""
+    def compiled(self, device=None, primary=None):
+        """(fn(gpu_frames, first_frame, out=None), frames multiple): one stage as its node runs it, several as ONE fused chain -- for
+        `device` (default: the compute device the stages were built for)."""
+        on = [(st.fn, st.fuse) if device is None else st.on(device, primary) for st in self.stages]
         if len(self.stages) == 1:
-            return self.stages[0].fn, self.stages[0].multiple_of
+            return on[0][0], self.stages[0].multiple_of
         from . import ops
-        fuse = {st.kind: st.fuse for st in self.stages}
+        fuse = {st.kind: f for st, (_fn, f) in zip(self.stages, on)}
         return (lambda gpu, first, out=None: ops.fused_stages(gpu, first, fuse, out=out)), self.multiple_of()
 
     def can_append(self, stage: "Stage", frame_bytes: int) -> bool:
@@ -474,8 +490,17 @@ class _Pending:
         Returns False when the frames were wanted in HBM but do not fit the budget (the caller downloads instead)."""
         r = self.recipe
         r.check_source()
-        fn, mult = r.compiled()
         F = int(self.host.shape[0])
+        if r.devices and len(r.devices) > 1:
+            # several GPUs: the pieces go round-robin over the lanes, every lane with its own copy of the stages' operands; the result comes
+            # to the host as the pieces finish (no lane keeps frames for a later node: a consumer that wants them in HBM uploads them)
+            if not to_host:
+                return False
+            fns = [r.compiled(d, self.device)[0] for d in r.devices]
+            _out, _produced, _queued, _lazy, _n = _pipeline(r.devices, fns, r.source, r.multiple_of(), self.host.dtype, out=self.host, lazy=False)
+            self.pieces, self.queued, self.nbytes, self.recipe, self._on_host = [], [], 0, None, True
+            return True
+        fn, mult = r.compiled()
         with torch.cuda.device(self.device):
             src = r.source
             if isinstance(src, LazyFrames) and src.is_cuda:           # a device-resident result of this pack as the source: run it, take its tensor
@@ -826,7 +851,7 @@ def _wrap_lazy(out: torch.Tensor, p: "_Pending", budget: int) -> "LazyFrames":
     return res
 
 
-def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device: torch.device):
+def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device: torch.device, devices=None):
     """The deferred form of one node call (see "Deferred graph fusion" above): a LazyFrames over a fresh result buffer whose recipe is the
     input's recipe + `stage` where that is one fused chain, else [`stage`] on top of the input.  None: this call is not deferred (switch
     off, several devices, frames that are not [F,H,W,C] fp32, a result too large to page-lock) -- the caller runs it now."""
@@ -846,13 +871,14 @@ def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device
     for d in images.shape[1:]:
         frame_bytes *= int(d)
     nbytes = int(images.shape[0]) * frame_bytes
+    lanes = list(devices) if devices and len(devices) > 1 and not src_cuda and out_device.type == "cpu" else None
     p_in = pending_of(images)
     recipe = None
     if p_in is not None and p_in.device == device and p_in.recipe is not None and p_in.host.device.type == out_device.type:
         with p_in.lock:
             r = p_in.recipe                    # (may have run meanwhile on the timer's thread)
-            if r is not None and r.can_append(stage, frame_bytes):
-                recipe = _Recipe(r.source, r.stages + [stage], r.source_pieces)
+            if r is not None and r.can_append(stage, frame_bytes) and (r.devices or None) == lanes:
+                recipe = _Recipe(r.source, r.stages + [stage], r.source_pieces, lanes)
                 _LAZY.fused += 1
     if p_in is not None and p_in.device == device:
         _LAZY.downloads_skipped += 1           # this node takes its frames on the device: its input is not downloaded for it
@@ -860,7 +886,7 @@ def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device
         pieces = None
         if p_in is None and not src_cuda:
             pieces = _DEVICE_COPIES.lookup(images, device)      # an unchanged, already downloaded result of this pack: still in HBM
-        recipe = _Recipe(images, [stage], pieces)
+        recipe = _Recipe(images, [stage], pieces if lanes is None else None, lanes)
     if out_device.type == "cuda":
         out = torch.empty(tuple(images.shape), dtype=torch.float32, device=device)
     else:
@@ -884,12 +910,12 @@ def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None
     `fn_for_device(device) -> fn` builds the per-device callable (device-resident operands -- LUT tables, reference statistics -- must
     live on the device that runs the piece); without it only one device is used.  Results are identical to one device."""
     devices = compute_devices() if fn_for_device is not None else [compute_device()]
+    if stage is not None and out_dtype in (None, torch.float32):
+        res = defer(images, devices[0], stage, torch.device("cpu"), devices)
+        if res is not None:
+            return res
     if len(devices) == 1:
         dev = devices[0]
-        if stage is not None and out_dtype in (None, torch.float32):
-            res = defer(images, dev, stage, torch.device("cpu"))
-            if res is not None:
-                return res
         with torch.cuda.device(dev):          # kernels, side streams and events all on the compute device
             return _stream_frames_on([dev], [fn if fn_for_device is None else fn_for_device(dev)], images, multiple_of, out_dtype)
     fns, made = [], {}

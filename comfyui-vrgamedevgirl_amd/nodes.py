@@ -36,14 +36,15 @@ def _frames_bytes(images: torch.Tensor) -> int:
 PIPELINED = True
 
 
-def _run_grouped(images, fn, multiple_of=1, fn_for_device=None, kind=None, fuse=None):
+def _run_grouped(images, fn, multiple_of=1, fn_for_device=None, kind=None, fuse=None, stage_for_device=None):
     """Stream `images` through the GPU in bounded groups; `fn(gpu_frames, first_frame, out=None)` returns GPU frames.  `fn_for_device(device)`
     builds that callable for one of several GPUs (VRGDG_DEVICES, _devices.stream_frames); `fn` is the compute device's.  `kind` / `fuse`:
     what this node is to ops.fused_chain (grain / lut / colormatch / sharpen and its parameters) -- with them the call may be DEFERRED and
     fused with the nodes of this pack that follow it in the graph (_devices.defer)."""
     dev = compute_device()
     out_dev = intermediate_device()
-    stage = Stage(kind, fn, multiple_of, fuse) if kind is not None else None
+    # (`stage_for_device(device) -> (fn, fuse)`: the stage for another GPU of VRGDG_DEVICES -- nodes whose stage holds device-resident operands)
+    stage = Stage(kind, fn, multiple_of, fuse, for_device=stage_for_device) if kind is not None else None
     if images.is_cuda:
         if stage is not None:
             res = defer(images, dev, stage, out_dev)
@@ -168,22 +169,34 @@ class ColorMatchToReference:
             return ops.color_match(gpu_frames, None, match_strength, ref_ms=ref_ms, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
                                    ref_event=ref_ready, out=out)
 
+        per_device = {}
+
+        def stats_on(device):
+            if device not in per_device:
+                per_device[device] = ops.reference_stats_async(ref.to(device), step_frames=step_frames)   # every GPU reduces the reference frame itself: same bits
+            return per_device[device]
+
         def run_on(device):
             if device == dev:
                 return run
-            ms_d, ready_d = ops.reference_stats_async(ref.to(device), step_frames=step_frames)   # every GPU reduces the reference frame itself: same bits
+            ms_d, ready_d = stats_on(device)
 
-            def run_d(gpu_frames, first):
+            def run_d(gpu_frames, first, out=None):
                 return ops.color_match(gpu_frames, None, match_strength, ref_ms=ms_d, cm_chunk=calls_of(first, int(gpu_frames.shape[0])),
-                                       ref_event=ready_d)
+                                       ref_event=ready_d, out=out)
             return run_d
+
+        def stage_on(device):
+            ms_d, ready_d = stats_on(device)
+            return run_on(device), {"ref_ms": ms_d, "k": match_strength, "calls_of": calls_of, "ref_event": ready_d}
 
         fuse = None
         if expand is not None:
             images = images[torch.tensor(expand, dtype=torch.long, device=images.device)]
         elif images.ndim == 4 and images.shape[-1] == 3:
             fuse = {"ref_ms": ref_ms, "k": match_strength, "calls_of": calls_of, "ref_event": ref_ready}
-        return (_run_grouped(images, run, multiple_of=group, fn_for_device=run_on, kind="colormatch" if fuse else None, fuse=fuse),)
+        return (_run_grouped(images, run, multiple_of=group, fn_for_device=run_on, kind="colormatch" if fuse else None, fuse=fuse,
+                             stage_for_device=stage_on),)
 
 
 class _Sharpen:

@@ -522,3 +522,39 @@ def test_random_graphs_deferred_equal_eager(pkg, monkeypatch, seed):
     for i in order:
         assert got[i].shape == want[i].shape and torch.equal(got[i], want[i]), (i, plan)
     D._DEVICE_COPIES.clear()
+
+
+@gpu
+def test_deferred_graph_over_several_gpu_lanes(pkg, monkeypatch, counted):
+    """VRGDG_DEVICES (one ComfyUI process, several GPUs): the deferred graph runs its fused chain on every lane -- the pieces go round-robin,
+    each lane with its own copy of the LUT table and its own reduction of the reference frame, the noise sliced from the ONE reservation the
+    grain node made on the primary generator.  The 1-GPU box runs it with the device list [cuda:0, cuda:0, cuda:0]; bits and generator state
+    must equal one device."""
+    from comfyui_vrgamedevgirl_amd import nodes, _devices as D, VRGDG_IV_Adjustments as iv
+    dev = torch.device("cuda", torch.cuda.current_device())
+    monkeypatch.setattr(D, "LAZY_SECONDS", 60.0)
+    x, ref = _rand((12, 48, 80, 3), 90), _rand((1, 20, 30, 3), 91)
+    monkeypatch.setattr(D, "PIPE_BYTES", 2 * x[0].numel() * 4)                 # six pieces of one noise chunk
+    monkeypatch.delenv("VRGDG_DEVICES", raising=False)
+    torch.manual_seed(19)
+    want = [w.clone() for w in _graph(nodes, iv, x, ref, cm_batch=2)]
+    state = torch.cuda.get_rng_state(dev)
+    monkeypatch.setenv("VRGDG_DEVICES", "0,0,0")
+    assert len(D.compute_devices()) == 3
+    counted.clear()
+    fused0 = D._LAZY.fused
+    torch.manual_seed(19)
+    got = _graph(nodes, iv, x, ref, cm_batch=2)
+    assert torch.equal(torch.cuda.get_rng_state(dev), state) and D._LAZY.fused == fused0 + 3 and not counted
+    assert D.pending_of(got[3]).recipe.devices is not None and len(D.pending_of(got[3]).recipe.devices) == 3
+    assert torch.equal(got[3], want[3]) and counted == [("fused_chain", 4)] * 6
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+    # a node that cannot join reads the multi-lane result through the host (no lane keeps frames): same bits
+    torch.manual_seed(19)
+    t = nodes.FastUnsharpSharpen().apply_unsharp(x, 0.5, False)[0]
+    t = nodes.FastFilmGrain().apply_grain(t, 0.05, 0.4, 2)[0]
+    monkeypatch.delenv("VRGDG_DEVICES", raising=False)
+    torch.manual_seed(19)
+    w = nodes.FastFilmGrain().apply_grain(nodes.FastUnsharpSharpen().apply_unsharp(x, 0.5, False)[0], 0.05, 0.4, 2)[0]
+    assert torch.equal(t, w)
+    D._DEVICE_COPIES.clear()

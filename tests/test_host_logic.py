@@ -244,7 +244,7 @@ def test_colour_match_node_hands_whole_statistics_calls_to_every_piece(pkg, monk
 
     monkeypatch.setattr(ops, "color_match", fake_color_match)
 
-    def grouped(images, fn, multiple_of=1, fn_for_device=None, kind=None, fuse=None):            # pieces of at most 2 * multiple_of frames
+    def grouped(images, fn, multiple_of=1, fn_for_device=None, kind=None, fuse=None, stage_for_device=None):            # pieces of at most 2 * multiple_of frames
         step = 2 * multiple_of
         return torch.cat([fn(images[s:s + step], s) for s in range(0, images.shape[0], step)], dim=0)
 
