@@ -853,8 +853,9 @@ def _wrap_lazy(out: torch.Tensor, p: "_Pending", budget: int) -> "LazyFrames":
 
 def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device: torch.device, devices=None):
     """The deferred form of one node call (see "Deferred graph fusion" above): a LazyFrames over a fresh result buffer whose recipe is the
-    input's recipe + `stage` where that is one fused chain, else [`stage`] on top of the input.  None: this call is not deferred (switch
-    off, several devices, frames that are not [F,H,W,C] fp32, a result too large to page-lock) -- the caller runs it now."""
+    input's recipe + `stage` where that is one fused chain, else [`stage`] on top of the input.  `devices`: the lanes of VRGDG_DEVICES (the
+    recipe then runs its pieces round-robin over them, each lane with its own copy of the stages' operands).  None: this call is not
+    deferred (switch off, frames that are not contiguous [F,H,W,C] fp32, a result too large to page-lock) -- the caller runs it now."""
     if not (DEFER_GRAPH and LAZY_DOWNLOAD and DEVICE_CACHE_BYTES > 0):
         return None
     if images.ndim != 4 or images.dtype != torch.float32 or int(images.shape[0]) == 0 or not images.is_contiguous():
@@ -901,8 +902,8 @@ def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device
 def stream_frames(images: torch.Tensor, fn, multiple_of: int = 1, out_dtype=None, fn_for_device=None, stage: "Stage" = None) -> torch.Tensor:
     """Run ``fn(gpu_frames, first_frame) -> gpu_frames`` over a CPU-resident batch with copies and kernels overlapped.
     Returns a CPU tensor shaped like `images` (dtype `out_dtype`, default the input's), page-locked when it fits
-    PIN_LIMIT_BYTES.  With `stage` (a node that says what it is: deferred graph fusion) and one compute device the call is recorded and
-    runs at the result's first use -- see `defer`.
+    PIN_LIMIT_BYTES.  With `stage` (a node that says what it is: deferred graph fusion) the call is recorded and runs at the result's
+    first use -- see `defer`.
 
     Several GPUs (``compute_devices()``, VRGDG_DEVICES): the pieces -- whole multiples of `multiple_of` frames -- go round-robin to
     the devices, each with its own upload / compute / download streams, and are SUBMITTED in frame order from this host thread, so
