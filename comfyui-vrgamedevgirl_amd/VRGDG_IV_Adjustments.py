@@ -107,18 +107,18 @@ class VRGDG_LUTS:
 
     @staticmethod
     def _get_luts_folder_state():
+        """The IS_CHANGED fingerprint of the LUTS folder (reference :186-201): "missing", "empty", or name:mtime:size of every cube."""
         if not os.path.isdir(LUTS_DIR):
             return "missing"
-        entries = []
-        for name in _list_lut_files():
-            if name == _NO_LUTS:
-                continue
+
+        def fingerprint(name):
             path = os.path.join(LUTS_DIR, name)
             try:
-                entries.append(f"{name}:{os.path.getmtime(path)}:{os.path.getsize(path)}")
+                return f"{name}:{os.path.getmtime(path)}:{os.path.getsize(path)}"
             except OSError:
-                entries.append(f"{name}:missing")
-        return "|".join(entries) if entries else "empty"
+                return f"{name}:missing"
+
+        return "|".join(fingerprint(n) for n in _list_lut_files() if n != _NO_LUTS) or "empty"
 
     @classmethod
     def _load_lut(cls, lut_name):

@@ -43,18 +43,21 @@ _ADJUST_BOUNDS = {
 }
 
 
+def _slider_value(raw) -> float:
+    try:
+        return float(raw)
+    except Exception:               # None, "", a list ...: the reference reads such a slider as 0
+        return 0.0
+
+
 def _normalize_adjust_settings(settings=None):
-    """Same contract as the reference (:280-304): non-dict -> defaults, unparsable -> 0, values clamped to the
-    slider range, ``enabled`` true unless it is literally ``False``."""
-    settings = settings if isinstance(settings, dict) else {}
-    normalized = {"enabled": settings.get("enabled", True) is not False}
-    for key, (lo, hi) in _ADJUST_BOUNDS.items():
-        try:
-            value = float(settings.get(key, 0.0))
-        except Exception:
-            value = 0.0
-        normalized[key] = max(lo, min(hi, value))
-    return normalized
+    """The routes' settings contract (reference :280-304; fixtures tests/golden/adjust_normalized.json): anything but a dict means
+    defaults, an unparsable slider is 0, every slider is clamped to its range (`max(lo, min(hi, v))`: a NaN clamps to `hi`), and
+    ``enabled`` is true unless it is literally ``False``."""
+    given = settings if isinstance(settings, dict) else {}
+    out = {"enabled": given.get("enabled", True) is not False}
+    out.update((name, max(lo, min(hi, _slider_value(given.get(name, 0.0))))) for name, (lo, hi) in _ADJUST_BOUNDS.items())
+    return out
 
 
 def _is_gpu_device(device) -> bool:
