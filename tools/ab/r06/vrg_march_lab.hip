@@ -40,6 +40,13 @@
 #ifndef LAB_MINW
 #define LAB_MINW 3
 #endif
+#ifndef LAB_SLOTS
+#define LAB_SLOTS 2            // LDS landing slots per wave of the quad-cooperative gathers: 3 = three siblings' gathers in flight (with LAB_MINW=2: two workgroups per CU, 256 VGPRs)
+#endif
+#define LAB_SL(m) ((m) % LAB_SLOTS)
+#ifndef LAB_ROTATE
+#define LAB_ROTATE 0           // 1: the NEXT row's noise (three Philox calls, six Box-Muller pairs: ~240 VALU instructions) is computed right behind the gathers' issue, in front of the first wait
+#endif
 #ifndef LAB_BALLAST
 #define LAB_BALLAST 0          // extra independent v_fma_f32 per row step (4 chains), a quarter behind each sibling: is the loop VALU-issue bound?
 #endif
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
     // 1040-byte rounds
     constexpr bool QUADP = (STAGES & VRG_STAGE_GRAIN) && (STAGES & VRG_STAGE_LUT) && WAVES == 4;
     constexpr int Q_ROUND = 1040, Q_SLOT = 6 * Q_ROUND;
-    __shared__ __attribute__((aligned(16))) char quad_slots[QUADP ? WGW * 2 * Q_SLOT : 16];
+    __shared__ __attribute__((aligned(16))) char quad_slots[QUADP ? WGW * LAB_SLOTS * Q_SLOT : 16];
 
     constexpr int CLO = SHARPEN ? 1 : 0;     // first lane that produces output
     constexpr int CW = SHARPEN ? 61 : 63;    // output lanes per wave (lane 63 only provides noise)
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
             const int nc = P.n - 1;
             // the wave's landing slots: LDS byte address (for M0) and this lane's two read positions
             const int wv_in_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-            char* const quad_my = quad_slots + (QUADP ? wv_in_wg * 2 * Q_SLOT : 0);
+            char* const quad_my = quad_slots + (QUADP ? wv_in_wg * LAB_SLOTS * Q_SLOT : 0);
             const unsigned quad_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) char*)quad_my);
             const char* const quad_a0 = quad_my + (lane & 3) * Q_ROUND + (lane & ~3) * 16;
             const char* const quad_a1 = quad_my + (4 + ((lane & 3) >> 1)) * Q_ROUND + ((lane & ~3) + 2 * (lane & 1)) * 16;
@@ -472,6 +479,13 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                 nzj[0] = a.x; nzj[1] = a.y; nzj[2] = b.x; nzj[3] = b.y;
             };
             float nz[3][4];
+#if LAB_ROTATE
+            {
+                const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
+            }
+#endif
             float bl0 = (float)lane;
             auto ballast = [&]() {
 #pragma unroll
@@ -482,18 +496,27 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
             while (more) {
                 u3 xraw[4];           // the next row's pixels, requested at the END of this row step (see there)
                 // ---- noise: three Philox calls per lane, twelve normals
+#if !LAB_ROTATE
                 {
                     const uint32_t idx0 = (uint32_t)(rowbase - q0s) + 3u * (uint32_t)lane;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) noise_call(idx0, j, nz[j]);
                 }
+#else
+                float nzn[3][4];
+                auto next_noise = [&]() {
+                    const uint32_t idx0 = (uint32_t)(rowbase + E - q0s) + 3u * (uint32_t)lane;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) noise_call(idx0, j, nzn[j]);
+                };
+#endif
                 const float nrm[4][3] = {{nz[0][0], nz[1][0], nz[2][0]},
                                          {nz[1][1], nz[2][1], lane_next(nz[0][1])},
                                          {nz[2][2], lane_next(nz[0][2]), lane_next(nz[1][2])},
                                          {nz[0][3], nz[1][3], nz[2][3]}};
                 // ---- grain, LUT axes + gathers
                 float V[4][3];
-                LutFetch F[2];
+                LutFetch F[LAB_SLOTS];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const float x[3] = {xin[m].r, xin[m].g, xin[m].b};
@@ -510,10 +533,10 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                 // statements carry a memory clobber, the waits are counted by hand -- between the issue of a sibling's six rounds and their
                 // use only the next sibling's six rounds are issued (the row's other memory operations sit at its end).
                 auto lut_issue_dma = [&](int m) {
-                    F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
-                    F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
-                    F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
-                    const int cell = ((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (LUT_REC_FLOATS * 4);
+                    F[LAB_SL(m)].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                    F[LAB_SL(m)].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                    F[LAB_SL(m)].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                    const int cell = ((F[LAB_SL(m)].B.cell * nc + F[LAB_SL(m)].G.cell) * P.n + F[LAB_SL(m)].R.cell) * (LUT_REC_FLOATS * 4);
                     const int ql16 = (lane & 3) * 16, qh16 = 64 + (lane & 1) * 16;
                     const int v0 = __builtin_amdgcn_update_dpp(0, cell, 0x00, 0xf, 0xf, false) + ql16;   // quad_perm [0,0,0,0]
                     const int v1 = __builtin_amdgcn_update_dpp(0, cell, 0x55, 0xf, 0xf, false) + ql16;   // [1,1,1,1]
@@ -521,7 +544,7 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                     const int v3 = __builtin_amdgcn_update_dpp(0, cell, 0xFF, 0xf, 0xf, false) + ql16;   // [3,3,3,3]
                     const int v4 = __builtin_amdgcn_update_dpp(0, cell, 0x50, 0xf, 0xf, false) + qh16;   // [0,0,1,1]
                     const int v5 = __builtin_amdgcn_update_dpp(0, cell, 0xFA, 0xf, 0xf, false) + qh16;   // [2,2,3,3]
-                    const unsigned l0 = quad_lds + (unsigned)((m & 1) * Q_SLOT);
+                    const unsigned l0 = quad_lds + (unsigned)(LAB_SL(m) * Q_SLOT);
                     unsigned keep;
                     asm volatile("s_mov_b32 %0, m0\n\t"
                                  "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
@@ -537,47 +560,47 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                                  : "memory");
                 };
                 auto lut_read_dma = [&](int m) {          // the pixel's six pieces out of its slot (after the hand-counted wait)
-                    const char* s0 = quad_a0 + (m & 1) * Q_SLOT;
-                    const char* s1 = quad_a1 + (m & 1) * Q_SLOT;
-                    F[m & 1].lo[0] = *reinterpret_cast<const f32x4*>(s0);
-                    F[m & 1].lo[1] = *reinterpret_cast<const f32x4*>(s0 + 16);
-                    F[m & 1].lo[2] = *reinterpret_cast<const f32x4*>(s0 + 32);
-                    F[m & 1].hi[0] = *reinterpret_cast<const f32x4*>(s0 + 48);
-                    F[m & 1].hi[1] = *reinterpret_cast<const f32x4*>(s1);
-                    F[m & 1].hi[2] = *reinterpret_cast<const f32x4*>(s1 + 16);
+                    const char* s0 = quad_a0 + LAB_SL(m) * Q_SLOT;
+                    const char* s1 = quad_a1 + LAB_SL(m) * Q_SLOT;
+                    F[LAB_SL(m)].lo[0] = *reinterpret_cast<const f32x4*>(s0);
+                    F[LAB_SL(m)].lo[1] = *reinterpret_cast<const f32x4*>(s0 + 16);
+                    F[LAB_SL(m)].lo[2] = *reinterpret_cast<const f32x4*>(s0 + 32);
+                    F[LAB_SL(m)].hi[0] = *reinterpret_cast<const f32x4*>(s0 + 48);
+                    F[LAB_SL(m)].hi[1] = *reinterpret_cast<const f32x4*>(s1);
+                    F[LAB_SL(m)].hi[2] = *reinterpret_cast<const f32x4*>(s1 + 16);
                 };
                 auto lut_issue = [&](int m) {
                     if (QUADP) { lut_issue_dma(m); return; }
                     if ((STAGES & VRG_STAGE_LUT) && WAVES != 4) {       // node table in LDS: the eight corners of the cell, laid out as the record form has them
-                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                        F[LAB_SL(m)].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                        F[LAB_SL(m)].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                        F[LAB_SL(m)].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
                         const int n = P.n, nn = n * n;
-                        const f32x4* t = lut_nodes + ((F[m & 1].B.cell * n + F[m & 1].G.cell) * n + F[m & 1].R.cell);
+                        const f32x4* t = lut_nodes + ((F[LAB_SL(m)].B.cell * n + F[LAB_SL(m)].G.cell) * n + F[LAB_SL(m)].R.cell);
                         const f32x4 q000 = t[0], q001 = t[nn], q010 = t[n], q011 = t[nn + n];
                         const f32x4 q100 = t[1], q101 = t[nn + 1], q110 = t[n + 1], q111 = t[nn + n + 1];
-                        F[m & 1].lo[0] = f32x4{q000.x, q001.x, q010.x, q011.x};  F[m & 1].hi[0] = f32x4{q100.x, q101.x, q110.x, q111.x};
-                        F[m & 1].lo[1] = f32x4{q000.y, q001.y, q010.y, q011.y};  F[m & 1].hi[1] = f32x4{q100.y, q101.y, q110.y, q111.y};
-                        F[m & 1].lo[2] = f32x4{q000.z, q001.z, q010.z, q011.z};  F[m & 1].hi[2] = f32x4{q100.z, q101.z, q110.z, q111.z};
+                        F[LAB_SL(m)].lo[0] = f32x4{q000.x, q001.x, q010.x, q011.x};  F[LAB_SL(m)].hi[0] = f32x4{q100.x, q101.x, q110.x, q111.x};
+                        F[LAB_SL(m)].lo[1] = f32x4{q000.y, q001.y, q010.y, q011.y};  F[LAB_SL(m)].hi[1] = f32x4{q100.y, q101.y, q110.y, q111.y};
+                        F[LAB_SL(m)].lo[2] = f32x4{q000.z, q001.z, q010.z, q011.z};  F[LAB_SL(m)].hi[2] = f32x4{q100.z, q101.z, q110.z, q111.z};
                         return;
                     }
                     if (STAGES & VRG_STAGE_LUT) {
-                        F[m & 1].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
-                        F[m & 1].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
-                        const uint32_t cell = (uint32_t)((F[m & 1].B.cell * nc + F[m & 1].G.cell) * P.n + F[m & 1].R.cell) * (uint32_t)(LUT_REC_FLOATS * 4);
+                        F[LAB_SL(m)].R = lut_axis(V[m][0], 0.0f, 1.0f, 1, P.top);
+                        F[LAB_SL(m)].G = lut_axis(V[m][1], 0.0f, 1.0f, 1, P.top);
+                        F[LAB_SL(m)].B = lut_axis(V[m][2], 0.0f, 1.0f, 1, P.top);
+                        const uint32_t cell = (uint32_t)((F[LAB_SL(m)].B.cell * nc + F[LAB_SL(m)].G.cell) * P.n + F[LAB_SL(m)].R.cell) * (uint32_t)(LUT_REC_FLOATS * 4);
                         const f32x4* q = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(P.cells) + cell);
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
-                            F[m & 1].lo[ch] = q[ch];
-                            F[m & 1].hi[ch] = q[3 + ch];
+                            F[LAB_SL(m)].lo[ch] = q[ch];
+                            F[LAB_SL(m)].hi[ch] = q[3 + ch];
                         }
                     }
                 };
                 u3 resq[4];
                 auto finish_emit = [&](int m) {
                     float Dn[3] = {V[m][0], V[m][1], V[m][2]};
-                    if (STAGES & VRG_STAGE_LUT) lut_fetch_finish(F[m & 1], Dn);
+                    if (STAGES & VRG_STAGE_LUT) lut_fetch_finish(F[LAB_SL(m)], Dn);
                     float res[3];
 #pragma unroll
                     for (int c = 0; c < (SHARPEN ? 0 : 3); ++c) res[c] = Dn[c];          // no stencil: the row as it is
@@ -605,9 +628,41 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                 // the gathers of sibling m + 1 are in flight while sibling m is interpolated, sharpened and stored.  The hand-counted waits
                 // of the quad form rest on the row's other memory operations sitting at its end: nothing but the next sibling's six rounds
                 // enters the (in-order) memory counter between a sibling's issue and its use.
+#if LAB_SLOTS == 3
+                // three siblings' gathers in flight: sibling m is read when at most the two later siblings' twelve rounds are outstanding
+                lut_issue(0);
+                lut_issue(1);
+                lut_issue(2);
+                LAB_FENCE();
+#if LAB_ROTATE
+                next_noise();
+                LAB_FENCE();
+#endif
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); lut_read_dma(0); }
+                finish_emit(0);
+                ballast();
+                LAB_FENCE();
+                lut_issue(3);
+                LAB_FENCE();
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); lut_read_dma(1); }
+                finish_emit(1);
+                ballast();
+                LAB_FENCE();
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(2); }
+                finish_emit(2);
+                ballast();
+                LAB_FENCE();
+                if (QUADP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lut_read_dma(3); }
+                finish_emit(3);
+                ballast();
+#else
                 lut_issue(0);
                 lut_issue(1);
                 LAB_FENCE();
+#if LAB_ROTATE
+                next_noise();
+                LAB_FENCE();
+#endif
                 if (QUADP) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); lut_read_dma(0); }
                 finish_emit(0);
                 ballast();
@@ -627,6 +682,7 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                 if (QUADP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lut_read_dma(3); }
                 finish_emit(3);
                 ballast();
+#endif
                 {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -644,6 +700,12 @@ __global__ __launch_bounds__(64 * (WAVES == 4 ? LAB_WGW : WAVES), WAVES == 4 ? M
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) xin[m] = px3{__uint_as_float(xraw[m].x), __uint_as_float(xraw[m].y), __uint_as_float(xraw[m].z)};
+#if LAB_ROTATE
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nz[j][q] = nzn[j][q];
+#endif
                 // ---- advance; is the next row steady as well?
                 ++rows_done;
                 ++rho;
