@@ -12,6 +12,7 @@ namespace vrg {
 // compiler does not hoist out of a divergent pixel loop).
 struct FrameCtx {
     float ims[6], rms[6];        // [3][2] (mean, std) of the frame / of the reference frame it is matched to
+    SigmaRecip sr;               // the frame's refined reciprocals of std (vrg_pixel_math.hpp: the unscaled form of (lab - mean) / std)
     uint64_t seed, off;          // generator seed / offset of the frame's noise chunk
     uint64_t elem0;              // element index of the frame's first element inside its chunk
 };
@@ -24,9 +25,12 @@ __device__ __forceinline__ FrameCtx frame_ctx(const ChainK& D, int64_t f) {
         const float* rms = D.cm.ref_ms + (D.cm.ref_frames == 1 ? 0 : (f % D.cm.ref_frames)) * 6;
 #pragma unroll
         for (int i = 0; i < 6; ++i) { C.ims[i] = ims[i]; C.rms[i] = rms[i]; }
+        C.sr = sigma_recip(C.ims);
     } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) { C.ims[i] = 0.0f; C.rms[i] = 0.0f; }
+        C.sr.usable = false;
+        C.sr.y1[0] = C.sr.y1[1] = C.sr.y1[2] = 0.0f;
     }
     if (STAGES & VRG_STAGE_GRAIN) {
         const int64_t chunk = f / D.noise.chunk_frames;
@@ -59,9 +63,9 @@ __device__ __forceinline__ void chain_apply_stages(const ChainK& D, const FrameC
     if (STAGES & VRG_STAGE_COLORMATCH) {
         float g[3];
         if (STAGES & VRG_STAGE_FROM_LAB)
-            colormatch_from_lab(v, C.ims, C.rms, D.cm.K, D.cm.T, g, PT);     // the input pixel is already Lab
+            colormatch_from_lab(v, C.ims, C.rms, D.cm.K, D.cm.T, g, PT, &C.sr);     // the input pixel is already Lab
         else
-            colormatch_pixel(v, C.ims, C.rms, D.cm.K, D.cm.T, g, PT);
+            colormatch_pixel(v, C.ims, C.rms, D.cm.K, D.cm.T, g, PT, &C.sr);
         v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
     }
     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];

@@ -871,6 +871,9 @@ VRG_HD float dev_pow_ziv(float x, float y, const float* T, uint32_t lo_bits, uin
     if (T) {
         float r;
         if (ziv_try(x, y, T, lo_bits, hi_bits, r)) return r;
+#if defined(VRG_LAB_VARIANT_SOURCE) && defined(LAB_ZIV_NO_FALLBACK)      /* tools/ab: the cost of the transcription branches (wrong bits in 0.1-0.3 % of the lanes) */
+        return r;
+#endif
     }
 #else
     (void)T; (void)lo_bits; (void)hi_bits;
@@ -890,6 +893,9 @@ VRG_HD void dev_pow_ziv3(const float x[3], float y, const float* T, uint32_t lo_
         const bool s1 = ziv_try(x[1], y, T, lo_bits, hi_bits, r1);
         const bool s2 = ziv_try(x[2], y, T, lo_bits, hi_bits, r2);
         o[0] = r0; o[1] = r1; o[2] = r2;
+#if defined(VRG_LAB_VARIANT_SOURCE) && defined(LAB_ZIV_NO_FALLBACK)
+        if (s0 | s1 | s2 | true) return;
+#endif
         if (!s0) o[0] = dev_pow_t<GUARD>(x[0], y);
         if (!s1) o[1] = dev_pow_t<GUARD>(x[1], y);
         if (!s2) o[2] = dev_pow_t<GUARD>(x[2], y);
@@ -1106,35 +1112,105 @@ VRG_HD float recip_newton(float s) {
 VRG_HD float cm_div_sigma(float d, float sigma, const PowTables&) { return div_const(d, sigma, recip_newton(sigma)); }
 VRG_HD float cm_div_sigma(float d, float sigma, const DevMath&) { return d / sigma; }
 
-template <class MATH>
-VRG_HD float colormatch_channel(float lab, float mu, float sigma, float mu_ref, float sigma_ref, float K, float T, const MATH& M) {
-    const float d = lab - mu;
-    const float z = cm_div_sigma(d, sigma, M);
-    const float w = z * sigma_ref;
-    const float m = w + mu_ref;
-    const float a = K * m;
-    const float b = T * lab;
-    return a + b;
+// ------------------------------------------------------------------------------------------
+// (lab - mu) / sigma under the device policy is the IEEE quotient: the backend's sequence (AMDGPU LowerFDIV32, as hipcc emits it and as
+// torch's kernel runs it) is
+//     bs = v_div_scale(sigma), as = v_div_scale(d);  y0 = v_rcp_f32(bs);  e = fma(-bs, y0, 1);  y1 = fma(e, y0, y0);
+//     q = as * y1;  r = fma(-bs, q, as);  q1 = fma(r, y1, q);  r1 = fma(-bs, q1, as);  v_div_fmas(r1, y1, q1);  v_div_fixup
+// i.e. 12 instructions of which two scalings, the v_div_fmas and the fix-up issue at half rate and the reciprocal at a quarter (37 issue
+// units, profiles/r06_valu_instruction_costs.json).  sigma is ONE value per (frame, channel): y1 is a per-frame constant, and when the
+// operands cannot trigger a scaling or a fix-up -- v_div_scale_f32 returns its operand and clears VCC, v_div_fmas_f32 is then a plain FMA,
+// v_div_fixup_f32 returns its first operand (ISA pseudocode) -- the quotient is the five full-rate operations q .. fma(r1, y1, q1) on
+// the unscaled operands: the same roundings, 12 issue units.  That holds when
+//     2^-40 <= sigma <= 2^30 and 2^-60 <= |mu| <= 2^40      (per frame: SigmaRecip::usable; then d = lab - mu is +0 or |d| >= 2^-85 --
+//                                                            Sterbenz inside [mu/2, 2 mu], >= |mu| / 2 outside -- never -0, never tiny:
+//                                                            exponent(d) > 23, d / sigma >= 2^-115 is normal, 1 / sigma is normal)
+//     |d_L| + |d_a| + |d_b| < 2^40                          (per pixel, one wave-uniform branch: exponent(d) - exponent(sigma) < 96, nothing
+//                                                            overflows; an Inf or NaN in any channel fails the comparison)
+// and d == +0 gives +0 through the FMAs as through the fix-up.  Everything else takes the division itself.  tests/test_gpu_parity.py
+// compares the two forms on 2^27 random (d, sigma, mu) triples and at the edges of the conditions.
+// ------------------------------------------------------------------------------------------
+struct SigmaRecip { float y1[3]; bool usable; };
+
+VRG_HD SigmaRecip sigma_recip(const float* img_ms) {
+    SigmaRecip R;
+    R.usable = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float mu = __builtin_fabsf(img_ms[2 * c]), s = img_ms[2 * c + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float y0 = __builtin_amdgcn_rcpf(s);
+#else
+        const float y0 = 1.0f / s;
+#endif
+        const float e = __builtin_fmaf(-s, y0, 1.0f);
+        R.y1[c] = __builtin_fmaf(e, y0, y0);
+        R.usable = R.usable && s >= 0x1p-40f && s <= 0x1p30f && mu >= 0x1p-60f && mu <= 0x1p40f;
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    R.usable = false;        // the host build (tests/host_math) has no v_rcp_f32: the division itself
+#endif
+    return R;
+}
+
+VRG_HD float div_sigma_unscaled(float d, float s, float y1) {
+    const float q = d * y1;
+    const float r = __builtin_fmaf(-s, q, d);
+    const float q1 = __builtin_fmaf(r, y1, q);
+    const float r1 = __builtin_fmaf(-s, q1, d);
+    return __builtin_fmaf(r1, y1, q1);
+}
+
+// z = (lab - mu) / sigma for the three channels
+VRG_HD void cm_normalise3(const float lab[3], const float* img_ms, float z[3], const PowTables& M, const SigmaRecip*) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[c] = cm_div_sigma(lab[c] - img_ms[2 * c], img_ms[2 * c + 1], M);
+}
+VRG_HD void cm_normalise3(const float lab[3], const float* img_ms, float z[3], const DevMath& M, const SigmaRecip* SR) {
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = lab[c] - img_ms[2 * c];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SR && SR->usable) {
+        const float mag = (__builtin_fabsf(d[0]) + __builtin_fabsf(d[1])) + __builtin_fabsf(d[2]);
+        if (__builtin_amdgcn_ballot_w64(!(mag < 0x1p40f)) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) z[c] = div_sigma_unscaled(d[c], img_ms[2 * c + 1], SR->y1[c]);
+            return;
+        }
+    }
+#else
+    (void)SR;
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[c] = cm_div_sigma(d[c], img_ms[2 * c + 1], M);
 }
 
 // ms: {mean, std+1e-5} per channel.  Lab of the pixel -> matched, blended, back to RGB.
+// SR: the frame's SigmaRecip (device policy only), or nullptr: every quotient by the division
 template <class MATH>
 VRG_HD void colormatch_from_lab(const float lab[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
-                                const MATH& PT) {
-    float bl[3];
+                                const MATH& PT, const SigmaRecip* SR = nullptr) {
+    float z[3], bl[3];
+    cm_normalise3(lab, img_ms, z, PT, SR);
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        bl[c] = colormatch_channel(lab[c], img_ms[2 * c], img_ms[2 * c + 1], ref_ms[2 * c], ref_ms[2 * c + 1], K, T, PT);
+    for (int c = 0; c < 3; ++c) {
+        const float w = z[c] * ref_ms[2 * c + 1];
+        const float m = w + ref_ms[2 * c];
+        const float a = K * m;
+        const float b = T * lab[c];
+        bl[c] = a + b;
+    }
     lab_to_rgb(bl, o, PT);
     // final .clamp(0,1) of nodes.py:121 is idempotent after lab_to_rgb's clip
 }
 
 template <class MATH>
 VRG_HD void colormatch_pixel(const float rgb[3], const float* img_ms, const float* ref_ms, float K, float T, float o[3],
-                             const MATH& PT) {
+                             const MATH& PT, const SigmaRecip* SR = nullptr) {
     float lab[3];
     rgb_to_lab(rgb, lab, PT);
-    colormatch_from_lab(lab, img_ms, ref_ms, K, T, o, PT);
+    colormatch_from_lab(lab, img_ms, ref_ms, K, T, o, PT, SR);
 }
 
 }  // namespace vrg

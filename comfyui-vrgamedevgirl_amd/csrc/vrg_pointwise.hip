@@ -784,7 +784,8 @@ __global__ __launch_bounds__(256) void k_colormatch_apply(const px3* __restrict_
     const float* ims = cm.img_ms + f * 6;
     const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
     float o[3];
-    colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT);
+    const SigmaRecip SR = sigma_recip(ims);
+    colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT, &SR);
     store_px_stream(out + at, px3{o[0], o[1], o[2]});
 }
 
@@ -807,12 +808,13 @@ __global__ __launch_bounds__(256) void k_colormatch_apply4(const px3* __restrict
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(out + f * pixels_per_frame), 0, pixels_per_frame * 12, 0x00020000);
     const float* ims = cm.img_ms + f * 6;
     const float* rms = cm.ref_ms + (cm.ref_frames == 1 ? 0 : (f % cm.ref_frames)) * 6;
+    const SigmaRecip SR = sigma_recip(ims);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int32_t p = p0 + 256 * j;
         const float x[3] = {v[j].r, v[j].g, v[j].b};
         float o[3];
-        colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT);
+        colormatch_pixel(x, ims, rms, cm.K, cm.T, o, PT, &SR);
         __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2])}, rs,
                                               (int)(p < pixels_per_frame ? (uint32_t)p * 12u : 0x80000000u), 0, 0);
     }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(1024) void k_dbg_lut_passes(const px3* __restrict__
 //  op 9 / 10 / 11: dev_pow_t<DEV_POW_ANY / _OVF / _UNIT>(x, y), the scaffolding-free transcription of ocml powf the device
 //        policy uses (_OVF in srgb -> linear, _UNIT in linear -> srgb and the Lab cube root)
 //  op 5: Lab of an RGB triple / op 6: RGB of a Lab triple, device policy; op 7 / 8: the same with the fast policy
+//  op 20: {lab, mean, std} -> {div_sigma_unscaled, (lab - mean) / std, 1.0 where sigma_recip's and the per-pixel condition hold}
 __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ in, float* __restrict__ out, int64_t n, int op, float y,
                                                       DevMath dm) {
     VRG_CM_MATH(PT, true, true, dm);
@@ -279,7 +280,15 @@ __global__ __launch_bounds__(256) void k_dbg_cm_math(const float* __restrict__ i
     dm.logt = zivt;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (op >= 16) {          // 16 / 17: ocml's ln x = hi + lo (epln, as transcribed); 18 / 19: dev_pow_ziv's table log
+    if (op == 20) {          // {lab, mean, std}: the unscaled form of (lab - mean) / std, the division itself, and whether the conditions admit the former
+        const float lab = in[3 * i], mu = in[3 * i + 1], sd = in[3 * i + 2];
+        const float ms[6] = {mu, sd, mu, sd, mu, sd};
+        const SigmaRecip R = sigma_recip(ms);
+        const float d = lab - mu;
+        out[3 * i] = div_sigma_unscaled(d, sd, R.y1[0]);
+        out[3 * i + 1] = d / sd;
+        out[3 * i + 2] = (R.usable && (__builtin_fabsf(d) + __builtin_fabsf(d)) + __builtin_fabsf(d) < 0x1p40f) ? 1.0f : 0.0f;
+    } else if (op >= 16) {          // 16 / 17: ocml's ln x = hi + lo (epln, as transcribed); 18 / 19: dev_pow_ziv's table log
         float a, b;
         float eh, aj;
         if (op <= 17) dev_epln<DEV_POW_UNIT>(in[i], a, b); else ziv_log(in[i], zivt, a, b, eh, aj);
@@ -686,7 +695,7 @@ int vrg_debug_copy_f32(const float* in, float* out, int64_t n_floats, int32_t mo
 }
 
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream) {
-    if (!in || !out || n <= 0 || op < 0 || op > 19) return VRG_ERR_BAD_ARG;
+    if (!in || !out || n <= 0 || op < 0 || op > 20) return VRG_ERR_BAD_ARG;
     const uint64_t blocks = (uint64_t)(n + 255) / 256;
     if (blocks > 0x7fffffffull) return VRG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(vrg::k_dbg_cm_math, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, in, out, n, op, y, vrg::host_dev_math());

@@ -35,7 +35,8 @@ int vrg_selftest_lanes(float* out128, void* stream);
  * (x >= 2^-20, 0 < y <= 0.5); 12 / 13 / 14 dev_pow_ziv(x, y) as sRGB -> linear / linear -> sRGB / the Lab cube root call it
  * (table logarithm + rounding test, the transcription where the test fails or x is outside the call site's domain);
  * 15: 1.0 where the rounding test of dev_pow_ziv fails for (x, y), else 0.0; 16 / 17 ocml's ln x (epln as transcribed), head / tail;
- * 18 / 19 dev_pow_ziv's table ln x, head / tail. */
+ * 18 / 19 dev_pow_ziv's table ln x, head / tail; 20 (n triples {lab, mean, std} -> triples): the unscaled FMA form of (lab - mean) / std,
+ * the division itself, and 1.0 where the conditions of the former hold (vrg_pixel_math.hpp, SigmaRecip). */
 int vrg_debug_cm_math(const float* in, float* out, int64_t n, int32_t op, float y, void* stream);
 /* Host-only (no GPU needed): the launch geometry vrg_lab_stats_torch_f32 derives -- torch's setReduceConfig on the MI355X -- for
  * `num_outputs` outputs of `reduce_len` contiguous fp32 elements, `vec` = 4 (mean) or 2 (std): cfg4 = {block_width, block_height,

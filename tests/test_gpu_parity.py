@@ -642,6 +642,43 @@ def test_device_math_divisions_are_torch_divisions(pkg, dev):
     assert torch.equal(torch.pow(x, 3.0).cpu(), torch.from_numpy((xn * xn) * xn))        # pow(., 3.0) is (x*x)*x
 
 
+def test_unscaled_sigma_division_is_the_division(pkg, dev):
+    """(lab - mean) / std of the colour transfer (nodes.py:112) is an IEEE quotient on the device.  The apply kernels evaluate it as the
+    backend's own division sequence WITHOUT its scalings and fix-up -- five FMAs around the frame's refined reciprocal -- wherever
+    sigma_recip()'s per-frame and the per-pixel condition hold (vrg_pixel_math.hpp): equal to torch's quotient bit for bit on 2^27 triples
+    of Lab-like values, on operands spread over the whole range the conditions admit (and beyond it: there the flag must be 0 or the
+    values still equal), and at the edges."""
+    g = torch.Generator(device=dev).manual_seed(77)
+
+    def check(lab, mu, sd, min_ok):
+        out = _dbg(pkg, torch.stack([lab, mu, sd], dim=-1), 20, triples=True)
+        fast, ieee, ok = out[..., 0], out[..., 1], out[..., 2] == 1
+        want = (lab - mu) / sd
+        assert torch.equal(torch.isnan(ieee), torch.isnan(want)) and torch.equal(torch.nan_to_num(ieee, nan=-7.0).view(torch.int32), torch.nan_to_num(want, nan=-7.0).view(torch.int32))
+        assert float(ok.float().mean()) >= min_ok, float(ok.float().mean())
+        assert not torch.isnan(want[ok]).any()
+        bad = fast[ok].view(torch.int32) != want[ok].view(torch.int32)
+        assert not bool(bad.any()), (int(bad.sum()), lab[ok][bad][:4], mu[ok][bad][:4], sd[ok][bad][:4])
+
+    n = 1 << 27
+    check((torch.rand(n, generator=g, device=dev) - 0.4) * 250.0, (torch.rand(n, generator=g, device=dev) - 0.5) * 200.0,
+          torch.exp(torch.rand(n, generator=g, device=dev) * 16.0 - 11.5), 0.999)                     # Lab-like; std + 1e-5 in 1e-5 .. 90
+    n = 1 << 25
+
+    def spread(lo, hi):      # +-2^U(lo, hi)
+        m = torch.exp2(torch.rand(n, generator=g, device=dev) * (hi - lo) + lo)
+        return torch.where(torch.rand(n, generator=g, device=dev) < 0.5, -m, m)
+    check(spread(-70, 45), spread(-65, 42), spread(-42, 32).abs(), 0.5)                             # across and beyond the conditions
+    mu = spread(-60, 40)
+    k = torch.randint(-6, 7, (n,), generator=g, device=dev, dtype=torch.int32)
+    near = (mu.view(torch.int32) + k).view(torch.float32)                                          # lab within a few ulp of the mean: d tiny or +0
+    check(near, mu, spread(-40, 30).abs(), 0.9)
+    edge = torch.tensor([[1.0, 1.0, 2.0 ** -40], [1.0, 2.0 ** -60, 2.0 ** 30], [-0.0, 2.0 ** -60, 1.0], [2.0 ** 39, -2.0 ** 38, 2.0 ** -40],
+                         [2.0 ** 40, 1.0, 1.0], [float("inf"), 1.0, 1.0], [float("nan"), 1.0, 1.0], [1.0, 0.0, 1.0], [0.0, 0.0, 1.0], [-0.0, 0.0, 1.0],
+                         [1e-45, 1.0, 1.0], [3.0, 3.0, 1e-5], [50.0, 50.000004, 1e-5], [1.0, 1.0, 2.0 ** -41], [1.0, 1.0, 2.0 ** 31]], device=dev)
+    check(edge[:, 0].contiguous(), edge[:, 1].contiguous(), edge[:, 2].contiguous(), 0.3)
+
+
 def test_lab_transforms_bit_equal_device_oracle(pkg, dev):
     x = _cm_image((3, 270, 480, 3), 11).to(dev)
     want_lab = R.kornia_rgb_to_lab(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()

@@ -68,15 +68,16 @@ def grain_lut(src):
 ref_ms = None
 
 
-def chain4_passes():
+def chain4_passes(src=None):
     global ref_ms
+    src = x if src is None else src
     if ref_ms is None:
         ref_ms = ops.reference_stats(x[:1])
     gen.manual_seed(5)
     ev = []
     w0, w1 = ops.HipEvent(), ops.HipEvent()
     w0.record()
-    ops.fused_chain(x, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), cm_chunk=1),
+    ops.fused_chain(src, ops.ChainSpec(grain=(0.04, 0.5, 4), lut=(lut, 10.0), colormatch=(ref_ms, 1.0), sharpen=("unsharp", 0.5, False), cm_chunk=1),
                     generator=gen, out=out, lab_workspace=ws, kernel_events=ev)
     w1.record()
     torch.cuda.synchronize()
@@ -102,6 +103,13 @@ def run_case(case):
         return {"grain_sharpen": timed(gs)}
     if case == "chain4":
         return {"chain4." + k: v for k, v in chain4_passes().items()}
+    if case == "chain4_video":
+        return {"chain4_video." + k: v for k, v in chain4_passes(xv).items()}
+    if case == "colormatch":           # configs[3]: the colour transfer alone (statistics + Lab image, torch-order statistics, apply)
+        global ref_ms
+        if ref_ms is None:
+            ref_ms = ops.reference_stats(x[:1])
+        return {"colormatch": timed(lambda: ops.color_match(x, x[:1], 1.0, ref_ms=ref_ms, out=out))}
     if case == "kernels":
         r = {}
         gen.manual_seed(5)

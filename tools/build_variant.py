@@ -2,6 +2,8 @@
     python tools/build_variant.py b -fno-slp-vectorize                               (every unit with the extra flags)
     python tools/build_variant.py c --unit vrg_march.hip -DVRG_MARCH_ROTATE=0        (only that unit rebuilt; the others linked from csrc/.obj)
     python tools/build_variant.py d --unit vrg_march.hip --source tools/ab/old.hip --no-unit-flags -mllvm -amdgpu-sched-strategy=max-ilp
+    python tools/build_variant.py e --unit vrg_produce.hip,vrg_apply_march.hip --source self -DLAB_ZIV_NO_FALLBACK=1   (several units; "self" = the unit's own
+                                                                  product source compiled as a lab variant, so that the LAB_ switches of the shared headers are let through)
 --source: compile this file in the unit's place (it must sit in csrc/ or include its headers by absolute path: it is copied into csrc/ under a
 temporary name); --no-unit-flags: drop build_ext.EXTRA_FLAGS of the unit (give the wanted ones explicitly).
 Used with tools/ab_interleaved.py --libs name=tools/ab/lib_<name>.so,..."""
@@ -29,17 +31,17 @@ be.build(verbose=False)                      # the default objects exist and are
 
 
 def one(src):
-    if unit is not None and src != unit:
+    if unit is not None and src not in unit.split(","):
         return os.path.join(be.CSRC, ".obj", src + ".o")
     obj = os.path.join(obj_dir, src + ".o")
     path = os.path.join(be.CSRC, src)
     tmp = None
-    if source is not None and src == unit:
+    if source is not None:
         tmp = os.path.join(be.CSRC, f"_variant_{name}_{src}")
-        shutil.copyfile(os.path.join(ROOT, source) if not os.path.isabs(source) else source, tmp)
+        shutil.copyfile(path if source == "self" else (os.path.join(ROOT, source) if not os.path.isabs(source) else source), tmp)
         path = tmp
     try:
-        flags = list(be.EXTRA_FLAGS.get(src, ())) if (unit_flags or src != unit) else []
+        flags = list(be.EXTRA_FLAGS.get(src, ())) if unit_flags else []
         if tmp:
             flags.append("-DVRG_LAB_VARIANT_SOURCE")        # a file that is not product source: vrg_common.hpp lets its -D switches through
         subprocess.run([be._hipcc(), *cflags, *flags, *extra, "-I", be.INCLUDE, "-x", "hip", "-c", path, "-o", obj], check=True)
