@@ -603,6 +603,25 @@ VRG_HD float dev_exp_core(float x) {
     return __builtin_ldexpf(VRG_HW_EXP2(a), (int)e);
 }
 
+// dev_exp_core for |x| < 2^20 whose result is a normal number -- every argument the Ziv route hands it from inside its domains (|y ln x|
+// <= 12 there) --: the same value with three half-rate instructions less.  rint(ph) as (ph + 1.5 * 2^23) - 1.5 * 2^23 (round to nearest
+// even, exact for |ph| < 2^22: what v_rndne_f32 returns), and ldexp(v_exp_f32(a), e) as an integer addition of e to the exponent field:
+// the sum's low mantissa bits ARE e in two's complement (the bit pattern is 0x4B400000 + e, and 0x4B400000 << 23 vanishes modulo 2^32),
+// v_exp_f32 of a in [-0.5, 0.5] is a normal number in [0.70, 1.42], and so is the scaled result.  One v_lshl_add_u32 instead of
+// v_rndne_f32 + v_cvt_i32_f32 + v_ldexp_f32 (9.3 instead of 13.4 issue units).  A NaN or out-of-range argument yields garbage here: the
+// callers' rounding / domain tests fail for exactly those lanes and send them to the transcription.
+VRG_HD float dev_exp_core_normal(float x) {
+    const float c = f32_from_bits(0x3fb8aa3bu);                      // log2(e), high word
+    const float ph = x * c;
+    const float f0 = __builtin_fmaf(x, c, -ph);
+    const float pl = __builtin_fmaf(x, f32_from_bits(0x32a5705fu), f0);
+    const float magic = f32_from_bits(0x4b400000u);                  // 1.5 * 2^23
+    const float t = ph + magic;
+    const float e = t - magic;
+    const float a = (ph - e) + pl;
+    return f32_from_bits(f32_bits(VRG_HW_EXP2(a)) + (f32_bits(t) << 23));
+}
+
 // ocml's epln: ln(x) = ln_hi + ln_lo
 template <int GUARD>
 VRG_HD void dev_epln(float x, float& ln_hi_out, float& ln_lo_out) {
@@ -847,6 +866,8 @@ VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
 }
 
 // The fast route alone: returns the candidate and whether the rounding test (and the domain test) passed.
+// IN_DOMAIN: the caller guarantees that x lies in [lo, hi] or is NaN (a NaN fails the rounding test by itself): no domain test.
+template <bool IN_DOMAIN = false>
 VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float& out) {
     float Lh, Ll, Eh, A;
     ziv_log(x, T, Lh, Ll, Eh, A);
@@ -858,10 +879,11 @@ VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t
     const float php = p17 + up;
     const float phm = p17 + dn;
     const float t = php - p17;                                       // exact; ocml's tail is y ln x - head = (p44 -+ ...) - t
-    const float e8 = dev_exp_core(php);
+    const float e8 = dev_exp_core_normal(php);
     const float rp = __builtin_fmaf(e8, up - t, e8);
     const float rm = __builtin_fmaf(e8, dn - t, e8);
     out = rp;
+    if (IN_DOMAIN) return (php == phm) & (rp == rm);
     return ((f32_bits(x) - lo_bits) <= (hi_bits - lo_bits)) & (php == phm) & (rp == rm);      // bitwise: no control flow here
 }
 
@@ -884,14 +906,14 @@ VRG_HD float dev_pow_ziv(float x, float y, const float* T, uint32_t lo_bits, uin
 // Three powers with one exponent (the three channels of a Lab transform): the three fast routes first, as straight-line code --
 // three independent chains for the scheduler to interleave, the three table reads in flight together -- then the (rare)
 // transcription per channel.  Same values as three dev_pow_ziv calls.
-template <int GUARD>
+template <int GUARD, bool IN_DOMAIN = false>
 VRG_HD void dev_pow_ziv3(const float x[3], float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float o[3]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (T) {
         float r0, r1, r2;
-        const bool s0 = ziv_try(x[0], y, T, lo_bits, hi_bits, r0);
-        const bool s1 = ziv_try(x[1], y, T, lo_bits, hi_bits, r1);
-        const bool s2 = ziv_try(x[2], y, T, lo_bits, hi_bits, r2);
+        const bool s0 = ziv_try<IN_DOMAIN>(x[0], y, T, lo_bits, hi_bits, r0);
+        const bool s1 = ziv_try<IN_DOMAIN>(x[1], y, T, lo_bits, hi_bits, r1);
+        const bool s2 = ziv_try<IN_DOMAIN>(x[2], y, T, lo_bits, hi_bits, r2);
         o[0] = r0; o[1] = r1; o[2] = r2;
 #if defined(VRG_LAB_VARIANT_SOURCE) && defined(LAB_ZIV_NO_FALLBACK)
         if (s0 | s1 | s2 | true) return;
@@ -948,15 +970,19 @@ VRG_HD float srgb_to_linear(float v, const DevMath& M) {
 }
 
 // the three channels at once (same values as three calls; the device policy phases its powers, see dev_pow_ziv3)
+// UNIT (device policy): the caller guarantees v in [0, 1 + 2^-22] or NaN -- the output of grain's or the cube's clamp, blended or not --,
+// so the power's base lies in its fast-path domain [0.0625, 2] (at most 1.0000003) and the domain test is dropped (ziv_try<IN_DOMAIN>)
+template <bool UNIT = false>
 VRG_HD void srgb_to_linear3(const float v[3], float o[3], const PowTables& T) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = srgb_to_linear(v[c], T);
 }
+template <bool UNIT = false>
 VRG_HD void srgb_to_linear3(const float v[3], float o[3], const DevMath& M) {
     float q[3], hi[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) q[c] = clamp_min(VRG_CM_DIVS(v[c] + 0.055f, 1.055, M), 0.0625f);
-    dev_pow_ziv3<DEV_POW_OVF>(q, M.e24, M.logt, 0x3d800000u, 0x40000000u, hi);                                        // fast path on [0.0625, 2]
+    dev_pow_ziv3<DEV_POW_OVF, UNIT>(q, M.e24, M.logt, 0x3d800000u, 0x40000000u, hi);                                  // fast path on [0.0625, 2]
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = v[c] > 0.04045f ? hi[c] : VRG_CM_DIVS(v[c], 12.92, M);
 }
@@ -1024,16 +1050,19 @@ VRG_HD float lab_f(float t, const MATH& T) {
     return t > thr ? pw : sc;
 }
 
+// UNIT (device policy): t = XYZ / white of a pixel whose RGB is in [0, 1 + 2^-22] or NaN: at most 1.000001, inside [0.008856, 4] after the clamp
+template <bool UNIT = false>
 VRG_HD void lab_f3(const float t[3], float o[3], const PowTables& T) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = lab_f(t[c], T);
 }
+template <bool UNIT = false>
 VRG_HD void lab_f3(const float t[3], float o[3], const DevMath& M) {
     const float thr = 0.008856f;
     float base[3], pw[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) base[c] = clamp_min(t[c], thr);
-    dev_pow_ziv3<DEV_POW_UNIT>(base, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u, pw);                                   // [0.008856, 4]
+    dev_pow_ziv3<DEV_POW_UNIT, UNIT>(base, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u, pw);                             // [0.008856, 4]
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = t[c] > thr ? pw[c] : 7.787f * t[c] + (float)(4.0 / 29.0);
 }
@@ -1046,17 +1075,17 @@ VRG_HD float dot3(float a, float x, float b, float y, float c, float z) {
     return s + r;
 }
 
-template <class MATH>
-VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const MATH& T) {
+template <bool UNIT, class MATH>
+VRG_HD void rgb_to_lab_t(const float rgb[3], float lab[3], const MATH& T) {
     float lin[3];
-    srgb_to_linear3(rgb, lin, T);
+    srgb_to_linear3<UNIT>(rgb, lin, T);
     const float r = lin[0], g = lin[1], b = lin[2];
     const float X = VRG_CM_DIVT(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f, T);
     const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b);   // / 1.0
     const float Z = VRG_CM_DIVT(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f, T);
     const float xyz[3] = {X, Y, Z};
     float f[3];
-    lab_f3(xyz, f, T);
+    lab_f3<UNIT>(xyz, f, T);
     const float fx = f[0], fy = f[1], fz = f[2];
     lab[0] = 116.0f * fy - 16.0f;
     const float dxy = fx - fy;
@@ -1064,6 +1093,11 @@ VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const MATH& T) {
     lab[1] = 500.0f * dxy;
     lab[2] = 200.0f * dyz;
 }
+template <class MATH>
+VRG_HD void rgb_to_lab(const float rgb[3], float lab[3], const MATH& T) { rgb_to_lab_t<false>(rgb, lab, T); }
+// the same values for a pixel that left grain's or the cube's clamp (RGB in [0, 1 + 2^-22] or NaN): the powers skip their domain tests
+template <class MATH>
+VRG_HD void rgb_to_lab_unit(const float rgb[3], float lab[3], const MATH& T) { rgb_to_lab_t<true>(rgb, lab, T); }
 
 template <class MATH>
 VRG_HD float lab_finv(float f, const MATH& T) {

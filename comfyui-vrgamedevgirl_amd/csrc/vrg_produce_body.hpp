@@ -122,6 +122,7 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
             for (int c = 0; c < 3; ++c) { s1[m][part][c] = 0.0; s2[m][part][c] = 0.0; }
 
 #define VRG_PR_PIPE 1     /* Lab-only form: 1 = pixels requested before the noise synthesis, 2 = and the LUT gathers pipelined, 3 = two siblings before, two after the barrier */
+    static_assert((STAGES & VRG_STAGE_GRAIN) != 0, "pass 1 of chains that START WITH GRAIN: its Lab transform relies on grain's clamp (rgb_to_lab_unit)");
     constexpr bool PIPE = VRG_PR_PIPE && !STATS && (STAGES & VRG_STAGE_GRAIN) && !(STAGES & VRG_STAGE_COLORMATCH);
     constexpr bool HAS_LUT = (STAGES & VRG_STAGE_LUT) != 0;
     for (int sub = 0; sub < PR_SUBS; ++sub) {
@@ -200,7 +201,7 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
                     pre[0] = gr[0]; pre[1] = gr[1]; pre[2] = gr[2];
                 }
                 if (VRG_PR_PIPE == 2 && m < 3) issue(m + 1);
-                rgb_to_lab(pre, lab, PT);
+                rgb_to_lab_unit(pre, lab, PT);      // pre left grain's / the cube's clamp
                 int p0;
                 int64_t e0;
                 if (place(m, p0, e0) && clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
@@ -219,7 +220,7 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
                 const float n[3] = {sn[m][p0], sn[m][p0 + 1], sn[m][p0 + 2]};
                 float pre[3], lab[3];
                 chain_apply_stages<STAGES>(D, FC0, x, n, pre, PT);
-                rgb_to_lab(pre, lab, PT);
+                rgb_to_lab_unit(pre, lab, PT);      // pre left grain's / the cube's clamp
                 if (clab) store_px_stream(reinterpret_cast<px3*>(clab + e0), px3{lab[0], lab[1], lab[2]});
                 const int part = TWO_PART ? (e0 >= fb[m] ? 1 : 0) : 0;
 #pragma unroll
