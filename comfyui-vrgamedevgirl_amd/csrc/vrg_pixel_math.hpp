@@ -60,6 +60,11 @@ VRG_HD float clamp01(float v) {
 }
 // clamp(v, min=lo)
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
+// The base of a power whose value is only USED for v above the threshold (sRGB <-> linear, the Lab cube root: the reference evaluates
+// pow on every element and selects afterwards): max(v, lo) in one v_max_f32 -- a NaN becomes lo here, and the select that follows takes
+// the other branch for it (NaN > threshold is false), which is NaN: the same element the reference produces.  (clamp_min keeps the NaN
+// and costs a compare, a select and their VCC wait states.)
+VRG_HD float pow_base_min(float v, float lo) { return __builtin_fmaxf(v, lo); }
 // clamp(v, 0, 1) in one v_med3_f32 where NaN cannot occur or the reference leaves NaN undefined (LUT index)
 VRG_HD float clamp01_finite(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -856,9 +861,13 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 #define VRG_ZIV_REL 1
 VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
 #if VRG_ZIV_REL
-    const float a = __builtin_fabsf(Lh), b = __builtin_fabsf(Eh);
-    const float rel = (a > b ? a : b) * f32_from_bits(0x2e06f428u);                 // 2^-34.92 = 1.25 x the measured maximum
-    return y * (rel < A ? rel : A);
+    // (v_max_f32 / v_min_f32: the ternaries compiled to a compare, a select and their VCC wait states each; a NaN here fails the rounding test anyway)
+    const float rel = __builtin_fmaxf(__builtin_fabsf(Lh), __builtin_fabsf(Eh)) * f32_from_bits(0x2e06f428u);      // 2^-34.92 = 1.25 x the measured maximum
+#if defined(__HIP_DEVICE_COMPILE__)
+    return y * __builtin_amdgcn_fmed3f(rel, A, 0.0f);       // min(rel, A) of two non-negative numbers; v_min_f32 would first canonicalise the table word (a v_max_f32 A, A)
+#else
+    return y * __builtin_fminf(rel, A);
+#endif
 #else
     (void)Lh; (void)Eh;
     return y * A;
@@ -955,7 +964,7 @@ VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float t = v + 0.055f;
     const float q = VRG_DIVC(t, 1.055f);
     // the power is only selected for v > 0.04045 (q > 0.09): keep its argument in pow_pos's domain
-    const float hi = pow_pos(clamp_min(q, 0.0625f), 2.4f, T);
+    const float hi = pow_pos(pow_base_min(q, 0.0625f), 2.4f, T);
     const float lo = VRG_DIVC(v, 12.92f);
     return v > 0.04045f ? hi : lo;
 }
@@ -964,7 +973,7 @@ VRG_HD float srgb_to_linear(float v, const DevMath& M) {
     const float q = VRG_CM_DIVS(t, 1.055, M);
     // (the reference evaluates pow on every element and selects afterwards: for v <= 0.04045 the value is discarded, so the
     //  base only has to stay in dev_pow's domain there)
-    const float hi = dev_pow_ziv<DEV_POW_OVF>(clamp_min(q, 0.0625f), M.e24, M.logt, 0x3d800000u, 0x40000000u);        // fast path on [0.0625, 2]
+    const float hi = dev_pow_ziv<DEV_POW_OVF>(pow_base_min(q, 0.0625f), M.e24, M.logt, 0x3d800000u, 0x40000000u);        // fast path on [0.0625, 2]
     const float lo = VRG_CM_DIVS(v, 12.92, M);
     return v > 0.04045f ? hi : lo;
 }
@@ -981,7 +990,7 @@ template <bool UNIT = false>
 VRG_HD void srgb_to_linear3(const float v[3], float o[3], const DevMath& M) {
     float q[3], hi[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) q[c] = clamp_min(VRG_CM_DIVS(v[c] + 0.055f, 1.055, M), 0.0625f);
+    for (int c = 0; c < 3; ++c) q[c] = pow_base_min(VRG_CM_DIVS(v[c] + 0.055f, 1.055, M), 0.0625f);
     dev_pow_ziv3<DEV_POW_OVF, UNIT>(q, M.e24, M.logt, 0x3d800000u, 0x40000000u, hi);                                  // fast path on [0.0625, 2]
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = v[c] > 0.04045f ? hi[c] : VRG_CM_DIVS(v[c], 12.92, M);
@@ -989,7 +998,7 @@ VRG_HD void srgb_to_linear3(const float v[3], float o[3], const DevMath& M) {
 
 VRG_HD float linear_to_srgb(float v, const PowTables& T) {
     const float thr = 0.0031308f;
-    const float base = clamp_min(v, thr);
+    const float base = pow_base_min(v, thr);
     const float pw = pow_pos(base, (float)(1.0 / 2.4), T);
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
@@ -997,7 +1006,7 @@ VRG_HD float linear_to_srgb(float v, const PowTables& T) {
 }
 VRG_HD float linear_to_srgb(float v, const DevMath& M) {
     const float thr = 0.0031308f;
-    const float base = clamp_min(v, thr);
+    const float base = pow_base_min(v, thr);
     const float pw = dev_pow_ziv<DEV_POW_UNIT>(base, M.e1_24, M.logt, 0x3b4d2e1cu, 0x40800000u);                      // [0.0031308, 4]
     const float hi = 1.055f * pw - 0.055f;
     const float lo = 12.92f * v;
@@ -1033,7 +1042,7 @@ VRG_HD void linear_to_srgb3(const float v[3], float o[3], const DevMath& M) {
     const float thr = 0.0031308f;
     float base[3], pw[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) base[c] = clamp_min(v[c], thr);
+    for (int c = 0; c < 3; ++c) base[c] = pow_base_min(v[c], thr);
     dev_pow_ziv3<DEV_POW_UNIT>(base, M.e1_24, M.logt, 0x3b4d2e1cu, 0x40800000u, pw);                                  // [0.0031308, 4]
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = v[c] > thr ? 1.055f * pw[c] - 0.055f : 12.92f * v[c];
@@ -1045,7 +1054,7 @@ VRG_HD float lab_cbrt(float t, const DevMath& M) { return dev_pow_ziv<DEV_POW_UN
 template <class MATH>
 VRG_HD float lab_f(float t, const MATH& T) {
     const float thr = 0.008856f;
-    const float pw = lab_cbrt(clamp_min(t, thr), T);
+    const float pw = lab_cbrt(pow_base_min(t, thr), T);
     const float sc = 7.787f * t + (float)(4.0 / 29.0);
     return t > thr ? pw : sc;
 }
@@ -1061,7 +1070,7 @@ VRG_HD void lab_f3(const float t[3], float o[3], const DevMath& M) {
     const float thr = 0.008856f;
     float base[3], pw[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) base[c] = clamp_min(t[c], thr);
+    for (int c = 0; c < 3; ++c) base[c] = pow_base_min(t[c], thr);
     dev_pow_ziv3<DEV_POW_UNIT, UNIT>(base, M.e1_3, M.logt, 0x3c1118c2u, 0x40800000u, pw);                             // [0.008856, 4]
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = t[c] > thr ? pw[c] : 7.787f * t[c] + (float)(4.0 / 29.0);
