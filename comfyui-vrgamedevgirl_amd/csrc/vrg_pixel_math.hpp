@@ -915,14 +915,19 @@ VRG_HD float dev_pow_ziv(float x, float y, const float* T, uint32_t lo_bits, uin
 // Three powers with one exponent (the three channels of a Lab transform): the three fast routes first, as straight-line code --
 // three independent chains for the scheduler to interleave, the three table reads in flight together -- then the (rare)
 // transcription per channel.  Same values as three dev_pow_ziv calls.
+// Contract: every x[c] >= the domain's lower end lo (the callers' pow_base_min(., lo)); IN_DOMAIN: also <= its upper end.
 template <int GUARD, bool IN_DOMAIN = false>
 VRG_HD void dev_pow_ziv3(const float x[3], float y, const float* T, uint32_t lo_bits, uint32_t hi_bits, float o[3]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (T) {
+        // the three bases arrive clamped from below to the domain's lower end (pow_base_min at every call site): what is left of the domain
+        // test is ONE comparison of the largest of them with the upper end -- two instructions for the triple instead of two per channel
+        // (a triple with one base above the domain sends its three channels to the transcription: same values)
         float r0, r1, r2;
-        const bool s0 = ziv_try<IN_DOMAIN>(x[0], y, T, lo_bits, hi_bits, r0);
-        const bool s1 = ziv_try<IN_DOMAIN>(x[1], y, T, lo_bits, hi_bits, r1);
-        const bool s2 = ziv_try<IN_DOMAIN>(x[2], y, T, lo_bits, hi_bits, r2);
+        const bool dom = IN_DOMAIN || __builtin_fmaxf(__builtin_fmaxf(x[0], x[1]), x[2]) <= f32_from_bits(hi_bits);
+        const bool s0 = ziv_try<true>(x[0], y, T, lo_bits, hi_bits, r0) & dom;
+        const bool s1 = ziv_try<true>(x[1], y, T, lo_bits, hi_bits, r1) & dom;
+        const bool s2 = ziv_try<true>(x[2], y, T, lo_bits, hi_bits, r2) & dom;
         o[0] = r0; o[1] = r1; o[2] = r2;
 #if defined(VRG_LAB_VARIANT_SOURCE) && defined(LAB_ZIV_NO_FALLBACK)
         if (s0 | s1 | s2 | true) return;

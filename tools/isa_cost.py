@@ -19,6 +19,9 @@ ap.add_argument("--source", default="")
 ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r06_valu_instruction_costs.json"))
 ap.add_argument("--json", default="")
 ap.add_argument("--list", action="store_true", help="list the loops of the kernel and stop")
+ap.add_argument("--label", default="", help="price the lines from this label to the LAST backward branch to it (a loop whose body holds conditional blocks is not 'innermost' for --loop); "
+                "blocks that are skipped at run time (the powers' transcriptions) are counted as if executed: an upper bound")
+ap.add_argument("--exclude-after", default="", help="with --label: comma-separated opcodes; a line range s_cbranch_execz X .. X: that contains one of them is left out (e.g. v_rcp_f32 = the transcriptions of ocml powf)")
 ap.add_argument("extra", nargs="*")
 a, unknown = ap.parse_known_args()
 extra = list(a.extra) + unknown
@@ -67,12 +70,35 @@ for j, l in enumerate(lines):
             loops.append((i, j))
 inner = [(i, j) for (i, j) in loops if not any((i2 > i or j2 < j) and i2 >= i and j2 <= j for (i2, j2) in loops if (i2, j2) != (i, j))]
 inner.sort(key=lambda ij: ij[0] - ij[1])
-if a.list or not inner:
+if a.list or (not inner and not a.label):
     for k, (i, j) in enumerate(inner):
         print(f"loop {k}: {lines[i]} .. line {j}: {j - i} lines")
+    outer = {}
+    for (i, j) in loops:
+        outer[i] = max(outer.get(i, 0), j)
+    for i, j in sorted(outer.items(), key=lambda ij: ij[0] - ij[1])[:8]:
+        print(f"label {lines[i]} .. last backward branch at line {j}: {j - i} lines   (--label)")
     raise SystemExit(0)
-i, j = inner[a.loop]
-ops = [l for l in lines[i:j + 1] if not l.endswith(":")]
+if a.label:
+    i = labels[a.label.rstrip(":")]
+    j = max(jj for (ii, jj) in loops if ii == i)
+    body = lines[i:j + 1]
+    if a.exclude_after:
+        marks = a.exclude_after.split(",")
+        keep, k = [], 0
+        while k < len(body):
+            m = re.match(r"s_cbranch_execz\s+(\.LBB\w+)", body[k])
+            if m and (m.group(1) + ":") in body[k:]:
+                end = k + body[k:].index(m.group(1) + ":")
+                if any(any(x.split()[0].startswith(mk) for mk in marks) for x in body[k + 1:end] if not x.endswith(":")):
+                    keep.append(body[k]); k = end
+                    continue
+            keep.append(body[k]); k += 1
+        body = keep
+    ops = [l for l in body if not l.endswith(":")]
+else:
+    i, j = inner[a.loop]
+    ops = [l for l in lines[i:j + 1] if not l.endswith(":")]
 hist = collections.Counter()
 for l in ops:
     op = l.split()[0]
