@@ -2,6 +2,7 @@
 // k_apply_march (round 3's fused stage kernel, tools/experiments/vrg_stage.hip.txt, ran it as a workgroup role).
 #pragma once
 #include "vrg_chain_stages.hpp"
+#include "vrg_lanes.hpp"
 
 namespace vrg {
 
@@ -10,12 +11,10 @@ constexpr int APPLY_ROWS = VRG_APPLY_ROWS;
 constexpr int APPLY_COLS = 62;                    // output columns per wave
 static_assert(APPLY_ROWS % 3 == 0, "APPLY_ROWS must be a multiple of 3");
 
-__device__ __forceinline__ float am_prev(float v) {   // value held by lane-1 (lane 0: unused)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float am_next(float v) {   // value held by lane+1 (lane 63: unused)
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
-}
+// value held by lane-1 / lane+1 (lane 0 / lane 63 read 0.0: halo lanes, their results are never stored).  The bound_ctrl form without an
+// `old` operand (vrg_lanes.hpp): the update_dpp(0, ...) form cost one v_mov_b32 v, 0 per shift on top of the v_mov_b32_dpp
+__device__ __forceinline__ float am_prev(float v) { return tap_prev(v); }
+__device__ __forceinline__ float am_next(float v) { return tap_next(v); }
 
 struct AmRow { float l[3], c[3], r[3]; };               // one processed row: left tap, own value, right tap per channel
 

@@ -58,6 +58,21 @@ VRG_HD float clamp01(float v) {
     return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
 #endif
 }
+// clamp01 of a pixel's three values.  The NaN pass-through costs a compare and a select per value; a NaN in any of the three makes their
+// SUM a NaN (so does +Inf next to -Inf), so one comparison of the sum and a wave-uniform branch decide for the pixel: v_med3_f32 alone
+// when no lane of the wave holds a NaN (every frame of a video), clamp01 otherwise.  Same values for every input.
+VRG_HD void clamp01_3(const float v[3], float o[3]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = (v[0] + v[1]) + v[2];
+    if (__builtin_amdgcn_ballot_w64(s != s) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = __builtin_amdgcn_fmed3f(v[c], 0.0f, 1.0f);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = clamp01(v[c]);
+}
 // clamp(v, min=lo)
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
 // The base of a power whose value is only USED for v above the threshold (sRGB <-> linear, the Lab cube root: the reference evaluates
@@ -229,11 +244,28 @@ VRG_HD float grain_element(float x, float n_own, float n_green, int channel, flo
     const float d = g * I;
     return clamp01(x + d);
 }
+// the same before the clamp
+VRG_HD float grain_element_raw(float x, float n_own, float n_green, int channel, float I, float S, float T) {
+    const float gain = channel == 0 ? 2.0f : (channel == 2 ? 3.0f : 1.0f);
+    const float scaled = n_own * gain;
+    const float a = S * scaled;
+    const float b = T * n_green;
+    const float g = a + b;
+    const float d = g * I;
+    return x + d;
+}
 
 VRG_HD void grain_pixel(const float x[3], const float n[3], float I, float S, float T, float o[3]) {
     o[0] = grain_element(x[0], n[0], n[1], 0, I, S, T);
     o[1] = grain_element(x[1], n[1], n[1], 1, I, S, T);
     o[2] = grain_element(x[2], n[2], n[1], 2, I, S, T);
+}
+// the same values with the pixel's three clamps behind ONE NaN test and a wave-uniform branch (clamp01_3): for kernels whose loop
+// tolerates a conditional block (pass 1 of the colour transfer; the wave-march kernels count their memory operations by hand and keep grain_pixel)
+VRG_HD void grain_pixel_nan_branch(const float x[3], const float n[3], float I, float S, float T, float o[3]) {
+    const float r[3] = {grain_element_raw(x[0], n[0], n[1], 0, I, S, T), grain_element_raw(x[1], n[1], n[1], 1, I, S, T),
+                        grain_element_raw(x[2], n[2], n[1], 2, I, S, T)};
+    clamp01_3(r, o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1139,9 +1171,7 @@ VRG_HD void lab_to_rgb(const float lab[3], float rgb[3], const MATH& T) {
     const float lin[3] = {lr, lg, lb};
     float s3[3];
     linear_to_srgb3(lin, s3, T);
-    rgb[0] = clamp01(s3[0]);
-    rgb[1] = clamp01(s3[1]);
-    rgb[2] = clamp01(s3[2]);
+    clamp01_3(s3, rgb);
 }
 
 // matched = (lab-mu)/sigma*sigma_ref + mu_ref ; blended = K*matched + T*lab (nodes.py:112-113)

@@ -185,7 +185,7 @@ __device__ __forceinline__ void produce_lab_body(uint32_t bx, const float* __res
                 int64_t e0;
                 if (!place(m, p0, e0)) p0 = 0;
                 const float n[3] = {sn[m][p0], sn[m][p0 + 1], sn[m][p0 + 2]};
-                grain_pixel(x, n, D.I, D.S, D.T, gr);
+                grain_pixel_nan_branch(x, n, D.I, D.S, D.T, gr);
                 if (HAS_LUT) lut_fetch_issue(D.lut, gr, F);
             };
             if (VRG_PR_PIPE == 3) { request(2); request(3); }         // land under the Lab arithmetic of siblings 0 and 1
