@@ -863,14 +863,12 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
     P = __builtin_fmaf(r, P, -0.25f);
     P = __builtin_fmaf(r, P, (float)(1.0 / 3.0));
     const float tail = __builtin_fmaf(-0.5f, l, (h * r) * P);        // -l/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6
-    const float s1 = Eh + th;                                        // |Eh| >= 0.69 > |th|, or Eh = 0: fast two-sum
-    const float e1 = th - (s1 - Eh);
+    const float s1 = Eh + th;                                        // EXACT for the exponents of the domains (e = -8 .. 2): th lies on the 2^-21 grid (make_ziv_log_table.py)
     const float s2 = __builtin_fmaf(-0.5f, h, r);                    // r - h/2 (h/2 is exact): |r| >= |h/2|, fast two-sum
     const float e2 = __builtin_fmaf(-0.5f, h, r - s2);               // (-h/2) - (s2 - r)
     const float s3 = s1 + s2;                                        // s1 = 0 or |s1| >= |s2|: fast two-sum
     const float e3 = s2 - (s3 - s1);
     float low = __builtin_fmaf(ef, f32_from_bits(0x35bfbe8eu), tl);  // e * (ln2 - head) + T_lo
-    low = low + e1;
     low = low + e3;
     low = low + e2;
     low = low + tail;

@@ -7,7 +7,7 @@ e = d >> 23, m = bits((d & 0x7fffff) + 0x3f2aaaab) -- and the table is indexed b
 2^16 consecutive floats.  Entry j = {c_j, T_hi_j, T_lo_j, A_j}:
     c_j   a reciprocal of the interval with a 7-BIT significand, so that r = m * c_j - 1 is EXACT in fp32 (one FMA) for every m of
           the interval (checked here over all 2^16 of them) and |r| < 2^-6.6; c_j = 1 around m = 1 (then T = 0 and r = m - 1);
-    T_j   = -ln(c_j) as an fp32 pair hi + lo,
+    T_j   = -ln(c_j) as an fp32 pair hi + lo, hi on the 2^-21 grid so that e ln2_head + T_hi is exact for the domains' exponents,
 so that ln x = e ln2 + T_j + log1p(r).  Computed with Python's decimal at 60 digits.
 """
 from __future__ import annotations
@@ -88,7 +88,16 @@ def main():
         c, rmax = best
         worst = max(worst, rmax)
         T = -(Decimal(c).ln())
-        th = f32(T)
+        # T_hi on the 2^-21 grid: e * ln2_head (a multiple of 2^-15, |.| <= 5.6 for the exponents e = -8 .. 2 of the fast-path domains
+        # [0.0031308, 4]) + T_hi is then EXACT in fp32 (|sum| < 8: 3 + 21 bits), and ziv_log needs no error term for that sum.  T_lo
+        # carries the rest (|T - T_hi| <= 2^-22: fp32 keeps it to 2^-46).  Outside those exponents the sum may round -- those arguments
+        # are outside every domain and never take the fast path's result.
+        th = float(int((T * (1 << 21)).to_integral_value(rounding="ROUND_HALF_EVEN"))) / float(1 << 21)
+        assert f32(th) == th
+        for e in range(-9, 4):
+            exact = Fraction(e * 22713, 1 << 15) + Fraction(th)          # 0x3f317200 = 22713 * 2^-15
+            got = np.float32(np.float32(e) * np.float32(0.693145751953125)) + np.float32(th)
+            assert Fraction(float(got)) == exact, (j, e)
         # no bias around m = 1 (T = 0 there, and for |ln m| < 0.08 the distance between the two logarithms is RELATIVE to |ln x|: a
         # constant shift would widen the relative bound that dev_pow_ziv's test uses near x = 1)
         u0, u1 = cal.get("unbiased_indexes", [128, -1])
