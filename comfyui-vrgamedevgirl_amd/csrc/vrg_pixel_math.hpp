@@ -849,14 +849,16 @@ VRG_HD void ziv_table_fill(float* dst, int first, int stride) {
 // tools/make_ziv_log_table.py), and |r| >= r^2/2.
 VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out, float& A_out) {
     const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
-    const float ef = (float)(d >> 23);
+    // e * 2^23 = d with its low 23 bits cleared (one full-rate v_and_b32 for the half-rate shift), converted exactly; the factor 2^-23
+    // sits in the two constants it is multiplied by -- the same products
+    const float ef23 = (float)(int32_t)((uint32_t)d & 0xff800000u);
     const uint32_t off = (uint32_t)d & 0x007fffffu;
     const float m = f32_from_bits(off + 0x3f2aaaabu);                // [2/3, 4/3)
     const float* t = T + ((off >> 16) << 2);
     const float c = t[0], th = t[1], tl = t[2];
     A_out = t[3];
     const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (7-bit c)
-    const float Eh = ef * f32_from_bits(0x3f317200u);                // e * ln2 head (15 bits: exact product)
+    const float Eh = ef23 * f32_from_bits(0x33b17200u);              // e * ln2 head (15 bits: exact product); 0x33b17200 = 0x3f317200 * 2^-23
     const float h = r * r;
     const float l = __builtin_fmaf(r, r, -h);                        // r^2 = h + l
     float P = __builtin_fmaf(r, (float)(-1.0 / 6.0), 0.2f);
@@ -868,7 +870,7 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
     const float e2 = __builtin_fmaf(-0.5f, h, r - s2);               // (-h/2) - (s2 - r)
     const float s3 = s1 + s2;                                        // s1 = 0 or |s1| >= |s2|: fast two-sum
     const float e3 = s2 - (s3 - s1);
-    float low = __builtin_fmaf(ef, f32_from_bits(0x35bfbe8eu), tl);  // e * (ln2 - head) + T_lo
+    float low = __builtin_fmaf(ef23, f32_from_bits(0x2a3fbe8eu), tl);       // e * (ln2 - head) + T_lo; 0x2a3fbe8e = 0x35bfbe8e * 2^-23
     low = low + e3;
     low = low + e2;
     low = low + tail;
@@ -892,7 +894,9 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
 #if VRG_ZIV_REL
     // (v_max_f32 / v_min_f32: the ternaries compiled to a compare, a select and their VCC wait states each; a NaN here fails the rounding test anyway)
-    const float rel = __builtin_fmaxf(__builtin_fabsf(Lh), __builtin_fabsf(Eh)) * f32_from_bits(0x2e06f428u);      // 2^-34.92 = 1.25 x the measured maximum
+    // max(|Lh|, |Eh|) only decides for e = 0 (Eh = 0): for e != 0 |Eh| >= 0.69, the relative bound is above every A_j (<= 2^-36) and the minimum
+    // picks A_j.  |Lh| + 64 |Eh| -- one full-rate FMA with |.| modifiers for the half-rate v_max_f32 -- is |Lh| for e = 0 and >= 44 otherwise: the same delta.
+    const float rel = __builtin_fmaf(__builtin_fabsf(Eh), 64.0f, __builtin_fabsf(Lh)) * f32_from_bits(0x2e06f428u);   // 2^-34.92 = 1.25 x the measured maximum
 #if defined(__HIP_DEVICE_COMPILE__)
     return y * __builtin_amdgcn_fmed3f(rel, A, 0.0f);       // min(rel, A) of two non-negative numbers; v_min_f32 would first canonicalise the table word (a v_max_f32 A, A)
 #else
