@@ -88,10 +88,17 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
     };
     auto emit = [&](int32_t y, const AmRow& a, const AmRow& b, const AmRow& c) {
         float res[3];
+        if (STAGES & VRG_STAGE_COLORMATCH) {       // the taps left lab_to_rgb's clip (or are border zeros): [0, 1] or NaN
+            const float p[3][3][3] = {{{a.l[0], a.c[0], a.r[0]}, {b.l[0], b.c[0], b.r[0]}, {c.l[0], c.c[0], c.r[0]}},
+                                      {{a.l[1], a.c[1], a.r[1]}, {b.l[1], b.c[1], b.r[1]}, {c.l[1], c.c[1], c.r[1]}},
+                                      {{a.l[2], a.c[2], a.r[2]}, {b.l[2], b.c[2], b.r[2]}, {c.l[2], c.c[2], c.r[2]}}};
+            stencil_value3_unit(D.stencil_op, p, D.strength, D.zero_border, res);
+        } else {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float p[3][3] = {{a.l[ch], a.c[ch], a.r[ch]}, {b.l[ch], b.c[ch], b.r[ch]}, {c.l[ch], c.c[ch], c.r[ch]}};
-            res[ch] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
+            for (int ch = 0; ch < 3; ++ch) {
+                const float p[3][3] = {{a.l[ch], a.c[ch], a.r[ch]}, {b.l[ch], b.c[ch], b.r[ch]}, {c.l[ch], c.c[ch], c.r[ch]}};
+                res[ch] = stencil_value(D.stencil_op, p, D.strength, D.zero_border);
+            }
         }
         if (GENERAL) {
             if (stores && y < y0 + rows) fout[(int64_t)y * W + x] = px3{res[0], res[1], res[2]};

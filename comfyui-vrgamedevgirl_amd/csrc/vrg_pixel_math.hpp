@@ -434,7 +434,10 @@ VRG_HD void lut_pixel(const LutParams& P, const float x[3], float o[3]) {
 // ------------------------------------------------------------------------------------------
 // 3x3 stencils.  p[r][c] = tap at (y-1+r, x-1+c) after border handling (replicated or 0.0f).
 // ------------------------------------------------------------------------------------------
-VRG_HD float unsharp_value(const float p[3][3], float strength) {
+// *_raw<UNIT>: the value before the final clamp.  UNIT: every tap is in [0, 1] or NaN (pixels that left a clamp, zero borders): the nine-tap
+// sum cannot be infinite, so x / 9 needs no Inf pass-through (a NaN goes through the FMA form by itself).
+template <bool UNIT = false>
+VRG_HD float unsharp_raw(const float p[3][3], float strength) {
     // nodes.py:194-207 (numpy) and avg_pool2d's running sum share this left-assoc raster order.
     float s = p[0][0] + p[0][1];
     s = s + p[0][2];
@@ -444,14 +447,15 @@ VRG_HD float unsharp_value(const float p[3][3], float strength) {
     s = s + p[2][0];
     s = s + p[2][1];
     s = s + p[2][2];
-    const float blur = div9(s);
+    const float blur = UNIT ? VRG_DIVC(s, 9.0f) : div9(s);
     const float x = p[1][1];
     const float d = x - blur;
     const float e = strength * d;
-    return clamp01(x + e);
+    return x + e;
 }
+VRG_HD float unsharp_value(const float p[3][3], float strength) { return clamp01(unsharp_raw<false>(p, strength)); }
 
-VRG_HD float laplacian_value(const float p[3][3], float strength, int zero_border) {
+VRG_HD float laplacian_raw(const float p[3][3], float strength, int zero_border) {
     const float x = p[1][1];
     float lap;
     if (!zero_border) {
@@ -469,10 +473,11 @@ VRG_HD float laplacian_value(const float p[3][3], float strength, int zero_borde
         lap = s - p[2][1];
     }
     const float e = strength * lap;
-    return clamp01(x + e);
+    return x + e;
 }
+VRG_HD float laplacian_value(const float p[3][3], float strength, int zero_border) { return clamp01(laplacian_raw(p, strength, zero_border)); }
 
-VRG_HD float sobel_value(const float p[3][3], float strength, int zero_border) {
+VRG_HD float sobel_raw(const float p[3][3], float strength, int zero_border) {
     const float x = p[1][1];
     float gx, gy, mag;
     if (!zero_border) {
@@ -508,13 +513,23 @@ VRG_HD float sobel_value(const float p[3][3], float strength, int zero_border) {
         mag = __builtin_sqrtf(c + 1e-6f);
     }
     const float e = strength * mag;
-    return clamp01(x + e);
+    return x + e;
 }
+VRG_HD float sobel_value(const float p[3][3], float strength, int zero_border) { return clamp01(sobel_raw(p, strength, zero_border)); }
 
 VRG_HD float stencil_value(int op, const float p[3][3], float strength, int zero_border) {
     if (op == 0) return unsharp_value(p, strength);
     if (op == 1) return laplacian_value(p, strength, zero_border);
     return sobel_value(p, strength, zero_border);
+}
+// The three channels of a pixel whose taps are in [0, 1] or NaN (the colour transfer's output): the same values with the three clamps behind
+// one NaN test (clamp01_3) and the unsharp mean without its Inf pass-through
+VRG_HD void stencil_value3_unit(int op, const float p[3][3][3], float strength, int zero_border, float o[3]) {
+    float raw[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        raw[ch] = op == 0 ? unsharp_raw<true>(p[ch], strength) : (op == 1 ? laplacian_raw(p[ch], strength, zero_border) : sobel_raw(p[ch], strength, zero_border));
+    clamp01_3(raw, o);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,7 +21,8 @@ ap.add_argument("--json", default="")
 ap.add_argument("--list", action="store_true", help="list the loops of the kernel and stop")
 ap.add_argument("--label", default="", help="price the lines from this label to the LAST backward branch to it (a loop whose body holds conditional blocks is not 'innermost' for --loop); "
                 "blocks that are skipped at run time (the powers' transcriptions) are counted as if executed: an upper bound")
-ap.add_argument("--exclude-after", default="", help="with --label: comma-separated opcodes; a line range s_cbranch_execz X .. X: that contains one of them is left out (e.g. v_rcp_f32 = the transcriptions of ocml powf)")
+ap.add_argument("--exclude-after", default="", help="with --label: comma-separated substrings; a line range s_cbranch_execz X .. X: that holds one of them in any line is left out "
+                "(0x3e76c4e1 = a coefficient of ocml's epln: the transcriptions of powf; v_div_fmas_f32: the IEEE divisions behind the unscaled / FMA forms)")
 ap.add_argument("extra", nargs="*")
 a, unknown = ap.parse_known_args()
 extra = list(a.extra) + unknown
@@ -85,16 +86,23 @@ if a.label:
     body = lines[i:j + 1]
     if a.exclude_after:
         marks = a.exclude_after.split(",")
-        keep, k = [], 0
-        while k < len(body):
-            m = re.match(r"s_cbranch_execz\s+(\.LBB\w+)", body[k])
-            if m and (m.group(1) + ":") in body[k:]:
-                end = k + body[k:].index(m.group(1) + ":")
-                if any(any(x.split()[0].startswith(mk) for mk in marks) for x in body[k + 1:end] if not x.endswith(":")):
-                    keep.append(body[k]); k = end
+
+        def strip(seq):
+            """drop the innermost `s_cbranch_execz X .. X:` ranges that hold a marker (the ranges around them stay)"""
+            out, k = [], 0
+            while k < len(seq):
+                m = re.match(r"s_cbranch_execz\s+(\.LBB\w+)", seq[k])
+                if m and (m.group(1) + ":") in seq[k:]:
+                    end = k + seq[k:].index(m.group(1) + ":")
+                    inner = strip(seq[k + 1:end])
+                    out.append(seq[k])
+                    if not any(any(mk in x for mk in marks) for x in inner):
+                        out += inner
+                    k = end
                     continue
-            keep.append(body[k]); k += 1
-        body = keep
+                out.append(seq[k]); k += 1
+            return out
+        body = strip(body)
     ops = [l for l in body if not l.endswith(":")]
 else:
     i, j = inner[a.loop]
