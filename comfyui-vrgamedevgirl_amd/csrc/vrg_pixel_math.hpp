@@ -866,10 +866,10 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
     const int32_t d = (int32_t)(f32_bits(x) - 0x3f2aaaabu);
     // e * 2^23 = d with its low 23 bits cleared (one full-rate v_and_b32 for the half-rate shift), converted exactly; the factor 2^-23
     // sits in the two constants it is multiplied by -- the same products
-    const float ef23 = (float)(int32_t)((uint32_t)d & 0xff800000u);
-    const uint32_t off = (uint32_t)d & 0x007fffffu;
-    const float m = f32_from_bits(off + 0x3f2aaaabu);                // [2/3, 4/3)
-    const float* t = T + ((off >> 16) << 2);
+    const uint32_t e23 = (uint32_t)d & 0xff800000u;
+    const float ef23 = (float)(int32_t)e23;
+    const float m = f32_from_bits(f32_bits(x) - e23);                // x * 2^-e in [2/3, 4/3): (d - e23) + 0x3f2aaaab in one subtraction
+    const float* t = T + (((uint32_t)d >> 16) & 0x7fu) * 4;          // index j = bits 16 .. 22 of d
     const float c = t[0], th = t[1], tl = t[2];
     A_out = t[3];
     const float r = __builtin_fmaf(m, c, -1.0f);                     // exact (7-bit c)
