@@ -60,16 +60,28 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
     const bool stores = lane >= 1 && lane <= APPLY_COLS && x_in;                 // (x_in: frames narrower than a strip)
     const px3* fin = in + f * ppf;
     px3* fout = out + f * ppf;
-    __amdgpu_buffer_rsrc_t frame_rsrc;
-    if (!GENERAL) {                                                              // wave-uniform frame base for the descriptor (SGPRs)
+    __amdgpu_buffer_rsrc_t frame_rsrc, in_rsrc;
+    if (!GENERAL) {                                                              // wave-uniform frame bases for the descriptors (SGPRs)
         const uint64_t fb = reinterpret_cast<uint64_t>(fout);
         const uint64_t fbu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fb);
         frame_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fbu), 0, (int)(ppf * 12), 0x00020000);
+        const uint64_t ib = reinterpret_cast<uint64_t>(fin);
+        const uint64_t ibu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ib >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ib);
+        in_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ibu), 0, (int)(ppf * 12), 0x00020000);
     }
     const FrameCtx FC = frame_ctx<STAGES>(D, f);
+    const uint32_t x_bytes = (uint32_t)xc * 12u;                                 // this lane's column inside a row: the loop-invariant vector offset
+    const uint32_t store_bytes = stores ? (uint32_t)x * 12u : 0x80000000u;       // the same for the store; halo lanes point past the frame
 
     auto load = [&](int32_t y) {                                                  // raw pixel of row y (clamped), this lane's column
         const int32_t yc = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        if (!GENERAL) {
+            // the row's byte offset is wave-uniform (the descriptor's scalar offset), the column's is loop-invariant: no vector arithmetic
+            // per row, where the 64-bit address of a global load cost two v_mad_u64_u32 and two moves
+            typedef unsigned u3 __attribute__((ext_vector_type(3)));
+            const u3 v = __builtin_amdgcn_raw_buffer_load_b96(in_rsrc, (int)x_bytes, (int)((uint32_t)(yc * W) * 12u), 0);
+            return px3{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z)};
+        }
         return fin[(int64_t)yc * W + xc];
     };
     auto process = [&](const px3& v, int32_t y) {                                 // pre stages + the row's left / right taps
@@ -104,8 +116,9 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
             if (stores && y < y0 + rows) fout[(int64_t)y * W + x] = px3{res[0], res[1], res[2]};
         } else {
             typedef unsigned u3 __attribute__((ext_vector_type(3)));
-            const uint32_t voff = stores ? (uint32_t)(y * W + x) * 12u : 0x80000000u;       // halo lanes: out of range, dropped
-            __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])}, frame_rsrc, (int)voff, 0, 0);
+            // halo lanes: a vector offset out of range, dropped by the hardware; the row's offset is the scalar one (y < H: the sum stays below 2^31 + 2^31)
+            __builtin_amdgcn_raw_buffer_store_b96(u3{__float_as_uint(res[0]), __float_as_uint(res[1]), __float_as_uint(res[2])}, frame_rsrc, (int)store_bytes,
+                                                  (int)((uint32_t)(y * W) * 12u), 0);
         }
     };
 
