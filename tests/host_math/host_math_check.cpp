@@ -121,6 +121,25 @@ static vrg::DevMath host_dev_math_() { return vrg::DevMath{(float)2.4, (float)(1
 void hm_dev_pow(const float* x, float* o, int64_t n, float y) {
     for (int64_t i = 0; i < n; ++i) o[i] = vrg::dev_pow(x[i], y);
 }
+// dev_exp_core against its integer-scaling form (round 6): the magic-number rint and the exponent-field add are plain C, so the two must be
+// bit-equal on the host wherever the form's preconditions hold
+void hm_exp_cores(const float* x, float* plain, float* normal, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) { plain[i] = vrg::dev_exp_core(x[i]); normal[i] = vrg::dev_exp_core_normal(x[i]); }
+}
+// The Ziv route on the host: the candidate of the table logarithm, whether its rounding test passes, and the transcription's value.  The
+// half-widths A_j are calibrated against the DEVICE's logarithm (v_rcp_f32 inside ocml's epln; here an IEEE reciprocal), so equality of
+// the passing lanes is expected in all but a handful of arguments: what the CPU suite holds is the table and the arithmetic around it.
+void hm_ziv(const float* x, float* cand, float* passed, float* transcription, int64_t n, float y, uint32_t lo_bits, uint32_t hi_bits) {
+    static float table[ZIV_TABLE_WORDS];
+    static bool init = false;
+    if (!init) { ziv_table_fill(table, 0, 1); init = true; }
+    for (int64_t i = 0; i < n; ++i) {
+        float r;
+        passed[i] = vrg::ziv_try(x[i], y, table, lo_bits, hi_bits, r) ? 1.0f : 0.0f;
+        cand[i] = r;
+        transcription[i] = vrg::dev_pow_t<vrg::DEV_POW_UNIT>(x[i], y);
+    }
+}
 void hm_rgb_to_lab_dev(const float* x, float* o, int64_t pixels) {
     for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p, host_dev_math_());
 }

@@ -42,6 +42,8 @@ def hm(tmp_path_factory):
     lib.hm_dev_pow.argtypes = [F32P, F32P, C.c_int64, C.c_float]
     lib.hm_rgb_to_lab_dev.argtypes = [F32P, F32P, C.c_int64]
     lib.hm_lab_to_rgb_dev.argtypes = [F32P, F32P, C.c_int64]
+    lib.hm_exp_cores.argtypes = [F32P, F32P, F32P, C.c_int64]
+    lib.hm_ziv.argtypes = [F32P, F32P, F32P, F32P, C.c_int64, C.c_float, C.c_uint32, C.c_uint32]
     lib.hm_divc_mismatches.argtypes = [F32P, C.c_int64, C.c_int]
     lib.hm_divc_mismatches.restype = C.c_int64
     return lib
@@ -313,3 +315,41 @@ def _one(hm, x, y):
     o = np.empty(1, np.float32)
     hm.hm_dev_pow(a, o, 1, f32(y))
     return o[0]
+
+
+def test_exp_core_with_integer_scaling_equals_the_plain_form(hm):
+    """dev_exp_core_normal (round 6): rint(ph) as (ph + 1.5 * 2^23) - 1.5 * 2^23 and ldexp as an integer add to the exponent field.  On the
+    host both forms call the same exp2f, so every difference would be the new form's own: bit-equal for every argument the Ziv route can
+    hand it (|y ln x| <= 12 in its domains; checked to +-60, ties of the rounding included)."""
+    rng = np.random.default_rng(8)
+    x = np.concatenate([rng.uniform(-60.0, 60.0, 2_000_000), (np.arange(-80, 81) + 0.5) * np.log(2.0), np.arange(-80, 81) * np.log(2.0),
+                        [0.0, -0.0, 1e-30, -1e-30, 12.0, -12.0]]).astype(np.float32)
+    a, b = np.empty_like(x), np.empty_like(x)
+    hm.hm_exp_cores(x, a, b, x.size)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("y,lo,hi", [(2.4, 0.0625, 2.0), (1 / 2.4, 0.0031308, 4.0), (1 / 3.0, 0.008856, 4.0)])
+def test_ziv_route_on_the_host(hm, y, lo, hi):
+    """The table logarithm of dev_pow_ziv (csrc/vrg_ziv_log_table.inc, T_hi on the 2^-21 grid), its product / exp / final FMA and the rounding
+    test, against the transcription of ocml powf, both compiled for the host.  The half-widths are calibrated against the DEVICE's logarithm
+    (its reciprocal is v_rcp_f32, here IEEE), so a passing lane may differ from the host transcription in rare arguments -- but a wrong table
+    word, a dropped term or a broken test shows as thousands: <= 5 per million passing lanes differ (measured: 0 of 4 million per exponent),
+    >= 99.9 % pass (measured 99.975-99.99 %), and no candidate is further than one ulp from the transcription."""
+    rng = np.random.default_rng(12)
+    lo_b, hi_b = int(np.float32(lo).view(np.uint32)), int(np.float32(hi).view(np.uint32))
+    x = np.concatenate([np.exp(rng.uniform(np.log(lo), np.log(hi), 1_000_000)), rng.uniform(lo, min(hi, 1.2), 1_000_000), [lo, hi, 1.0, 0.99999994, 1.0000001]]).astype(np.float32)
+    x = np.clip(x, np.float32(lo), np.float32(hi))
+    cand, ok, ref = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    hm.hm_ziv(x, cand, ok, ref, x.size, f32(y), lo_b, hi_b)
+    passed = ok == 1
+    assert passed.mean() >= 0.999, passed.mean()
+    differ = cand[passed].view(np.uint32) != ref[passed].view(np.uint32)
+    assert differ.sum() <= 5e-6 * passed.sum(), (int(differ.sum()), int(passed.sum()))
+    ulps = np.abs(cand.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+    assert ulps.max() <= 1, ulps.max()
+    # outside the domain the test must fail
+    out = np.array([lo * 0.5, hi * 2.0, 1e-20, 1e20], np.float32)
+    c2, o2, r2 = np.empty_like(out), np.empty_like(out), np.empty_like(out)
+    hm.hm_ziv(out, c2, o2, r2, out.size, f32(y), lo_b, hi_b)
+    assert not o2.any()
