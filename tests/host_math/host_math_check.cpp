@@ -140,6 +140,15 @@ void hm_ziv(const float* x, float* cand, float* passed, float* transcription, in
         transcription[i] = vrg::dev_pow_t<vrg::DEV_POW_UNIT>(x[i], y);
     }
 }
+// (lab - mean) / std in the unscaled form (round 6), with the host's IEEE reciprocal where the device has v_rcp_f32
+void hm_div_sigma(const float* d, const float* sd, float* unscaled, float* ieee, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        const float ms[6] = {1.0f, sd[i], 1.0f, sd[i], 1.0f, sd[i]};
+        const vrg::SigmaRecip R = vrg::sigma_recip(ms);
+        unscaled[i] = vrg::div_sigma_unscaled(d[i], sd[i], R.y1[0]);
+        ieee[i] = d[i] / sd[i];
+    }
+}
 void hm_rgb_to_lab_dev(const float* x, float* o, int64_t pixels) {
     for (int64_t p = 0; p < pixels; ++p) rgb_to_lab(x + 3 * p, o + 3 * p, host_dev_math_());
 }

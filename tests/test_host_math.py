@@ -44,6 +44,7 @@ def hm(tmp_path_factory):
     lib.hm_lab_to_rgb_dev.argtypes = [F32P, F32P, C.c_int64]
     lib.hm_exp_cores.argtypes = [F32P, F32P, F32P, C.c_int64]
     lib.hm_ziv.argtypes = [F32P, F32P, F32P, F32P, C.c_int64, C.c_float, C.c_uint32, C.c_uint32]
+    lib.hm_div_sigma.argtypes = [F32P, F32P, F32P, F32P, C.c_int64]
     lib.hm_divc_mismatches.argtypes = [F32P, C.c_int64, C.c_int]
     lib.hm_divc_mismatches.restype = C.c_int64
     return lib
@@ -353,3 +354,18 @@ def test_ziv_route_on_the_host(hm, y, lo, hi):
     c2, o2, r2 = np.empty_like(out), np.empty_like(out), np.empty_like(out)
     hm.hm_ziv(out, c2, o2, r2, out.size, f32(y), lo_b, hi_b)
     assert not o2.any()
+
+
+def test_unscaled_sigma_division_structure_on_the_host(hm):
+    """div_sigma_unscaled (round 6) is the backend's division sequence minus its scalings and fix-up.  On the host the reciprocal is IEEE
+    instead of v_rcp_f32, which only makes the Newton / Markstein steps start closer: the five FMAs must return the correctly rounded
+    quotient for every ordinary operand pair (a wrong sign, a swapped operand or a missing step would not); bit-equality with the
+    DEVICE's division is the GPU suite's test."""
+    rng = np.random.default_rng(21)
+    n = 2_000_000
+    d = ((rng.random(n) - 0.4) * 250.0).astype(np.float32)
+    sd = np.exp(rng.uniform(np.log(1e-5), np.log(90.0), n)).astype(np.float32)
+    d[:5] = [0.0, 1.0, -1.0, 2.0 ** -80, 2.0 ** 39]
+    a, b = np.empty_like(d), np.empty_like(d)
+    hm.hm_div_sigma(d, sd, a, b, n)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a.view(np.uint32) != b.view(np.uint32)).sum())
