@@ -897,8 +897,9 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 // Half-width of the interval that contains ocml's y ln x around this function's: y * |ln x (ocml) - ln x (table)|.  The two
 // logarithms are deterministic functions of x, so their distance has an exact maximum over a finite domain.  Almost all of it is
 // ocml's own error (its epln is good to 2^-34.7, the table log to 2^-37.3), a smooth function of m: the table's T_lo_j carries the
-// midpoint of that distance over the arguments with table index j (so the table tracks OCML's logarithm), and its fourth word A_j =
-// 1.25 x the largest distance left for index j, measured over EVERY fp32 of [0.0031308, 4] (tools/ziv_per_index.py ->
+// midpoint of that distance over the arguments with table index j (so the table tracks OCML's logarithm), and its fourth word holds A_j =
+// 1.25 x the largest distance left for index j (divided by the relative bound's constant, see VRG_ZIV_REL_BITS), measured over EVERY
+// fp32 of [0.0031308, 4] (tools/ziv_per_index.py ->
 // tools/ziv_calibration.json; 2^-38.8 for the median index, 2^-36.2 for the worst, where one global bound used to stand at
 // 2^-35.7).  Near x = 1 -- the indexes around m = 1 carry no bias -- the distance is relative to |ln x|: the second bound, 1.25 x the
 // measured global maximum relative to max(|e ln2|, |ln x|) (2^-35.25 with this table).  It is not optional: saturated pixels
@@ -906,20 +907,24 @@ VRG_HD void ziv_log(float x, const float* T, float& Lh, float& Ll, float& Eh_out
 // wave (VRG_ZIV_REL = 0: 928 instead of 709 instructions per pixel).  (The +-delta additions and ocml's own last roundings are
 // five orders of magnitude smaller.)
 #define VRG_ZIV_REL 1
-VRG_HD float ziv_delta(float y, float Lh, float Eh, float A) {
+// The relative bound's constant C = 2^-34.92 = 1.25 x the measured maximum.  The table's fourth word holds A_j / C (rounded up), so that
+// the half-width is C * min(|Lh| + 64 |Eh|, A_j / C) and the factor C joins y in ONE loop-invariant product (ziv_try): no multiply here.
+#define VRG_ZIV_REL_BITS 0x2e06f428u
+// (returns the half-width of the LOGARITHM's interval in units of C; ziv_try scales it by y * C inside the two FMAs that form the interval's ends)
+VRG_HD float ziv_delta(float Lh, float Eh, float A_over_C) {
 #if VRG_ZIV_REL
-    // (v_max_f32 / v_min_f32: the ternaries compiled to a compare, a select and their VCC wait states each; a NaN here fails the rounding test anyway)
     // max(|Lh|, |Eh|) only decides for e = 0 (Eh = 0): for e != 0 |Eh| >= 0.69, the relative bound is above every A_j (<= 2^-36) and the minimum
-    // picks A_j.  |Lh| + 64 |Eh| -- one full-rate FMA with |.| modifiers for the half-rate v_max_f32 -- is |Lh| for e = 0 and >= 44 otherwise: the same delta.
-    const float rel = __builtin_fmaf(__builtin_fabsf(Eh), 64.0f, __builtin_fabsf(Lh)) * f32_from_bits(0x2e06f428u);   // 2^-34.92 = 1.25 x the measured maximum
+    // picks A_j.  |Lh| + 64 |Eh| -- one full-rate FMA with |.| modifiers for the half-rate v_max_f32 -- is |Lh| for e = 0 and >= 44 otherwise: the same bound.
+    // (a NaN here fails the rounding test anyway)
+    const float rel = __builtin_fmaf(__builtin_fabsf(Eh), 64.0f, __builtin_fabsf(Lh));
 #if defined(__HIP_DEVICE_COMPILE__)
-    return y * __builtin_amdgcn_fmed3f(rel, A, 0.0f);       // min(rel, A) of two non-negative numbers; v_min_f32 would first canonicalise the table word (a v_max_f32 A, A)
+    return __builtin_amdgcn_fmed3f(rel, A_over_C, 0.0f);    // min of two non-negative numbers; v_min_f32 would first canonicalise the table word (a v_max_f32 A, A)
 #else
-    return y * __builtin_fminf(rel, A);
+    return __builtin_fminf(rel, A_over_C);
 #endif
 #else
     (void)Lh; (void)Eh;
-    return y * A;
+    return A_over_C;
 #endif
 }
 
@@ -932,8 +937,9 @@ VRG_HD bool ziv_try(float x, float y, const float* T, uint32_t lo_bits, uint32_t
     const float p17 = y * Lh;
     const float p24 = __builtin_fmaf(y, Lh, -p17);
     const float p44 = __builtin_fmaf(y, Ll, p24);
-    const float delta = ziv_delta(y, Lh, Eh, A);
-    const float up = p44 + delta, dn = p44 - delta;
+    const float yc = y * f32_from_bits(VRG_ZIV_REL_BITS);            // loop-invariant (y is a kernel argument)
+    const float dl = ziv_delta(Lh, Eh, A);
+    const float up = __builtin_fmaf(yc, dl, p44), dn = __builtin_fmaf(-yc, dl, p44);    // p44 +- y * half-width, one rounding each
     const float php = p17 + up;
     const float phm = p17 + dn;
     const float t = php - p17;                                       // exact; ocml's tail is y ln x - head = (p44 -+ ...) - t

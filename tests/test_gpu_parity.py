@@ -613,11 +613,11 @@ def test_ziv_interval_covers_the_distance_between_the_two_logarithms(pkg, dev):
     inc = open(os.path.join(PKG_DIR, "csrc", "vrg_ziv_log_table.inc")).read()
     words = re.findall(r"\{0x([0-9a-f]{8})u, 0x([0-9a-f]{8})u, 0x([0-9a-f]{8})u, 0x([0-9a-f]{8})u\}", inc)
     assert len(words) == 128
-    A = np.array([int(w[3], 16) for w in words], dtype=np.uint32).view(np.float32).astype(np.float64)
+    rel_const = float(np.array([0x2e06f428], dtype=np.uint32).view(np.float32)[0])      # VRG_ZIV_REL_BITS
+    A = np.array([int(w[3], 16) for w in words], dtype=np.uint32).view(np.float32).astype(np.float64) * rel_const       # the fourth word holds A_j / C
     measured = np.array(per["per_j_abs_max"])
     assert (measured > 0).all() and (measured * 1.2 <= A).all(), (measured * 1.2 / A).max()
     assert A.max() <= 2.0 ** -36.0 and np.median(A) <= 2.0 ** -38.5                      # what the per-index bound buys over the global 2^-35.7
-    rel_const = float(np.array([0x2e06f428], dtype=np.uint32).view(np.float32)[0])      # ziv_delta()
     src = open(os.path.join(PKG_DIR, "csrc", "vrg_pixel_math.hpp")).read()
     assert "0x2e06f428u" in src
     assert per["global_rel"] * 1.2 <= rel_const, per["global_rel_log2"]

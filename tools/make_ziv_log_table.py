@@ -4,7 +4,7 @@
 
 The argument is split like ocml's epln does, x = m * 2^e with m in [2/3, 4/3) -- from the bit pattern: d = bits(x) - 0x3f2aaaab,
 e = d >> 23, m = bits((d & 0x7fffff) + 0x3f2aaaab) -- and the table is indexed by j = (d & 0x7fffff) >> 16: 128 intervals of
-2^16 consecutive floats.  Entry j = {c_j, T_hi_j, T_lo_j, A_j}:
+2^16 consecutive floats.  Entry j = {c_j, T_hi_j, T_lo_j, A_j / C}:
     c_j   a reciprocal of the interval with a 7-BIT significand, so that r = m * c_j - 1 is EXACT in fp32 (one FMA) for every m of
           the interval (checked here over all 2^16 of them) and |r| < 2^-6.6; c_j = 1 around m = 1 (then T = 0 and r = m - 1);
     T_j   = -ln(c_j) as an fp32 pair hi + lo, hi on the 2^-21 grid so that e ln2_head + T_hi is exact for the domains' exponents,
@@ -103,7 +103,13 @@ def main():
         u0, u1 = cal.get("unbiased_indexes", [128, -1])
         bias = 0.0 if (c == 1.0 or u0 <= j <= u1) else cal["bias"][j]
         tl = f32(T - Decimal(th) + Decimal(bias))
-        rows.append((c, th, tl, f32(cal["A"][j])))
+        # fourth word: A_j / C with C = the relative bound's constant (vrg_pixel_math.hpp VRG_ZIV_REL_BITS), rounded UP: the kernel forms
+        # C * min(|ln x| + 64 |e ln2|, A_j / C) with C folded into one loop-invariant factor
+        Cc = float(np.array([0x2E06F428], dtype=np.uint32).view(np.float32)[0])
+        a_over_c = np.float32(cal["A"][j] / Cc)
+        if float(a_over_c) * Cc < cal["A"][j]:
+            a_over_c = np.nextafter(a_over_c, np.float32(np.inf))
+        rows.append((c, th, tl, float(a_over_c)))
         # ziv_log adds e ln2 + T_j and r - r^2/2 with the three-operation two-sum: needs a zero first operand or |first| >= |second|
         rj, _ = exact_r(mbits, c)
         s2max = float(np.abs(rj - 0.5 * rj * rj).max()) * (1.0 + 2.0 ** -20)
@@ -112,8 +118,8 @@ def main():
             assert s1 == 0.0 or abs(float(s1)) >= s2max, (j, e, float(s1), s2max)
     assert worst < 2.0 ** -6.5, worst
     lines = ["// generated by tools/make_ziv_log_table.py -- do not edit",
-             "// {bits(c_j), bits(T_hi_j), bits(T_lo_j), bits(A_j)}: c_j a 7-bit reciprocal of interval j of m in [2/3, 4/3), T_j = -ln(c_j) + the",
-             "// calibration bias towards ocml's logarithm, A_j = half-width of the rounding test for index j (tools/ziv_calibration.json);",
+             "// {bits(c_j), bits(T_hi_j), bits(T_lo_j), bits(A_j / C)}: c_j a 7-bit reciprocal of interval j of m in [2/3, 4/3), T_j = -ln(c_j) + the",
+             "// calibration bias towards ocml's logarithm, A_j = half-width of the rounding test for index j (tools/ziv_calibration.json), C = 0x2e06f428 (the relative bound);",
              "// max |m * c_j - 1| = %.6f (exact in fp32 for every m, checked by the generator)" % worst,
              "static constexpr unsigned VRG_ZIV_LOGT[128][4] = {"]
     for c, th, tl, aj in rows:
