@@ -89,10 +89,18 @@ __device__ __forceinline__ void apply_march_body(uint32_t vblock, uint32_t vgrid
         const float xi[3] = {v.r, v.g, v.b};
         float o[3];
         chain_apply_stages<STAGES>(D, FC, xi, n0, o, PT);
-        const bool inside = x_in && y >= 0 && y < H;
+        r.c[0] = o[0]; r.c[1] = o[1]; r.c[2] = o[2];                              // replicate border = the clamped coordinate's own value
+        if (zero) {
+            // zero border (the reference's use_gpu flag): pixels outside the frame count as 0.  A wave-uniform branch that the optimiser must
+            // keep (the empty volatile asm cannot be speculated): as three selects in the straight line it cost every row of the default,
+            // replicated, border three v_cndmask_b32
+            asm volatile("" ::: "memory");
+            const bool inside = x_in && y >= 0 && y < H;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r.c[c] = inside ? r.c[c] : 0.0f;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            r.c[c] = (zero && !inside) ? 0.0f : o[c];                             // replicate border = the clamped coordinate's own value
             r.l[c] = am_prev(r.c[c]);
             r.r[c] = am_next(r.c[c]);
         }

@@ -1019,6 +1019,27 @@ VRG_HD float cm_div_tensor(float x, float c, float rc, const DevMath&) {
     return x / c;
 }
 #define VRG_CM_DIVT(x, c, M) ::vrg::cm_div_tensor((x), (c), 1.0f / (c), (M))
+// X / Xn and Z / Zn of a pixel whose RGB is in [0, 1 + 2^-22] or NaN (rgb_to_lab_unit): both numerators are sums of non-negative products, at
+// most 1.0001 -- never negative, never -0, never above the proven range.  What is left of the range test is "not in (0, 1e-30)": on the bit
+// patterns of non-negative numbers, (bits - 1) >= bits(1e-30) - 1 as UNSIGNED integers (+0 wraps to the top; a NaN passes, and the FMA form
+// hands a NaN on as the division does): an add and a compare per value instead of a subtraction and two compares; one ballot for the pair.
+VRG_HD void cm_div_white_unit(float X, float Z, float& Xo, float& Zo, const PowTables& M) {
+    Xo = cm_div_tensor(X, 0.95047f, 1.0f / 0.95047f, M);
+    Zo = cm_div_tensor(Z, 1.08883f, 1.0f / 1.08883f, M);
+}
+VRG_HD void cm_div_white_unit(float X, float Z, float& Xo, float& Zo, const DevMath&) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = 0x0da24260u - 1u;                             // bits(1e-30f) - 1
+    const bool proven = ((f32_bits(X) - 1u) >= k) & ((f32_bits(Z) - 1u) >= k);
+    if (__builtin_amdgcn_ballot_w64(!proven) == 0) {
+        Xo = div_const(X, 0.95047f, 1.0f / 0.95047f);
+        Zo = div_const(Z, 1.08883f, 1.0f / 1.08883f);
+        return;
+    }
+#endif
+    Xo = X / 0.95047f;
+    Zo = Z / 1.08883f;
+}
 
 VRG_HD float srgb_to_linear(float v, const PowTables& T) {
     const float t = v + 0.055f;
@@ -1149,9 +1170,15 @@ VRG_HD void rgb_to_lab_t(const float rgb[3], float lab[3], const MATH& T) {
     float lin[3];
     srgb_to_linear3<UNIT>(rgb, lin, T);
     const float r = lin[0], g = lin[1], b = lin[2];
-    const float X = VRG_CM_DIVT(dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), 0.95047f, T);
+    float X, Z;
+    const float Xs = dot3(0.412453f, r, 0.357580f, g, 0.180423f, b), Zs = dot3(0.019334f, r, 0.119193f, g, 0.950227f, b);
+    if (UNIT) {
+        cm_div_white_unit(Xs, Zs, X, Z, T);
+    } else {
+        X = VRG_CM_DIVT(Xs, 0.95047f, T);
+        Z = VRG_CM_DIVT(Zs, 1.08883f, T);
+    }
     const float Y = dot3(0.212671f, r, 0.715160f, g, 0.072169f, b);   // / 1.0
-    const float Z = VRG_CM_DIVT(dot3(0.019334f, r, 0.119193f, g, 0.950227f, b), 1.08883f, T);
     const float xyz[3] = {X, Y, Z};
     float f[3];
     lab_f3<UNIT>(xyz, f, T);
