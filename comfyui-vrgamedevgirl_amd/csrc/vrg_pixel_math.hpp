@@ -64,14 +64,18 @@ VRG_HD float clamp01(float v) {
 VRG_HD void clamp01_3(const float v[3], float o[3]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const float s = (v[0] + v[1]) + v[2];
-    if (__builtin_amdgcn_ballot_w64(s != s) == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = __builtin_amdgcn_fmed3f(v[c], 0.0f, 1.0f);
-        return;
+    const float a = v[0], b = v[1], c = v[2];
+    float x = __builtin_amdgcn_fmed3f(a, 0.0f, 1.0f), y = __builtin_amdgcn_fmed3f(b, 0.0f, 1.0f), z = __builtin_amdgcn_fmed3f(c, 0.0f, 1.0f);
+    if (__builtin_amdgcn_ballot_w64(s != s) != 0) {      // the rare side patches the three results in place: no copies where the sides meet
+        x = (a != a) ? a : x;
+        y = (b != b) ? b : y;
+        z = (c != c) ? c : z;
     }
-#endif
+    o[0] = x; o[1] = y; o[2] = z;
+#else
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = clamp01(v[c]);
+#endif
 }
 // clamp(v, min=lo)
 VRG_HD float clamp_min(float v, float lo) { return v < lo ? lo : v; }
