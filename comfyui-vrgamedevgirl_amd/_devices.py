@@ -469,6 +469,15 @@ class _Pending:
         self.born = time.monotonic()
         self.owner = None            # weak reference to the LazyFrames handed out
 
+    def _ensure_storage(self):
+        """A device result's buffer is given its memory when the recipe is about to run into it (see defer)."""
+        if self.host.is_cuda:
+            st = self.host.untyped_storage()
+            need = self.host.numel() * self.host.element_size()
+            if st.size() < need:
+                with torch.cuda.device(self.device):
+                    st.resize_(need)
+
     def _download(self):
         """Queue the copies of the pieces on the download stream and wait for the last one."""
         with torch.cuda.device(self.device):
@@ -508,6 +517,7 @@ class _Pending:
             if self.host.is_cuda:                                     # device-resident graph: the result buffer IS the destination
                 if isinstance(src, LazyFrames):
                     src = materialise(src)._vrg_plain()
+                self._ensure_storage()
                 fn(src.to(self.device), 0, out=self.host)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
@@ -889,7 +899,12 @@ def defer(images: torch.Tensor, device: torch.device, stage: "Stage", out_device
             pieces = _DEVICE_COPIES.lookup(images, device)      # an unchanged, already downloaded result of this pack: still in HBM
         recipe = _Recipe(images, [stage], pieces if lanes is None else None, lanes)
     if out_device.type == "cuda":
+        # a device result: its tensor exists from here on (shape, strides, device), its MEMORY from the moment the recipe runs into it
+        # (_Pending._ensure_storage) -- a node whose result only feeds the next node of the pack is fused away and never gets any.  (Four
+        # 25 GB results per graph of 256 4K frames, three of them unused, once pushed the allocator of a 288 GB device into freeing and
+        # re-mapping its cache on every graph: 599 ms instead of 49.)
         out = torch.empty(tuple(images.shape), dtype=torch.float32, device=device)
+        out.untyped_storage().resize_(0)
     else:
         pinned, out = _result_buffer(tuple(images.shape), torch.float32, nbytes)
         if not pinned:

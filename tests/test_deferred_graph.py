@@ -404,7 +404,10 @@ def test_device_resident_graph_defers_and_fuses_too(pkg, monkeypatch, counted):
     got = _graph(nodes, iv, x, ref, cm_batch=1)
     assert torch.equal(torch.cuda.get_rng_state(dev), state) and not counted
     assert all(g.is_cuda and tuple(g.shape) == tuple(x.shape) and D.pending_of(g) is not None for g in got)
+    # a deferred device result has a tensor but no memory until its recipe runs into it: a node that is fused away never gets any
+    assert all(D.pending_of(g).host.untyped_storage().size() == 0 for g in got)
     assert torch.equal(got[3], want[3]) and counted == [("fused_chain", 4)]
+    assert D.pending_of(got[2]) is not None and D.pending_of(got[2]).host.untyped_storage().size() == 0        # the last node's result ran; its inputs did not
     assert got[3].data_ptr() and D.pending_of(got[3]) is None
     assert torch.equal(got[2], want[2]) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     # a consumer that is not of this pack: any torch op on the device tensor
