@@ -586,6 +586,9 @@ def graph_leg(C, args, frames, steps, warmup):
     saved = {k: sys.modules.get(k) for k in ("comfy", "comfy.model_management")}
     sys.modules["comfy"], sys.modules["comfy.model_management"] = comfy, mm
     try:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()            # the legs before this one held up to 200 GB: start from an unfragmented pool
         x = make_frames(frames, H, W, dev, 1234, "uniform")
         ref = make_frames(1, H, W, dev, 4321, "uniform")
         N = pack.NODE_CLASS_MAPPINGS
