@@ -414,6 +414,17 @@ def test_device_resident_graph_defers_and_fuses_too(pkg, monkeypatch, counted):
     torch.manual_seed(13)
     last = _graph(nodes, iv, x, ref, cm_batch=1)[3]
     assert torch.equal((last * 1.0).cpu(), want[3].cpu())
+    # as ComfyUI runs it: inside torch.inference_mode(), the result first used by another thread outside it (the storage is sized there)
+    with torch.inference_mode():
+        torch.manual_seed(13)
+        inf = _graph(nodes, iv, x, ref, cm_batch=1)
+        assert all(D.pending_of(g).host.untyped_storage().size() == 0 for g in inf)
+    seen = []
+    th = threading.Thread(target=lambda: seen.append(D.materialise(inf[3]).cpu()))
+    th.start(); th.join()
+    assert len(seen) == 1 and torch.equal(seen[0], want[3].cpu())
+    with torch.inference_mode():
+        assert torch.equal(inf[1].cpu(), want[1].cpu())
     # device frames in, host frames out (intermediate device = cpu, the default): deferred as well, downloaded at first use
     mm.intermediate_device = lambda: torch.device("cpu")
     counted.clear()
